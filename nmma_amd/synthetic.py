@@ -1,0 +1,168 @@
+"""Seeded synthetic inputs shaped like the reference's production runs.
+
+Shapes follow SURVEY.md section 8d / BASELINE.md section 3:
+
+* SVD surrogate per filter: ``Dense(NP -> 2048, relu) -> Dense(2048 -> 10)`` fp32
+  (architecture nmma/em/training.py:353-364; weight statistics measured on the
+  reference's own trained nets ``nmma/tests/data/Bu2019nsbh_tf/*.h5``), an
+  orthonormal SVD basis ``VA[NT, NC]`` fp64, 211-point training grid
+  ``arange(0, 21.1, 0.1)`` (doc/training.md:49).
+* Photometry: AT2017gfo filter set and per-filter epoch counts taken from
+  ``example_files/lightcurves/AT2017gfo.dat`` (counts only, no data copied),
+  sigma ~ U(0.01, 0.2) mag, one upper limit (sigma = inf).
+* theta: uniform / sine draws from the ``priors/Bu2019lm.prior`` box.
+
+This module only *creates inputs* (it contains a small numpy forward of the
+surrogate, used solely to place synthetic data points on a fiducial light curve).
+It is not the oracle and not the product compute path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+#: model_parameters of the SVD families used by BASELINE.json's configs
+#: (names: nmma/em/model.py:29-87)
+MODEL_PARAMETERS = {
+    "Bu2019lm": ["log10_mej_dyn", "log10_mej_wind", "KNphi", "KNtheta"],
+    "Bu2019nsbh": ["log10_mej_dyn", "log10_mej_wind", "KNtheta"],
+    "Bu2022Ye": ["log10_mej_dyn", "vej_dyn", "Yedyn", "log10_mej_wind", "vej_wind", "KNtheta"],
+}
+
+#: surrogate input box (the prior box the grids were simulated on)
+PARAM_BOX = {
+    "log10_mej_dyn": (-3.0, -1.0), "log10_mej_wind": (-3.0, -0.5), "KNphi": (15.0, 75.0),
+    "KNtheta": (0.0, 90.0), "vej_dyn": (0.12, 0.25), "Yedyn": (0.15, 0.3),
+    "vej_wind": (0.03, 0.15),
+}
+
+AT2017GFO_FILTERS = ["ps1::g", "ps1::r", "ps1::i", "ps1::z", "ps1::y", "2massj"]
+AT2017GFO_COUNTS = {"ps1::g": 13, "ps1::r": 19, "ps1::i": 20, "ps1::z": 18, "ps1::y": 15,
+                    "2massj": 14, "2massh": 17, "2massks": 23, "sdssu": 2}
+
+
+def make_svd_model(seed, filters, model="Bu2019lm", n_hidden=2048, n_coeff=10, tt=None):
+    """Random surrogate with the statistics of a trained one.  Returns
+    ``(model_parameters, svd_model)`` with ``svd_model[filt]`` holding
+    W1,b1,W2,b2 (f32), VA[NT,NC],mins,maxs,tt,param_mins,param_maxs (f64), n_coeff."""
+    rng = np.random.default_rng(seed)
+    names = MODEL_PARAMETERS[model]
+    n_p = len(names)
+    if tt is None:
+        tt = np.arange(0.0, 21.1, 0.1)
+    n_t = len(tt)
+    pmin = np.array([PARAM_BOX[n][0] for n in names])
+    pmax = np.array([PARAM_BOX[n][1] for n in names])
+    svd = {}
+    for f in filters:
+        q, _ = np.linalg.qr(rng.standard_normal((n_t, n_t)))
+        # leading coefficient large and negative like the trained nets (range [-13, -1])
+        b2 = (0.15 * rng.standard_normal(n_coeff)).astype(np.float32)
+        svd[f] = dict(
+            W1=(0.78 * rng.standard_normal((n_p, n_hidden))).astype(np.float32),
+            b1=(0.12 * rng.standard_normal(n_hidden)).astype(np.float32),
+            W2=(0.03 * rng.standard_normal((n_hidden, n_coeff))).astype(np.float32),
+            b2=b2,
+            VA=np.ascontiguousarray(q[:, :n_coeff]),
+            mins=-18.0 + 0.1 * rng.random(n_t),
+            maxs=-8.0 + 0.1 * rng.random(n_t),
+            tt=np.array(tt, dtype=float),
+            param_mins=pmin.copy(), param_maxs=pmax.copy(), n_coeff=n_coeff,
+        )
+    return names, svd
+
+
+def flat_lcdm_grid(d_min, d_max, n=50, H0=67.66, Om0=0.30966):
+    """(dist_grid, z_grid) with the layout of nmma/core/conversion.py:49-55
+    (50 geometric redshift nodes spanning [z(d_min), z(d_max)]).  Flat LCDM
+    (matter + Lambda) by trapezoid quadrature -- an INPUT to the path, not a
+    parity claim about astropy's Planck18."""
+    c_kms = 299792.458
+
+    def d_lum(z):
+        z = np.atleast_1d(z)
+        out = np.empty_like(z)
+        for i, zi in enumerate(z):
+            zz = np.linspace(0.0, zi, 2049)
+            ez = np.sqrt(Om0 * (1 + zz) ** 3 + (1 - Om0))
+            out[i] = (1 + zi) * c_kms / H0 * np.trapezoid(1.0 / ez, zz)
+        return out
+
+    def z_at(d):
+        lo, hi = 0.0, 10.0
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            if d_lum(mid)[0] < d:
+                lo = mid
+            else:
+                hi = mid
+        return 0.5 * (lo + hi)
+
+    z_grid = np.geomspace(z_at(d_min), z_at(d_max), n)
+    return d_lum(z_grid), z_grid
+
+
+def _forward_abs_mag(svd_filt, plist):
+    """numpy forward of one filter (data synthesis only)."""
+    x = ((np.asarray(plist, float) - svd_filt["param_mins"]) /
+         (svd_filt["param_maxs"] - svd_filt["param_mins"])).astype(np.float32)
+    h = np.maximum(x @ svd_filt["W1"] + svd_filt["b1"], 0)
+    c = (h @ svd_filt["W2"] + svd_filt["b2"]).astype(np.float64)
+    return (svd_filt["VA"][:, :svd_filt["n_coeff"]] @ c) * (svd_filt["maxs"] - svd_filt["mins"]) + svd_filt["mins"]
+
+
+def make_photometry(seed, svd, model_parameters, filters=None, counts=None, fiducial=None,
+                    t_range=(0.5, 14.0), n_upper_limits=1, upper_limit_filter="ps1::i",
+                    cosmo_grid=None):
+    """AT2017gfo-shaped photometry placed on the fiducial light curve.
+    Returns ``(times, mags, sigmas)`` dicts keyed by filter (days since trigger)."""
+    rng = np.random.default_rng(seed)
+    filters = list(filters or AT2017GFO_FILTERS)
+    counts = counts or AT2017GFO_COUNTS
+    if fiducial is None:
+        fiducial = dict(log10_mej_dyn=-2.2, log10_mej_wind=-1.3, KNphi=30.0, KNtheta=25.0,
+                        vej_dyn=0.2, Yedyn=0.2, vej_wind=0.08,
+                        luminosity_distance=40.0, timeshift=0.0)
+    plist = [fiducial[k] for k in model_parameters]
+    d_l = fiducial.get("luminosity_distance", 40.0)
+    z = float(np.interp(d_l, *cosmo_grid)) if cosmo_grid is not None else 0.0
+    distmod = 5.0 * (5 + np.log10(d_l)) - 2.5 * np.log10(1 + z)
+    times, mags, sigmas = {}, {}, {}
+    for f in filters:
+        n = counts[f] if isinstance(counts, dict) else int(counts)
+        t = np.sort(rng.uniform(t_range[0], t_range[1], n))
+        sig = rng.uniform(0.01, 0.2, n)
+        tt = svd[f]["tt"]
+        m_true = np.interp((t - fiducial.get("timeshift", 0.0)) / (1 + z), tt,
+                           _forward_abs_mag(svd[f], plist)) + distmod
+        m = m_true + sig * rng.standard_normal(n)
+        if f == upper_limit_filter and n_upper_limits:
+            idx = rng.choice(n, size=n_upper_limits, replace=False)
+            sig[idx] = np.inf
+            m[idx] = m_true[idx] - 0.5       # limit brighter than the model: mild penalty
+        times[f], mags[f], sigmas[f] = t, m, sig
+    return times, mags, sigmas
+
+
+def draw_theta(seed, batch, names=None):
+    """Prior draws (``priors/Bu2019lm.prior`` box): returns ``(names, theta[B, D])``."""
+    rng = np.random.default_rng(seed)
+    names = list(names or ["luminosity_distance", "KNphi", "inclination_EM", "timeshift",
+                           "log10_mej_dyn", "log10_mej_wind"])
+    cols = []
+    for n in names:
+        if n == "luminosity_distance":
+            cols.append(rng.uniform(1.0, 200.0, batch))
+        elif n == "inclination_EM":                       # bilby Sine prior on [0, pi/2]
+            cols.append(np.arccos(1.0 - rng.uniform(0.0, 1.0, batch)))
+        elif n == "timeshift":
+            cols.append(rng.uniform(-2.0, 0.1, batch))
+        elif n.startswith("em_syserr"):
+            cols.append(rng.uniform(0.1, 2.0, batch))
+        elif n == "Ebv":
+            cols.append(rng.uniform(0.0, 0.5, batch))
+        elif n in PARAM_BOX:
+            lo, hi = PARAM_BOX[n]
+            cols.append(rng.uniform(lo, hi, batch))
+        else:
+            raise KeyError(n)
+    return names, np.stack(cols, axis=1)

@@ -1,0 +1,180 @@
+"""Named, seeded parity cases shared by the golden-vector generator
+(``tools/make_golden.py``), the oracle tests and the GPU parity tests.
+
+A case is a plain dict of *inputs* (numpy arrays, lists, floats):
+
+  model_parameters, svd (filter -> tensors), model_filters, sample_times (or None),
+  cosmo_grid (dist_grid, z_grid) or None, data (times, mags, sigmas),
+  observed_filters, detection_limit, systematics (oracle-style spec, see
+  oracle/nmma_oracle.py:OracleSystematics), systematics_ref (kwargs that make the
+  *reference's* FilterSystematicsHandler behave the same), names, theta[B, D]
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from nmma_amd import synthetic as syn
+
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _base(seed=1234, model="Bu2019lm", filters=None, counts=None, batch=64, n_hidden=2048,
+          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0)):
+    filters = list(filters or syn.AT2017GFO_FILTERS)
+    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden)
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    data = syn.make_photometry(seed + 1, svd, mp, filters=filters, counts=counts,
+                               cosmo_grid=grid, upper_limit_filter=upper_limit_filter,
+                               t_range=t_range)
+    names, theta = syn.draw_theta(seed + 2, batch, names)
+    return dict(model=model, model_parameters=mp, svd=svd, model_filters=filters,
+                sample_times=sample_times, cosmo_grid=grid, data=data,
+                observed_filters=filters, detection_limit=np.inf,
+                systematics=dict(mode="budget", values={f: 1.0 for f in filters}),
+                systematics_ref=dict(error_budget=1.0, systematics_file=None),
+                names=names, theta=theta)
+
+
+def case_c2_default():
+    """BASELINE config 2 shape: Bu2019lm, 6 AT2017gfo filters, sample_times = training grid."""
+    return _base()
+
+
+def case_c2_dt05_limit():
+    """Canonical CLI grid ``--em-tmin .1 --em-tmax 20 --em-tstep .5`` (two-stage lerp)
+    plus a finite detection limit (truncated Gaussian, -inf when m_obs > lim)."""
+    c = _base(seed=2234)
+    c["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    # a limit just above the faintest datum of most filters; below one datum of 2massj
+    lim = {f: float(np.max(c["data"][1][f]) + 0.3) for f in c["observed_filters"]}
+    c["detection_limit"] = lim
+    return c
+
+
+def case_limit_violated():
+    """One datum fainter than the detection limit -> -inf -> floor for every sample."""
+    c = _base(seed=2235, batch=8)
+    f = c["observed_filters"][1]
+    c["detection_limit"] = {g: np.inf for g in c["observed_filters"]}
+    c["detection_limit"][f] = float(np.sort(c["data"][1][f])[-2])
+    return c
+
+
+def case_syserr_param():
+    """Sampled global ``em_syserr`` (FilterSystematicsHandler.from_param)."""
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift",
+             "log10_mej_dyn", "log10_mej_wind", "em_syserr"]
+    c = _base(seed=3234, names=names)
+    c["systematics"] = dict(mode="param", name="em_syserr")
+    c["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    return c
+
+
+def case_syserr_time_nodes():
+    """Time-dependent systematics: 4 linear time nodes shared by two filter groups and
+    a single parameter for the rest (from_parameters = single + interpolated)."""
+    filters = syn.AT2017GFO_FILTERS
+    g1 = ["ps1::g", "ps1::r"]
+    nodes = np.linspace(0.0, 21.0, 4)
+    n_a = [f"em_syserr_blue_{i}" for i in range(4)]
+    n_b = [f"em_syserr_2massj_{i}" for i in range(4)]
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift",
+             "log10_mej_dyn", "log10_mej_wind", "em_syserr_rest"] + n_a + n_b
+    c = _base(seed=4234, names=names, batch=48)
+    spec_names = {f: "em_syserr_rest" for f in filters if f not in g1 + ["2massj"]}
+    spec_nodes = {f: (n_a, nodes) for f in g1}
+    spec_nodes["2massj"] = (n_b, nodes)
+    c["systematics"] = dict(mode="mixed", names=spec_names, nodes=spec_nodes)
+    c["systematics_ref"] = dict(
+        error_budget=None,
+        systematics_file={
+            "blue": {"filters": g1, "time_nodes": 4, "time_range": "lin 0.0 21.0"},
+            "2massj": {"time_nodes": 4, "time_range": "lin 0.0 21.0"},
+            "rest": {"prior": "unused"},
+        })
+    return c
+
+
+def case_averaging():
+    """Observed filters the model does not provide (``w``, ``o``, ``I``): arithmetic mean
+    of mapped model bands (em_likelihood.py:326-333), plus renamed ``B -> g``."""
+    model_filters = ["g", "r", "i", "z", "y"]
+    c = _base(seed=5234, filters=model_filters, counts=12, batch=32, upper_limit_filter="i")
+    times, mags, sigmas = c["data"]
+    rng = np.random.default_rng(99)
+    for new, src in (("w", ["g", "r", "i"]), ("o", ["r", "i"]), ("I", ["z", "y"]), ("B", ["g"])):
+        t = np.sort(rng.uniform(0.6, 13.0, 9))
+        m = np.mean([np.interp(t, times[s], mags[s]) for s in src], axis=0)
+        times[new], mags[new], sigmas[new] = t, m + 0.05 * rng.standard_normal(9), rng.uniform(0.02, 0.1, 9)
+    observed = ["g", "r", "i", "z", "y", "w", "o", "I", "B"]
+    for k in list(times):
+        if k not in observed:
+            del times[k], mags[k], sigmas[k]
+    c["observed_filters"] = observed
+    c["systematics"] = dict(mode="budget", values={f: 0.5 for f in observed})
+    c["systematics_ref"] = dict(error_budget=0.5, systematics_file=None)
+    return c
+
+
+def case_edges():
+    """timeshift / redshift pushing data out of the model window (m_est = +inf ->
+    NaN -> floor), an upper-limit-only filter and a one-point filter."""
+    c = _base(seed=6234, batch=40, t_range=(0.3, 20.5))
+    times, mags, sigmas = c["data"]
+    f_ul = c["observed_filters"][4]
+    sigmas[f_ul][:] = np.inf                                  # only upper limits
+    f_one = c["observed_filters"][5]
+    for d in (times, mags, sigmas):
+        d[f_one] = d[f_one][:1].copy()                        # single datum
+    th = c["theta"]
+    i_ts = c["names"].index("timeshift")
+    th[:10, i_ts] = np.linspace(-2.0, 0.9, 10)                # positive shift: early data lost
+    th[10:14, i_ts] = 0.3
+    return c
+
+
+def case_c4_shape():
+    """BASELINE config 4 shape: Bu2022Ye (NP=6), 12 filters x 200 epochs."""
+    filters = [f"band{i:02d}" for i in range(12)]
+    names = ["luminosity_distance", "inclination_EM", "timeshift", "log10_mej_dyn", "vej_dyn",
+             "Yedyn", "log10_mej_wind", "vej_wind"]
+    c = _base(seed=7234, model="Bu2022Ye", filters=filters, counts=200, batch=16, names=names,
+              upper_limit_filter="band03")
+    return c
+
+
+def case_small_hidden():
+    """Tiny surrogate (NH=64) for fast pure-Python loops."""
+    return _base(seed=8234, n_hidden=64, batch=16)
+
+
+CASES = {
+    "c2_default": case_c2_default,
+    "c2_dt05_limit": case_c2_dt05_limit,
+    "limit_violated": case_limit_violated,
+    "syserr_param": case_syserr_param,
+    "syserr_time_nodes": case_syserr_time_nodes,
+    "averaging": case_averaging,
+    "edges": case_edges,
+    "c4_shape": case_c4_shape,
+    "small_hidden": case_small_hidden,
+}
+
+
+def load_golden(name):
+    """Expected outputs produced by the reference's own source (tools/make_golden.py)."""
+    path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def weights_digest(svd):
+    """Order-stable checksum of a synthetic model (guards the seeded generator)."""
+    acc = 0.0
+    for f in sorted(svd):
+        for k in ("W1", "b1", "W2", "b2", "VA", "mins", "maxs"):
+            a = np.asarray(svd[f][k], dtype=np.float64)
+            acc += float(np.sum(a * np.cos(np.arange(a.size).reshape(a.shape) % 97)))
+    return acc
