@@ -1,0 +1,184 @@
+/*
+ * nmma_hip.h -- C ABI of libnmma_hip.so: the MI355X (gfx950) implementation of NMMA's
+ * per-sample electromagnetic light-curve log-likelihood, evaluated for a whole batch
+ * of parameter vectors per call.
+ *
+ * The reference (nuclear-multimessenger-astronomy/nmma v1.0.1) is pure Python and has no
+ * FFI for this path; the boundary it exposes is the pair of Python protocols
+ *   - bilby Likelihood:  nmma/core/base.py:77-82, :133-185  (log_likelihood(parameters))
+ *   - light-curve model: nmma/em/model.py:175-408, :535-731 (gen_detector_lc(parameters))
+ * which nmma_amd/em/ (Python) re-implement on top of the entry points below through ctypes
+ * (see INTEGRATION.md for the binding a maintainer would add to the reference).
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (message via
+ * nmma_last_error(), thread-local); nothing throws across the boundary; the library
+ * copies all configuration arrays during nmma_em_create (caller keeps ownership of its
+ * buffers); theta / out buffers are owned by the caller; one handle per (process, device);
+ * calls on one handle must be serialised by the caller (or issued on one stream).
+ */
+#ifndef NMMA_HIP_H
+#define NMMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMMA_ABI_VERSION 1
+#define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
+#define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
+#define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
+
+/* The value np.nan_to_num(-np.inf): nmma/core/base.py:82, :181; em_likelihood.py:194,:220,:348 */
+#define NMMA_LOGL_FLOOR (-1.7976931348623157e308)
+
+/* How one scalar the path needs is obtained from a row of theta[B, D]. */
+enum nmma_slot_op {
+    NMMA_OP_IDENT = 0,        /* v = theta[col]                                              */
+    NMMA_OP_RAD2DEG = 1,      /* v = theta[col] * 180.0 / pi   (KNtheta <- inclination_EM;
+                                 nmma/core/conversion.py:123)                                */
+    NMMA_OP_DEG2RAD = 2,      /* v = theta[col] / 180.0 * pi   (conversion.py:125)           */
+    NMMA_OP_LOG10 = 3,        /* v = log10(theta[col])         (model.py:279-280)            */
+    NMMA_OP_POW10 = 4,        /* v = 10 ** theta[col]          (model.py:281-282)            */
+    NMMA_OP_THETAJN2DEG = 5,  /* v = min(t, pi - t) * 180/pi   (conversion.py:120-123)       */
+    NMMA_OP_COSTHETAJN2DEG = 6 /* t = arccos(theta[col]) then as 5                           */
+};
+
+typedef struct nmma_slot {
+    int32_t col;     /* column of theta, or -1: use `value` (fixed / default parameter) */
+    int32_t op;      /* enum nmma_slot_op                                                */
+    double value;    /* constant used when col < 0                                       */
+} nmma_slot;
+
+enum nmma_redshift_mode {
+    NMMA_Z_ZERO = 0,      /* no distance information: z = 0 (conversion.py:62-64)            */
+    NMMA_Z_SLOT = 1,      /* sampled "redshift" (conversion.py:58-59)                         */
+    NMMA_Z_GRID = 2       /* z = interp(d_L; dist_grid, z_grid)  (model.py:262-265)           */
+};
+
+enum nmma_sys_kind {
+    NMMA_SYS_CONST = 0,   /* FilterSystematicsHandler.from_budget (systematics.py:51,:203-210) */
+    NMMA_SYS_PARAM = 1,   /* from_param / from_single_params      (systematics.py:279-286)     */
+    NMMA_SYS_NODES = 2    /* from_interpolated_params: K time nodes, constant extrapolation
+                             (systematics.py:288-291 -> utils.py:665-668)                      */
+};
+
+/* Everything static about one likelihood: surrogate tensors, time grids, photometry,
+ * systematics layout, and how theta columns map to physical parameters.
+ * All pointers are HOST pointers; arrays are dense, row-major, in the shapes given. */
+typedef struct nmma_em_config {
+    int32_t abi_version;          /* NMMA_ABI_VERSION */
+    int32_t device;               /* HIP device ordinal */
+
+    /* ---- SVD surrogate: eval_svd_model, nmma/em/lightcurve_generation.py:180-217 ---- */
+    int32_t n_model_filters;      /* M  */
+    int32_t n_params;             /* NP (<= NMMA_MAX_PARAMS) */
+    int32_t n_hidden;             /* NH (any value; padded internally) */
+    int32_t n_coeff;              /* NC (<= NMMA_MAX_COEFF) */
+    int32_t n_tt;                 /* NT: length of the SVD time grid */
+    const float* W1;              /* [M][NP][NH]  first Dense kernel (training.py:353-364) */
+    const float* b1;              /* [M][NH]                                               */
+    const float* W2;              /* [M][NH][NC]  second Dense kernel                      */
+    const float* b2;              /* [M][NC]                                               */
+    const double* VA;             /* [M][NT][NC]  svd_model["VA"][:, :NC]                  */
+    const double* mins;           /* [M][NT]                                               */
+    const double* maxs;           /* [M][NT]                                               */
+    const double* tt;             /* [M][NT]      svd_model["tt"]                          */
+    const double* param_mins;     /* [M][NP]                                               */
+    const double* param_maxs;     /* [M][NP]                                               */
+
+    /* ---- model sample times: model.py:655-660, utils.py:72-93 ---- */
+    int32_t n_sample_times;       /* NS; 0 => use tt of model filter 0 */
+    const double* sample_times;   /* [NS] strictly increasing */
+
+    /* ---- z(d_L) grid: conversion.py:49-55, model.py:255-267 ---- */
+    int32_t redshift_mode;        /* enum nmma_redshift_mode */
+    int32_t n_cosmo;              /* grid length (50 in the reference) */
+    const double* dist_grid;      /* [n_cosmo] increasing, Mpc */
+    const double* z_grid;         /* [n_cosmo] */
+
+    /* ---- theta layout: em_parameter_setup, model.py:288-303; combine_lc_params :701-705 ---- */
+    int32_t n_dim;                          /* D: columns of theta */
+    nmma_slot model_param[NMMA_MAX_PARAMS]; /* surrogate inputs in model_parameters order */
+    nmma_slot luminosity_distance;          /* default value 1e-5 Mpc (model.py:291-293)  */
+    nmma_slot redshift;                     /* used when redshift_mode == NMMA_Z_SLOT      */
+    nmma_slot timeshift;                    /* default 0 (model.py:297)                    */
+    nmma_slot ebv;                          /* default 0 (model.py:290)                    */
+
+    /* ---- extinction: ext_mag[m] = ebv_coeff[m] * Ebv when Ebv != 0 (model.py:323-350);
+     *      NULL => Ebv ignored.  Coefficients are an input (dust law is third-party). ---- */
+    const double* ebv_coeff;      /* [M] or NULL */
+
+    /* ---- photometry in the detector frame: utils.py:255-286 (days since trigger) ---- */
+    int32_t n_obs_filters;        /* O  */
+    const int32_t* data_offsets;  /* [O+1] CSR offsets into the three arrays below */
+    const double* data_times;     /* [N] */
+    const double* data_mags;      /* [N] */
+    const double* data_sigmas;    /* [N]  +inf marks an upper limit (em_likelihood.py:227-228) */
+    const double* detection_limit;/* [O]  +inf = none (em_likelihood.py:299-300)               */
+    const int32_t* n_sources;     /* [O]  1, or 2..3 for averaged bands (em_likelihood.py:326-333) */
+    const int32_t* sources;       /* [O][NMMA_MAX_SOURCES] model-filter indices */
+
+    /* ---- systematics: systematics.py:194-296 ---- */
+    const int32_t* sys_kind;      /* [O] enum nmma_sys_kind */
+    const double* sys_const;      /* [O] value for NMMA_SYS_CONST */
+    const int32_t* sys_n_nodes;   /* [O] 1 for NMMA_SYS_PARAM, K for NMMA_SYS_NODES, 0 otherwise */
+    const int32_t* sys_slot_offsets; /* [O+1] CSR offsets into sys_slots / sys_node_times */
+    const nmma_slot* sys_slots;   /* per node: where its sigma_sys comes from */
+    const double* sys_node_times; /* per node: time of the node (ignored for NMMA_SYS_PARAM) */
+} nmma_em_config;
+
+typedef struct nmma_em_handle nmma_em_handle;
+
+/* ABI / build identification. */
+int32_t nmma_abi_version(void);
+const char* nmma_build_info(void);
+const char* nmma_last_error(void);
+
+/* Replaces object construction: SVDLightCurveModel.__init__ (model.py:568-653) +
+ * MultiFilterTransient.__init__ (em_likelihood.py:290-303). */
+int32_t nmma_em_create(const nmma_em_config* cfg, nmma_em_handle** out);
+void nmma_em_destroy(nmma_em_handle* h);
+
+/* Replaces B calls of NMMALikelihoodMixin.log_likelihood (core/base.py:77-82, :178-182)
+ * -> MultiFilterTransient.log_likelihood (em_likelihood.py:186-204, :313-352).
+ * theta_dev: device pointer, row-major [B][ld] doubles (ld >= D); out_dev: device [B].
+ * stream: hipStream_t (NULL = default stream).  Asynchronous. */
+int32_t nmma_em_loglike(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                        double* out_dev, void* stream);
+
+/* Same with host buffers (staged through internal pinned/device buffers; synchronous). */
+int32_t nmma_em_loglike_host(nmma_em_handle* h, const double* theta_host, int64_t B, int64_t ld,
+                             double* out_host);
+
+/* Per-observed-filter pieces before the cross-filter sum (em_likelihood.py:337-352):
+ * chi_dev[O][B] = sum of truncated-Gaussian terms, gp_dev[O][B] = sum of logsf terms. */
+int32_t nmma_em_loglike_parts(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                              double* chi_dev, double* gp_dev, void* stream);
+
+/* Replaces B calls of gen_detector_lc (model.py:352-404):
+ * obs_times_dev[B][NS], mag_dev[B][M][NS] apparent magnitudes (+inf outside the SVD grid). */
+int32_t nmma_em_lightcurves(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                            double* obs_times_dev, double* mag_dev, void* stream);
+
+/* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
+int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                             float* coeff_dev, void* stream);
+
+/* Introspection used by bench.py / tests. */
+int32_t nmma_em_n_sample_times(const nmma_em_handle* h);
+int64_t nmma_em_flops_per_eval(const nmma_em_handle* h);   /* SURVEY.md section 8d figure */
+int32_t nmma_em_last_launch_geometry(const nmma_em_handle* h, int32_t* grid_x, int32_t* grid_y,
+                                     int32_t* block, int32_t* tile_samples, int32_t* lds_bytes);
+
+/* HIP-event timing of the dominant kernel on the launch stream: between begin and end
+ * every nmma_em_loglike call brackets its fused per-filter kernel with two events. */
+int32_t nmma_em_profile_begin(nmma_em_handle* h, int32_t max_launches);
+int32_t nmma_em_profile_end(nmma_em_handle* h, double* fused_ms_total, double* combine_ms_total,
+                            int32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMMA_HIP_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of ``libnmma_hip.so`` (C ABI: ``include/nmma_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing or fails to load, or if
+no HIP device is present when a handle is created, the product path raises
+:class:`NMMAHipError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmma_hip.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
+
+ABI_VERSION = 1
+MAX_PARAMS = 8
+MAX_COEFF = 16
+MAX_SOURCES = 3
+LOGL_FLOOR = -1.7976931348623157e308
+
+OP_IDENT, OP_RAD2DEG, OP_DEG2RAD, OP_LOG10, OP_POW10, OP_THETAJN2DEG, OP_COSTHETAJN2DEG = range(7)
+Z_ZERO, Z_SLOT, Z_GRID = range(3)
+SYS_CONST, SYS_PARAM, SYS_NODES = range(3)
+
+
+class NMMAHipError(RuntimeError):
+    """Raised for every failure of the HIP path (missing library, HIP error, bad config)."""
+
+
+class Slot(C.Structure):
+    _fields_ = [("col", C.c_int32), ("op", C.c_int32), ("value", C.c_double)]
+
+    @classmethod
+    def column(cls, col, op=OP_IDENT):
+        return cls(int(col), int(op), 0.0)
+
+    @classmethod
+    def constant(cls, value):
+        return cls(-1, OP_IDENT, float(value))
+
+
+_pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+
+
+class EmConfig(C.Structure):
+    """Mirror of ``struct nmma_em_config`` (field order must match the header)."""
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32),
+        ("n_model_filters", C.c_int32), ("n_params", C.c_int32), ("n_hidden", C.c_int32),
+        ("n_coeff", C.c_int32), ("n_tt", C.c_int32),
+        ("W1", _pf), ("b1", _pf), ("W2", _pf), ("b2", _pf),
+        ("VA", _pd), ("mins", _pd), ("maxs", _pd), ("tt", _pd),
+        ("param_mins", _pd), ("param_maxs", _pd),
+        ("n_sample_times", C.c_int32), ("sample_times", _pd),
+        ("redshift_mode", C.c_int32), ("n_cosmo", C.c_int32), ("dist_grid", _pd), ("z_grid", _pd),
+        ("n_dim", C.c_int32),
+        ("model_param", Slot * MAX_PARAMS),
+        ("luminosity_distance", Slot), ("redshift", Slot), ("timeshift", Slot), ("ebv", Slot),
+        ("ebv_coeff", _pd),
+        ("n_obs_filters", C.c_int32), ("data_offsets", _pi),
+        ("data_times", _pd), ("data_mags", _pd), ("data_sigmas", _pd),
+        ("detection_limit", _pd), ("n_sources", _pi), ("sources", _pi),
+        ("sys_kind", _pi), ("sys_const", _pd), ("sys_n_nodes", _pi), ("sys_slot_offsets", _pi),
+        ("sys_slots", C.POINTER(Slot)), ("sys_node_times", _pd),
+    ]
+
+
+#: name -> (restype, argtypes); every symbol ``include/nmma_hip.h`` declares
+PROTOTYPES = {
+    "nmma_abi_version": (C.c_int32, []),
+    "nmma_build_info": (C.c_char_p, []),
+    "nmma_last_error": (C.c_char_p, []),
+    "nmma_em_create": (C.c_int32, [C.POINTER(EmConfig), C.POINTER(C.c_void_p)]),
+    "nmma_em_destroy": (None, [C.c_void_p]),
+    "nmma_em_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_em_loglike_host": (C.c_int32, [C.c_void_p, _pd, C.c_int64, C.c_int64, _pd]),
+    "nmma_em_loglike_parts": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "nmma_em_lightcurves": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "nmma_em_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p]),
+    "nmma_em_n_sample_times": (C.c_int32, [C.c_void_p]),
+    "nmma_em_flops_per_eval": (C.c_int64, [C.c_void_p]),
+    "nmma_em_last_launch_geometry": (C.c_int32, [C.c_void_p] + [_pi] * 5),
+    "nmma_em_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "nmma_em_profile_end": (C.c_int32, [C.c_void_p, _pd, _pd, _pi]),
+}
+
+_lib = None
+
+
+def build_library(force=False, extra_flags=()):
+    """Compile ``csrc/em_kernels.hip`` for gfx950 into ``libnmma_hip.so`` (in-tree)."""
+    srcs = [SRC_PATH] + [os.path.join(_HERE, "csrc", f) for f in ("em_api.inc", "em_math.h", "em_device.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "nmma_hip.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+           "-shared", "-Wno-comment", SRC_PATH, "-o", LIB_PATH, *extra_flags]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise NMMAHipError("hipcc failed:\n" + proc.stderr[-4000:])
+    return LIB_PATH
+
+
+def load_library():
+    """Load the HIP library (after torch, so both share one HIP runtime) and bind prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NMMAHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or tools/build_lib.sh.  nmma_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first; our .so then resolves to the same runtime)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise NMMAHipError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise NMMAHipError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nmma_abi_version() != ABI_VERSION:
+        raise NMMAHipError("libnmma_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    lib = load_library()
+    msg = lib.nmma_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(status, what):
+    if status != 0:
+        raise NMMAHipError(f"{what}: {last_error()}")

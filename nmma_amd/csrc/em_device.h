@@ -1,0 +1,67 @@
+// em_device.h -- device-side view of one likelihood (built once by nmma_em_create).
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/nmma_hip.h"
+
+namespace nmma {
+
+// Floats per hidden-block record of the pre-swizzled surrogate weights:
+//   [0, 256)            W2 fragment : lane l, r in 0..3 -> W2[hb*16 + (l>>4)*4 + r][coef = l&15]
+//   [256, 256+64*KP)    W1 fragments: kp, lane l       -> W1[p = 4*kp + (l>>4)][hb*16 + (l&15)]
+//   [.., +16)           b1[hb*16 .. hb*16+15]
+// One record feeds (1 or 2) + 4 MFMAs per 16-sample row block; a wave streams its
+// records linearly with 16-byte loads (no LDS staging: every wave owns its hidden slice).
+__host__ __device__ constexpr int rec_floats(int kp) { return 256 + 64 * kp + 16; }
+
+enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2 };
+
+struct EmDev {
+    // dims
+    int32_t M, NP, KP, NH_pad, HB, NC, NT, NS, D, O;
+    int32_t n_cosmo, redshift_mode, has_ebv, kmax;
+    // surrogate
+    const float* wrec;        // [M][HB + 1][rec_floats(KP)]   (+1 zero record: branch-free prefetch)
+    const float* b2;          // [M][16]
+    const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid)
+    const double* mins;       // [M][NT]
+    const double* span;       // [M][NT]   maxs - mins
+    const double* pmin;       // [M][NP]
+    const double* pspan;      // [M][NP]   param_maxs - param_mins
+    const double* ebv_coeff;  // [M]
+    // stage-1 interpolation tables (sample_times <- tt), static per model filter
+    const double* st;         // [NS] sample times
+    const int32_t* s1_idx;    // [M][NS]  left node in tt (-1: outside the SVD grid -> +inf)
+    const double* s1_dx;      // [M][NS]  tt[i+1] - tt[i]
+    const double* s1_off;     // [M][NS]  st[j] - tt[i]
+    const int32_t* s1_range;  // [M][4]   jlo, jhi (finite nodes), identity flag, n_finite
+    // cosmology
+    const double* dist_grid;
+    const double* z_grid;
+    // theta mapping
+    nmma_slot model_param[NMMA_MAX_PARAMS];
+    nmma_slot lumdist, redshift, timeshift, ebv;
+    // photometry (CSR over observed filters)
+    const int32_t* doff;      // [O+1]
+    const double* dt;         // [N]
+    const double* dm;         // [N]
+    const double* dsig;       // [N]
+    const double* dsigtot;    // [N]  sqrt(sig^2 + e^2) for NMMA_SYS_CONST filters
+    const double* dlogsig;    // [N]  log of the above
+    const double* lim;        // [O]
+    const int32_t* nsrc;      // [O]
+    const int32_t* src;       // [O][3]
+    const int32_t* group;     // [O]  lanes cooperating on one sample (power of two <= 64)
+    // systematics
+    const int32_t* sys_kind;  // [O]
+    const double* sys_const;  // [O]
+    const int32_t* sys_nn;    // [O]
+    const int32_t* sys_off;   // [O+1]
+    const nmma_slot* sys_slots;
+    const int32_t* sys_nidx;  // [N]  node bracket per datum (-1: left of first, K-1: at/after last)
+    const double* sys_ndx;    // [N]  node spacing
+    const double* sys_noff;   // [N]  t - node time
+};
+
+}  // namespace nmma

@@ -1,0 +1,158 @@
+// em_math.h -- scalar fp64 building blocks of the EM likelihood, shared by the HIP
+// kernels (device) and by tests/hostcheck (host build of the very same source, so the
+// branchy numerics can be checked on a CPU against scipy / the oracle).
+//
+// Everything here follows numpy / scipy semantics of the reference's call sites:
+//   np.interp                     numpy/_core/src/multiarray/compiled_base.c (arr_interp)
+//   scipy.stats.truncnorm.logpdf  nmma/em/em_likelihood.py:252-256
+//   scipy.stats.norm.logsf        nmma/em/em_likelihood.py:247-249
+// Build with -ffp-contract=off: the reference's expressions are not fused.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/nmma_hip.h"
+
+#if defined(__HIPCC__)
+#define NM_HD __host__ __device__ __forceinline__
+// rarely-taken, transcendental-heavy paths: keep them out of line so they do not
+// inflate the register budget of the MFMA loop they share a kernel with
+#define NM_HD_COLD __host__ __device__ __noinline__
+#else
+#define NM_HD inline
+#define NM_HD_COLD inline
+#endif
+
+namespace nmma {
+
+constexpr double kPi = 3.141592653589793;            // np.pi
+constexpr double kSqrt1_2 = 0.7071067811865476;      // M_SQRT1_2
+constexpr double kNormPdfLogC = 0.9189385332046727;  // log(sqrt(2*pi)) (scipy _norm_pdf_logC)
+
+NM_HD double dinf() { return HUGE_VAL; }
+NM_HD double dnan() { return HUGE_VAL - HUGE_VAL; }
+
+// ---------------------------------------------------------------------------
+// theta column -> physical scalar (nmma/core/conversion.py:119-126, em/model.py:272-286)
+// ---------------------------------------------------------------------------
+NM_HD_COLD double apply_slot_op(double v, int op) {
+    switch (op) {
+        case NMMA_OP_RAD2DEG: return v * 180.0 / kPi;
+        case NMMA_OP_DEG2RAD: return v / 180.0 * kPi;
+        case NMMA_OP_LOG10: return log10(v);
+        case NMMA_OP_POW10: return pow(10.0, v);
+        case NMMA_OP_THETAJN2DEG: { const double t = fmin(v, kPi - v); return t * 180.0 / kPi; }
+        case NMMA_OP_COSTHETAJN2DEG: { double t = acos(v); t = fmin(t, kPi - t); return t * 180.0 / kPi; }
+        default: return v;
+    }
+}
+
+NM_HD double apply_slot(const nmma_slot& s, const double* row) {
+    if (s.col < 0) return s.value;
+    const double v = row[s.col];
+    if (s.op == NMMA_OP_IDENT) return v;
+    return apply_slot_op(v, s.op);
+}
+
+// ---------------------------------------------------------------------------
+// np.interp on explicit arrays (cosmology grid, systematics nodes)
+// ---------------------------------------------------------------------------
+// Piecewise-linear value between two nodes exactly as arr_interp evaluates it,
+// including its NaN fallbacks.
+NM_HD double lerp_np(double x, double x0, double x1, double y0, double y1) {
+    const double slope = (y1 - y0) / (x1 - x0);
+    double r = slope * (x - x0) + y0;
+    if (r != r) {
+        r = slope * (x - x1) + y1;
+        if (r != r && y0 == y1) r = y0;
+    }
+    return r;
+}
+
+// np.interp(x, xp[0..n), fp[0..n), left, right); xp increasing, n >= 1.
+NM_HD double interp_np(double x, const double* xp, const double* fp, int n, double left, double right) {
+    if (x != x) return x;
+    if (n == 1) return x < xp[0] ? left : (x > xp[0] ? right : fp[0]);
+    if (x < xp[0]) return left;
+    if (x > xp[n - 1]) return right;
+    int lo = 0, hi = n - 1;  // xp[lo] <= x <= xp[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (x == xp[n - 1]) return fp[n - 1];
+    if (xp[lo] == x) return fp[lo];
+    return lerp_np(x, xp[lo], xp[lo + 1], fp[lo], fp[lo + 1]);
+}
+
+// ---------------------------------------------------------------------------
+// scipy.special pieces (xsf): ndtr, log_ndtr
+// ---------------------------------------------------------------------------
+NM_HD double erfcx_pos_or_neg(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ::erfcx(t);
+#else
+    // host build (tests only): libm has no erfcx; large-t continued fraction keeps the
+    // product finite where exp(t*t) would overflow.
+    if (t < 25.0) return exp(t * t) * erfc(t);
+    const double t2 = t * t;
+    return (1.0 / (t * 1.772453850905516)) * (1.0 - 0.5 / t2 + 0.75 / (t2 * t2));
+#endif
+}
+
+// xsf::cephes::ndtr
+NM_HD double ndtr(double a) {
+    if (a != a) return a;
+    const double x = a * kSqrt1_2;
+    const double z = fabs(x);
+    if (z < kSqrt1_2) return 0.5 + 0.5 * erf(x);
+    double y = 0.5 * erfc(z);
+    if (x > 0) y = 1.0 - y;
+    return y;
+}
+
+// xsf::log_ndtr (scipy >= 1.9): log(erfcx(-t)/2) - t^2 for x < -1, log1p(-erfc(t)/2) otherwise
+NM_HD_COLD double log_ndtr(double x) {
+    const double t = x * kSqrt1_2;
+    if (x < -1.0) return log(erfcx_pos_or_neg(-t) / 2) - t * t;
+    return log1p(-erfc(t) / 2);
+}
+
+// scipy.stats._continuous_distns._log_gauss_mass(a = -inf, b)
+NM_HD_COLD double log_gauss_mass_neginf(double b) {
+    if (b <= 0) return log_ndtr(b);       // case_left: log_ndtr(b) + log1p(-exp(-inf)) = log_ndtr(b)
+    if (b > 0) return log1p(-ndtr(-b));   // case_central: log1p(-ndtr(a) - ndtr(-b)), ndtr(-inf) = 0
+    return dnan();
+}
+
+// One detection: truncnorm.logpdf(m, a=-inf, b=(lim-est)/sigma, loc=est, scale=sigma)
+// rv_continuous.logpdf: NaN for invalid args (b NaN, b <= a, scale <= 0), -inf outside [a, b].
+NM_HD double detection_term(double m, double est, double sigma, double log_sigma, double lim) {
+    const double b = (lim - est) / sigma;
+    if (!(b > -dinf()) || !(sigma > 0)) return dnan();   // also catches b = NaN (est = +inf)
+    const double x = (m - est) / sigma;
+    if (x != x) return dnan();
+    if (x > b) return -dinf();
+    const double mass = (lim == dinf()) ? 0.0 : log_gauss_mass_neginf(b);
+    return ((-(x * x) / 2.0 - kNormPdfLogC) - mass) - log_sigma;
+}
+
+// One upper limit: norm.logsf(m, est, sigma_sys) = log_ndtr(-(m - est)/sigma_sys);
+// rv_continuous.logsf: scale <= 0 or NaN args -> NaN; x at the lower support edge -> 0.
+NM_HD double upper_limit_term(double m, double est, double sigma_sys) {
+    if (!(sigma_sys > 0)) return dnan();
+    const double x = (m - est) / sigma_sys;
+    if (x != x) return dnan();
+    if (x == -dinf()) return 0.0;
+    if (x == dinf()) return -dinf();
+    return log_ndtr(-x);
+}
+
+// ---------------------------------------------------------------------------
+// distance quantities (nmma/core/conversion.py:30-34, em/model.py:389)
+// ---------------------------------------------------------------------------
+NM_HD double distance_modulus(double d_lum) { return 5.0 * (5 + log10(d_lum)); }
+NM_HD double redshift_correction(double z) { return -2.5 * log10(1 + z); }
+
+}  // namespace nmma

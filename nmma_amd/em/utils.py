@@ -1,0 +1,96 @@
+"""Host-side helpers of the EM sector (setup-time only; nothing here runs per sample).
+
+Mirrors the pieces of ``nmma/em/utils.py`` the likelihood path needs:
+filter-name maps (:478-584), per-filter dict broadcasting (:218-235), photometry
+preparation (:255-286) and the model-window consistency check (:289-353).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+#: names the reference maps to themselves without consulting sncosmo (utils.py:486-510)
+BUILTIN_FILTERS = [
+    "u", "g", "r", "i", "z", "y", "J", "H", "K", "X-ray-1keV", "X-ray-5keV", "radio-5.5GHz",
+    "radio-1.25GHz", "radio-6GHz", "radio-3GHz", "sdss::u", "sdss::g", "sdss::r", "sdss::i",
+    "sdss::z", "swope2::y", "swope2::J", "swope2::H",
+]
+#: hard-coded renames (utils.py:519-529)
+FILTER_RENAMES = {"B": "g", "R": "z", "F160W": "H", "U": "u", "UVW2": "u", "UVW1": "u", "UVM2": "u"}
+#: observed bands built as the mean of model bands (utils.py:549-563, :566-584)
+FILTER_AVERAGES = {"w": ["g", "r", "i"], "o": ["r", "i"], "c": ["g", "r"], "V": ["g", "r"],
+                   "F606W": ["g", "r"], "I": ["z", "y"], "F814W": ["z", "y"]}
+
+
+def get_filter_name_mapping(observed_filters, known_filters=()):
+    """``(direct_map, averaging_map)`` as ``nmma.em.utils.get_filter_name_mapping``.
+
+    ``known_filters`` stands in for the sncosmo bandpass registry the reference
+    consults (utils.py:511): every name in it maps to itself."""
+    if isinstance(observed_filters, str):
+        observed_filters = [observed_filters]
+    known = set(BUILTIN_FILTERS) | set(known_filters)
+    direct, averaging = {}, {}
+    for f in observed_filters:
+        if f in FILTER_RENAMES:
+            direct[f] = FILTER_RENAMES[f]
+        elif f in known or f.startswith("radio") or f.startswith("X-ray"):
+            direct[f] = f
+        elif f in FILTER_AVERAGES:
+            averaging[f] = list(FILTER_AVERAGES[f])
+        else:
+            raise ValueError(f"Unknown filter: {f}. Cannot be processed")
+    return direct, averaging
+
+
+def set_filter_associated_dict(quantity, filters, default_limit=np.inf):
+    """utils.py:218-235."""
+    if isinstance(quantity, (int, float)):
+        return {x: float(quantity) for x in filters}
+    if isinstance(quantity, (list, tuple)):
+        assert len(quantity) == len(filters), f" {quantity} must match the number of filters: {filters}."
+        return {x: float(y) for x, y in zip(filters, quantity)}
+    if isinstance(quantity, dict):
+        return {filt: float(quantity.get(filt, default_limit)) for filt in filters}
+    raise ValueError(f"Could not derive a dict for {quantity} and filters {filters}.")
+
+
+def setup_filtered_lc_data(light_curve_data, trigger_time):
+    """utils.py:255-286: ``{filt: {time, mag, mag_error}}`` -> (times, mags, sigmas, trigger_time)
+    with times in days since the trigger."""
+    lc_times, lc_mags, lc_unc = {}, {}, {}
+    min_time = np.inf
+    for filt, sub in light_curve_data.items():
+        lc_mags[filt] = np.array(sub["mag"])
+        lc_unc[filt] = np.array(sub["mag_error"])
+        lc_times[filt] = np.array(sub["time"])
+        min_time = np.minimum(min_time, np.min(sub["time"]))
+    if min_time < 0:
+        raise ValueError(f"trigger_time is {-min_time} days later than earliest data time. "
+                         "Please provide a valid trigger time.")
+    lc_times = {filt: lc_times[filt] - trigger_time for filt in lc_times}
+    return (lc_times, lc_mags, lc_unc, trigger_time)
+
+
+def resolve_sources(observed_filters, model_filters, known_filters=()):
+    """Model bands feeding each observed band (em_likelihood.py:313-335).
+
+    Reference quirk kept: helper bands of an averaged filter are looked up in the map
+    built from the *observed* filters (em_likelihood.py:330), so each helper must itself
+    be observed; and a mapped band the model does not provide is an error."""
+    direct, averaging = get_filter_name_mapping(observed_filters,
+                                                set(known_filters) | set(model_filters))
+    sources = {}
+    for f in observed_filters:
+        if f in direct:
+            names = [direct[f]]
+        else:
+            names = []
+            for h in averaging[f]:
+                if h not in direct:
+                    raise KeyError(h)
+                names.append(direct[h])
+        for n in names:
+            if n not in model_filters:
+                raise KeyError(f"model provides no light curve for filter {n!r} (needed by {f!r})")
+        sources[f] = names
+    return sources

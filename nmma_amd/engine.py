@@ -1,0 +1,356 @@
+"""EMEngine: one GPU-resident EM likelihood (a ``nmma_em_handle``) and its batched calls.
+
+This is the thin layer between the reference-shaped Python classes
+(``nmma_amd.em.model.SVDLightCurveModel``, ``nmma_amd.em.em_likelihood.EMTransientLikelihood``)
+and the C ABI.  It translates *names* (model parameters, sampled parameters, filters)
+into the flat ``nmma_em_config`` the library copies to the device, and moves batches
+``theta[B, D]`` through the kernels.  torch is used only to hold device buffers and
+to supply the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_AVG_DEFAULT_LD = 1e-5   # nmma/em/model.py:291-293: default distance 10 pc = 1e-5 Mpc
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def resolve_model_param_slot(key, names, fixed):
+    """Where one surrogate input comes from, following the reference's conversions:
+    nmma/core/conversion.py:119-126 (KNtheta <-> inclination_EM / theta_jn) and
+    nmma/em/model.py:272-286 (log10_ aliases, including its ``lstrip`` semantics)."""
+    names = list(names)
+    if key in names:
+        return L.Slot.column(names.index(key))
+    if key in fixed:
+        return L.Slot.constant(fixed[key])
+    if key == "KNtheta":
+        if "inclination_EM" in names:
+            return L.Slot.column(names.index("inclination_EM"), L.OP_RAD2DEG)
+        if "inclination_EM" in fixed:
+            return L.Slot.constant(fixed["inclination_EM"] * 180.0 / np.pi)
+        if "theta_jn" in names:
+            return L.Slot.column(names.index("theta_jn"), L.OP_THETAJN2DEG)
+        if "cos_theta_jn" in names:
+            return L.Slot.column(names.index("cos_theta_jn"), L.OP_COSTHETAJN2DEG)
+        tj = fixed.get("theta_jn", np.arccos(fixed.get("cos_theta_jn", 1.0)))
+        return L.Slot.constant(min(tj, np.pi - tj) * 180.0 / np.pi)
+    if key == "inclination_EM":
+        if "KNtheta" in names:
+            return L.Slot.column(names.index("KNtheta"), L.OP_DEG2RAD)
+        if "KNtheta" in fixed:
+            return L.Slot.constant(fixed["KNtheta"] / 180.0 * np.pi)
+    stripped = key.lstrip("log10_")          # sic: character-set strip, as the reference does
+    if stripped in names:
+        return L.Slot.column(names.index(stripped), L.OP_LOG10)
+    if stripped in fixed:
+        return L.Slot.constant(np.log10(fixed[stripped]))
+    if "log10_" + key in names:
+        return L.Slot.column(names.index("log10_" + key), L.OP_POW10)
+    if "log10_" + key in fixed:
+        return L.Slot.constant(10 ** fixed["log10_" + key])
+    raise KeyError(f"model parameter {key!r} is neither sampled nor fixed "
+                   f"(sampled: {names}, fixed: {sorted(fixed)})")
+
+
+def _plain_slot(key, names, fixed, default):
+    names = list(names)
+    if key in names:
+        return L.Slot.column(names.index(key))
+    return L.Slot.constant(fixed.get(key, default))
+
+
+class EMEngine:
+    """Owns one ``nmma_em_handle``.
+
+    Parameters
+    ----------
+    svd_model : dict  filter -> dict(W1, b1, W2, b2, VA, mins, maxs, tt, param_mins, param_maxs, n_coeff)
+    model_filters : list[str]   model filters to upload (order defines indices)
+    model_parameters : list[str]  surrogate inputs, in the model's order
+    parameter_names : list[str]   columns of ``theta``
+    fixed : dict  fixed (delta-function) parameters
+    sample_times : array or None  (None: the SVD training grid, model.py:655-660)
+    cosmo_grid : (dist_grid, z_grid) or None
+    data : (times, mags, sigmas) dicts keyed by observed filter, or None (model-only engine)
+    observed_filters : list[str]
+    sources : dict observed filter -> list of model filters (1, or 2-3 to average)
+    detection_limit : dict observed filter -> float
+    systematics : dict, see ``nmma_amd.em.systematics.FilterSystematicsHandler.kernel_spec``
+    ebv_coeff : dict model filter -> A_filter / E(B-V), or None
+    """
+
+    def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
+                 sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
+                 detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None):
+        self._handle = None
+        lib = L.load_library()
+        fixed = dict(fixed or {})
+        names = list(parameter_names)
+        model_filters = list(model_filters)
+        self.parameter_names = names
+        self.model_filters = model_filters
+        self.observed_filters = list(observed_filters)
+        self.device = int(device)
+
+        first = svd_model[model_filters[0]]
+        n_p = int(np.asarray(first["W1"]).shape[0])
+        n_h = int(np.asarray(first["W1"]).shape[1])
+        nc_trained = int(first["n_coeff"])
+        # lightcurve_generation.py:182-185; with a Keras net the output width is fixed
+        n_c = min(int(n_coeff), nc_trained) if n_coeff else nc_trained
+        if n_c != int(np.asarray(first["W2"]).shape[1]):
+            raise L.NMMAHipError("svd_mag_ncoeff must equal the network's output width "
+                                 "(nmma/em/lightcurve_generation.py:182-198)")
+        n_t = len(first["tt"])
+        if len(model_parameters) != n_p:
+            raise L.NMMAHipError("model_parameters do not match the surrogate input width")
+        for f in model_filters:
+            t = svd_model[f]
+            if (np.asarray(t["W1"]).shape != (n_p, n_h) or np.asarray(t["W2"]).shape != (n_h, n_c)
+                    or len(t["tt"]) != n_t):
+                raise L.NMMAHipError(f"filter {f}: surrogate shapes differ between filters")
+        stack = lambda k, conv: conv(np.stack([np.asarray(svd_model[f][k]) for f in model_filters]))
+        W1, b1, W2, b2 = (stack(k, _f32) for k in ("W1", "b1", "W2", "b2"))
+        VA = _f64(np.stack([np.asarray(svd_model[f]["VA"])[:, :n_c] for f in model_filters]))
+        mins, maxs, tt = (stack(k, _f64) for k in ("mins", "maxs", "tt"))
+        pmin, pmax = stack("param_mins", _f64), stack("param_maxs", _f64)
+        self.n_params, self.n_hidden, self.n_coeff, self.n_tt = n_p, n_h, n_c, n_t
+
+        cfg = L.EmConfig()
+        keep = [W1, b1, W2, b2, VA, mins, maxs, tt, pmin, pmax]
+        cfg.abi_version, cfg.device = L.ABI_VERSION, self.device
+        cfg.n_model_filters, cfg.n_params, cfg.n_hidden = len(model_filters), n_p, n_h
+        cfg.n_coeff, cfg.n_tt = n_c, n_t
+        cfg.W1, cfg.b1, cfg.W2, cfg.b2 = (_ptr(a, C.c_float) for a in (W1, b1, W2, b2))
+        cfg.VA, cfg.mins, cfg.maxs, cfg.tt = (_ptr(a, C.c_double) for a in (VA, mins, maxs, tt))
+        cfg.param_mins, cfg.param_maxs = _ptr(pmin, C.c_double), _ptr(pmax, C.c_double)
+
+        if sample_times is not None:
+            st = _f64(sample_times)
+            keep.append(st)
+            cfg.n_sample_times, cfg.sample_times = len(st), _ptr(st, C.c_double)
+            self.sample_times = st
+        else:
+            cfg.n_sample_times = 0
+            self.sample_times = tt[0].copy()
+
+        # redshift: conversion.py:57-64, model.py:255-267
+        cfg.n_dim = len(names)
+        if "redshift" in names or "redshift" in fixed:
+            cfg.redshift_mode = L.Z_SLOT
+            cfg.redshift = _plain_slot("redshift", names, fixed, 0.0)
+        elif cosmo_grid is not None and ("luminosity_distance" in names or "luminosity_distance" in fixed):
+            dg, zg = _f64(cosmo_grid[0]), _f64(cosmo_grid[1])
+            keep += [dg, zg]
+            cfg.redshift_mode, cfg.n_cosmo = L.Z_GRID, len(dg)
+            cfg.dist_grid, cfg.z_grid = _ptr(dg, C.c_double), _ptr(zg, C.c_double)
+            cfg.redshift = L.Slot.constant(0.0)
+        else:
+            cfg.redshift_mode = L.Z_ZERO
+            cfg.redshift = L.Slot.constant(0.0)
+        for p, key in enumerate(model_parameters):
+            cfg.model_param[p] = resolve_model_param_slot(key, names, fixed)
+        for p in range(n_p, L.MAX_PARAMS):
+            cfg.model_param[p] = L.Slot.constant(0.0)
+        cfg.luminosity_distance = _plain_slot("luminosity_distance", names, fixed, _AVG_DEFAULT_LD)
+        cfg.timeshift = _plain_slot("timeshift", names, fixed, 0.0)
+        cfg.ebv = _plain_slot("Ebv", names, fixed, 0.0)
+        if ebv_coeff is not None:
+            ec = _f64([ebv_coeff[f] for f in model_filters])
+            keep.append(ec)
+            cfg.ebv_coeff = _ptr(ec, C.c_double)
+
+        # photometry + systematics
+        obs = self.observed_filters
+        cfg.n_obs_filters = len(obs)
+        if obs:
+            times, mags, sigmas = data
+            offs = np.zeros(len(obs) + 1, dtype=np.int32)
+            for i, f in enumerate(obs):
+                if not (len(times[f]) == len(mags[f]) == len(sigmas[f])):
+                    raise L.NMMAHipError(f"filter {f}: ragged photometry arrays")
+                offs[i + 1] = offs[i] + len(times[f])
+            cat = lambda d: _f64(np.concatenate([np.asarray(d[f], dtype=float) for f in obs])
+                                 if offs[-1] else np.zeros(0))
+            dt, dm, ds = cat(times), cat(mags), cat(sigmas)
+            lim = _f64([np.inf if detection_limit is None else detection_limit.get(f, np.inf) for f in obs])
+            srcs = sources or {f: [f] for f in obs}
+            nsrc = _i32([len(srcs[f]) for f in obs])
+            src = np.zeros((len(obs), L.MAX_SOURCES), dtype=np.int32)
+            for i, f in enumerate(obs):
+                for k, mf in enumerate(srcs[f]):
+                    src[i, k] = model_filters.index(mf)
+            sysk, sysc, sysn, sysoff, slots, node_t = self._systematics_arrays(systematics, obs, names, fixed)
+            keep += [offs, dt, dm, ds, lim, nsrc, src, sysk, sysc, sysn, sysoff, node_t]
+            cfg.data_offsets = _ptr(offs, C.c_int32)
+            cfg.data_times, cfg.data_mags, cfg.data_sigmas = (_ptr(a, C.c_double) for a in (dt, dm, ds))
+            cfg.detection_limit = _ptr(lim, C.c_double)
+            cfg.n_sources, cfg.sources = _ptr(nsrc, C.c_int32), _ptr(src, C.c_int32)
+            cfg.sys_kind, cfg.sys_const = _ptr(sysk, C.c_int32), _ptr(sysc, C.c_double)
+            cfg.sys_n_nodes, cfg.sys_slot_offsets = _ptr(sysn, C.c_int32), _ptr(sysoff, C.c_int32)
+            slot_arr = (L.Slot * max(1, len(slots)))(*slots)
+            keep.append(slot_arr)
+            cfg.sys_slots = C.cast(slot_arr, C.POINTER(L.Slot))
+            cfg.sys_node_times = _ptr(node_t, C.c_double)
+            self.n_data = int(offs[-1])
+        else:
+            self.n_data = 0
+
+        h = C.c_void_p()
+        L.check(lib.nmma_em_create(C.byref(cfg), C.byref(h)), "nmma_em_create")
+        self._handle = h
+        self._lib = lib
+        self.n_sample_times = int(lib.nmma_em_n_sample_times(h))
+        self.flops_per_eval = int(lib.nmma_em_flops_per_eval(h))
+        del keep
+
+    @staticmethod
+    def _systematics_arrays(spec, obs, names, fixed):
+        spec = spec or {"mode": "budget", "values": {f: 1.0 for f in obs}}
+        kind = np.zeros(len(obs), dtype=np.int32)
+        const = np.zeros(len(obs))
+        nn = np.zeros(len(obs), dtype=np.int32)
+        off = np.zeros(len(obs) + 1, dtype=np.int32)
+        slots, node_t = [], []
+        mode = spec["mode"]
+        for i, f in enumerate(obs):
+            off[i] = len(slots)
+            if mode == "budget":
+                kind[i], const[i] = L.SYS_CONST, float(spec["values"][f])
+                continue
+            if mode == "param":
+                pname, nodes = spec["name"], None
+            elif f in spec.get("names", {}):
+                pname, nodes = spec["names"][f], None
+            elif f in spec.get("nodes", {}):
+                pname, nodes = spec["nodes"][f]
+            else:
+                raise L.NMMAHipError(f"systematics spec has no entry for filter {f}")
+            if nodes is None:
+                kind[i], nn[i] = L.SYS_PARAM, 1
+                slots.append(_plain_slot(pname, names, fixed, np.nan))
+                node_t.append(0.0)
+            else:
+                kind[i], nn[i] = L.SYS_NODES, len(nodes)
+                for p, t in zip(pname, nodes):
+                    slots.append(_plain_slot(p, names, fixed, np.nan))
+                    node_t.append(float(t))
+        off[len(obs)] = len(slots)
+        return kind, _f64(const), nn, off, slots, _f64(node_t if node_t else [0.0])
+
+    # ------------------------------------------------------------------ calls
+    def _dev_theta(self, theta):
+        import torch
+        if isinstance(theta, torch.Tensor):
+            t = theta
+            if t.dtype != torch.float64 or not t.is_cuda:
+                t = t.to(device=f"cuda:{self.device}", dtype=torch.float64)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(f"cuda:{self.device}")
+        if t.dim() != 2 or t.shape[1] < len(self.parameter_names):
+            raise L.NMMAHipError(f"theta must be [B, >={len(self.parameter_names)}], got {tuple(t.shape)}")
+        return t.contiguous()
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def loglike(self, theta, out=None):
+        """logL for every row of ``theta[B, D]``.  torch CUDA tensor in -> torch tensor out
+        (asynchronous on the current stream); numpy in -> numpy out (synchronous)."""
+        import torch
+        if not isinstance(theta, torch.Tensor):
+            th = _f64(theta)
+            if th.ndim != 2 or th.shape[1] < len(self.parameter_names):
+                raise L.NMMAHipError(f"theta must be [B, >={len(self.parameter_names)}], got {th.shape}")
+            res = np.empty(th.shape[0])
+            L.check(self._lib.nmma_em_loglike_host(self._handle, _ptr(th, C.c_double), th.shape[0],
+                                                   th.shape[1], _ptr(res, C.c_double)),
+                    "nmma_em_loglike_host")
+            return res
+        t = self._dev_theta(theta)
+        if out is None:
+            out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        L.check(self._lib.nmma_em_loglike(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                          C.c_void_p(out.data_ptr()), self._stream()), "nmma_em_loglike")
+        return out
+
+    def loglike_parts(self, theta):
+        """(chi[O, B], gp[O, B]) per observed filter (em_likelihood.py:337-352)."""
+        import torch
+        t = self._dev_theta(theta)
+        n_o = len(self.observed_filters)
+        chi = torch.empty((n_o, t.shape[0]), dtype=torch.float64, device=t.device)
+        gp = torch.empty_like(chi)
+        L.check(self._lib.nmma_em_loglike_parts(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                                C.c_void_p(chi.data_ptr()), C.c_void_p(gp.data_ptr()),
+                                                self._stream()), "nmma_em_loglike_parts")
+        return chi, gp
+
+    def lightcurves(self, theta):
+        """(obs_times[B, NS], mag[B, M, NS]) -- gen_detector_lc for every row (model.py:352-404)."""
+        import torch
+        t = self._dev_theta(theta)
+        ns, m = self.n_sample_times, len(self.model_filters)
+        tobs = torch.empty((t.shape[0], ns), dtype=torch.float64, device=t.device)
+        mag = torch.empty((t.shape[0], m, ns), dtype=torch.float64, device=t.device)
+        L.check(self._lib.nmma_em_lightcurves(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                              C.c_void_p(tobs.data_ptr()), C.c_void_p(mag.data_ptr()),
+                                              self._stream()), "nmma_em_lightcurves")
+        return tobs, mag
+
+    def coefficients(self, theta):
+        """SVD coefficients c[B, M, NC] (fp32), the surrogate output (lightcurve_generation.py:198)."""
+        import torch
+        t = self._dev_theta(theta)
+        c = torch.empty((t.shape[0], len(self.model_filters), self.n_coeff), dtype=torch.float32, device=t.device)
+        L.check(self._lib.nmma_em_coefficients(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                               C.c_void_p(c.data_ptr()), self._stream()), "nmma_em_coefficients")
+        return c
+
+    def last_launch_geometry(self):
+        v = [C.c_int32() for _ in range(5)]
+        L.check(self._lib.nmma_em_last_launch_geometry(self._handle, *[C.byref(x) for x in v]),
+                "nmma_em_last_launch_geometry")
+        return dict(zip(("grid_x", "grid_y", "block", "tile_samples", "lds_bytes"), (x.value for x in v)))
+
+    def profile_begin(self, max_launches):
+        L.check(self._lib.nmma_em_profile_begin(self._handle, int(max_launches)), "nmma_em_profile_begin")
+
+    def profile_end(self):
+        f, c, n = C.c_double(), C.c_double(), C.c_int32()
+        L.check(self._lib.nmma_em_profile_end(self._handle, C.byref(f), C.byref(c), C.byref(n)),
+                "nmma_em_profile_end")
+        return dict(fused_ms_total=f.value, combine_ms_total=c.value, n_launches=n.value)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.nmma_em_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

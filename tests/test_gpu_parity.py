@@ -1,0 +1,153 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors produced by
+the reference's own source, and against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative on fp64 logL magnitudes.  The
+surrogate MLP is fp32 in the reference (Keras) -- its summation order is not
+reproducible, so coefficients are compared at fp32-rounding level (stated below).
+"""
+import numpy as np
+import pytest
+
+from tests import cases
+from tests.helpers import engine_from_case, oracle_from_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOGL_RTOL = 1e-6          # north_star tolerance
+COEFF_ATOL = 3e-5         # fp32 accumulation-order noise on |c| <~ 15 (K = 2048 chain)
+FLOOR = -1.7976931348623157e308
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_logl_matches_reference_golden(name, torch_cuda):
+    torch = torch_cuda
+    case = cases.CASES[name]()
+    gold = cases.load_golden(name)
+    assert cases.weights_digest(case["svd"]) == pytest.approx(float(gold["digest"]), rel=1e-13)
+    eng = engine_from_case(case)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    got = eng.loglike(th).cpu().numpy()
+    want = gold["logl"]
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor), f"floor pattern differs: {np.nonzero((got == FLOOR) != floor)}"
+    err = rel_err(got[~floor], want[~floor])
+    print(f"{name}: max rel err {err.max() if err.size else 0:.3e} over {err.size} finite rows")
+    assert err.size == 0 or err.max() <= LOGL_RTOL
+    # host-buffer entry point gives the same numbers
+    got_h = eng.loglike(np.asarray(case["theta"]))
+    assert np.array_equal(got_h, got)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2_default", "c2_dt05_limit", "c4_shape"])
+def test_coefficients_and_lightcurves(name, torch_cuda):
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    case = cases.CASES[name]()
+    gold = cases.load_golden(name)
+    eng = engine_from_case(case)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    c = eng.coefficients(th).cpu().numpy()
+    tobs, mag = (x.cpu().numpy() for x in eng.lightcurves(th))
+    olik = oracle_from_case(case)
+    for i in range(4):
+        for k, f in enumerate(case["model_filters"]):
+            np.testing.assert_allclose(c[i, k], gold[f"s{i}_c_{k}"], atol=COEFF_ATOL, rtol=0)
+            want = gold[f"s{i}_app_{k}"]
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isfinite(mag[i, k]), fin)
+            np.testing.assert_allclose(mag[i, k][fin], want[fin], rtol=2e-6)
+        np.testing.assert_allclose(tobs[i], gold[f"s{i}_obs_times"], rtol=1e-15)
+    # ideal-fp32 coefficients (fp64 accumulation, order independent) for the whole batch
+    p = olik.model.parameter_conversion(dict(zip(case["names"], case["theta"].T)))
+    plist = np.stack([np.broadcast_to(p[k], (len(case["theta"]),)) for k in case["model_parameters"]], 1)
+    for k, f in enumerate(case["model_filters"]):
+        t = case["svd"][f]
+        x = (plist - t["param_mins"]) / (t["param_maxs"] - t["param_mins"])
+        ideal = orc.mlp_forward(x, t["W1"], t["b1"], t["W2"], t["b2"], "f64acc")
+        np.testing.assert_allclose(c[:, k], ideal, atol=COEFF_ATOL, rtol=0)
+    eng.close()
+
+
+def test_parts_match_oracle(torch_cuda):
+    torch = torch_cuda
+    case = cases.case_c2_dt05_limit()
+    eng = engine_from_case(case)
+    olik = oracle_from_case(case, use_scipy=False)
+    th = torch.as_tensor(case["theta"][:16], device="cuda:0")
+    chi, gp = (x.cpu().numpy() for x in eng.loglike_parts(th))
+    for i in range(16):
+        p = olik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in case["theta"][i]))))
+        tot, parts, _ = olik.sub_log_likelihood(p, return_parts=True)
+        for j, f in enumerate(case["observed_filters"]):
+            assert chi[j, i] == pytest.approx(parts[f][0], rel=2e-6, abs=1e-6)
+            assert gp[j, i] == pytest.approx(parts[f][1], rel=2e-6, abs=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("batch", [1, 15, 17, 33, 100])
+def test_ragged_batches_and_tilings(batch, torch_cuda, monkeypatch):
+    torch = torch_cuda
+    case = cases.case_c2_default()
+    gold = cases.load_golden("c2_default")["logl"]
+    idx = np.arange(batch) % len(gold)
+    th = torch.as_tensor(case["theta"][idx], device="cuda:0")
+    for tile in ("1,4", "2,4", "4,4", "1,8", "2,8", None):
+        if tile is None:
+            monkeypatch.delenv("NMMA_EM_TILE", raising=False)
+        else:
+            monkeypatch.setenv("NMMA_EM_TILE", tile)
+        eng = engine_from_case(case)
+        got = eng.loglike(th).cpu().numpy()
+        assert rel_err(got, gold[idx]).max() <= LOGL_RTOL, tile
+        eng.close()
+
+
+def test_empty_batch_and_errors(torch_cuda):
+    torch = torch_cuda
+    from nmma_amd._lib import NMMAHipError
+    case = cases.case_small_hidden()
+    eng = engine_from_case(case)
+    out = eng.loglike(torch.empty((0, len(case["names"])), dtype=torch.float64, device="cuda:0"))
+    assert out.numel() == 0
+    with pytest.raises(NMMAHipError):
+        eng.loglike(torch.zeros((4, 2), dtype=torch.float64, device="cuda:0"))
+    nan_theta = torch.as_tensor(case["theta"][:4].copy(), device="cuda:0")
+    nan_theta[1, 0] = float("nan")
+    got = eng.loglike(nan_theta).cpu().numpy()
+    assert got[1] == FLOOR and np.all(got[[0, 2, 3]] > FLOOR)
+    eng.close()
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE config 2 at its full batch (4096): size-independent properties --
+    permutation equivariance, batch-composition independence, determinism."""
+    torch = torch_cuda
+    case = cases.case_c2_default()
+    from nmma_amd import synthetic as syn
+    _, theta = syn.draw_theta(4242, 4096, case["names"])
+    eng = engine_from_case(case)
+    th = torch.as_tensor(theta, device="cuda:0")
+    a = eng.loglike(th).cpu().numpy()
+    b = eng.loglike(th).cpu().numpy()
+    assert np.array_equal(a, b)                                   # deterministic
+    perm = np.random.default_rng(0).permutation(4096)
+    c = eng.loglike(th[torch.as_tensor(perm, device="cuda:0")]).cpu().numpy()
+    assert np.array_equal(c, a[perm])                             # row-wise independent
+    d = eng.loglike(th[:1000]).cpu().numpy()
+    assert np.array_equal(d, a[:1000])                            # independent of batch size
+    assert np.all(np.isfinite(a)) and np.all(a <= 0)
+    # spot-check 64 rows against the oracle
+    olik = oracle_from_case(case, use_scipy=False)
+    from oracle import nmma_oracle as orc
+    rows = np.linspace(0, 4095, 64).astype(int)
+    want = orc.log_likelihood_batch(olik, case["names"], theta[rows])
+    assert rel_err(a[rows], want).max() <= LOGL_RTOL
+    eng.close()
