@@ -21,10 +21,13 @@ struct EmDev {
     // dims
     int32_t M, NP, KP, NH_pad, HB, NC, NT, NS, D, O;
     int32_t n_cosmo, redshift_mode, has_ebv, kmax;
+    int32_t st_uniform, pad0;     // sample_times equally spaced: bracket guess by division
+    double st0, st_inv_dt;
     // surrogate
     const float* wrec;        // [M][HB + 1][rec_floats(KP)]   (+1 zero record: branch-free prefetch)
     const float* b2;          // [M][16]
-    const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid)
+    const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
+    const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
     const double* mins;       // [M][NT]
     const double* span;       // [M][NT]   maxs - mins
     const double* pmin;       // [M][NP]

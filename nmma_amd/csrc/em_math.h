@@ -129,6 +129,12 @@ NM_HD_COLD double log_gauss_mass_neginf(double b) {
 // One detection: truncnorm.logpdf(m, a=-inf, b=(lim-est)/sigma, loc=est, scale=sigma)
 // rv_continuous.logpdf: NaN for invalid args (b NaN, b <= a, scale <= 0), -inf outside [a, b].
 NM_HD double detection_term(double m, double est, double sigma, double log_sigma, double lim) {
+    if (lim == dinf()) {   // untruncated: b = +inf for finite est (mass = log 1 = 0), NaN otherwise
+        if (!(est < dinf()) || !(sigma > 0)) return dnan();
+        const double x = (m - est) / sigma;
+        if (x != x) return dnan();
+        return ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - log_sigma;
+    }
     const double b = (lim - est) / sigma;
     if (!(b > -dinf()) || !(sigma > 0)) return dnan();   // also catches b = NaN (est = +inf)
     const double x = (m - est) / sigma;

@@ -4,7 +4,7 @@ import numpy as np
 
 def engine_from_case(case, device=0):
     from nmma_amd.engine import EMEngine
-    from nmma_amd.em.utils import resolve_sources
+    from nmma_amd.em.utils import resolve_sources, FILTER_AVERAGES
     obs = list(case["observed_filters"])
     lim = case["detection_limit"]
     if not isinstance(lim, dict):
@@ -12,7 +12,8 @@ def engine_from_case(case, device=0):
     return EMEngine(case["svd"], case["model_filters"], case["model_parameters"], case["names"],
                     sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
                     data=case["data"], observed_filters=obs,
-                    sources=resolve_sources(obs, case["model_filters"], known_filters=obs),
+                    sources=resolve_sources(obs, case["model_filters"],
+                                            known_filters=[f for f in obs if f not in FILTER_AVERAGES]),
                     detection_limit=lim, systematics=case["systematics"], device=device)
 
 

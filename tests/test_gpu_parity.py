@@ -63,7 +63,7 @@ def test_coefficients_and_lightcurves(name, torch_cuda):
             want = gold[f"s{i}_app_{k}"]
             fin = np.isfinite(want)
             assert np.array_equal(np.isfinite(mag[i, k]), fin)
-            np.testing.assert_allclose(mag[i, k][fin], want[fin], rtol=2e-6)
+            np.testing.assert_allclose(mag[i, k][fin], want[fin], rtol=0, atol=2e-5)  # fp32 coefficient noise x span
         np.testing.assert_allclose(tobs[i], gold[f"s{i}_obs_times"], rtol=1e-15)
     # ideal-fp32 coefficients (fp64 accumulation, order independent) for the whole batch
     p = olik.model.parameter_conversion(dict(zip(case["names"], case["theta"].T)))
