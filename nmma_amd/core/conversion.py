@@ -1,0 +1,94 @@
+"""Per-sample conversions on the EM path (host-side restatements used at setup time and
+by the single-sample convenience API; the batched path does them on the device).
+
+Mirrors ``nmma/core/conversion.py``: :30-34 distance modulus, :49-55 z(d_L) grid,
+:57-64 get_redshift, :119-126 observation_angle_conversion.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+#: Planck18 flat LCDM (astropy.cosmology.Planck18 parameters: H0, Om0, Tcmb0, Neff, m_nu)
+PLANCK18 = dict(H0=67.66, Om0=0.30966, Tcmb0=2.7255, Neff=3.046, m_nu=(0.0, 0.0, 0.06))
+
+
+def distance_modulus_nmma(d_lum=1e-5):
+    return 5.0 * (5 + np.log10(d_lum))
+
+
+def observation_angle_conversion(parameters):
+    theta_jn = parameters.get("theta_jn", np.arccos(parameters.get("cos_theta_jn", 1.0)))
+    theta_jn = np.minimum(theta_jn, np.pi - theta_jn)
+    if "KNtheta" not in parameters:
+        parameters["KNtheta"] = parameters.get("inclination_EM", theta_jn) * 180.0 / np.pi
+    if "inclination_EM" not in parameters:
+        parameters["inclination_EM"] = parameters["KNtheta"] / 180.0 * np.pi
+    return parameters
+
+
+class FlatLambdaCDM:
+    """Native flat LCDM luminosity distance (photons + massless/massive neutrinos as in
+    astropy's FlatLambdaCDM: massive species via the Komatsu et al. fitting function).
+    Replaces the astropy dependency of ``get_cosmo_grids``; parity vs astropy is
+    UNPINNED (astropy is absent from the build image) -- expected agreement ~1e-6."""
+
+    def __init__(self, H0=67.66, Om0=0.30966, Tcmb0=2.7255, Neff=3.046, m_nu=(0.0, 0.0, 0.06)):
+        self.H0, self.Om0 = H0, Om0
+        h = H0 / 100.0
+        # photon density: 4 sigma T^4 / c^3 / rho_crit
+        a_rad = 7.565733250280007e-15            # erg cm^-3 K^-4
+        rho_crit = 1.878341616e-29 * h ** 2      # g cm^-3
+        self.Ogamma0 = a_rad * Tcmb0 ** 4 / (2.99792458e10 ** 2) / rho_crit
+        self.Neff, self.m_nu = Neff, np.asarray(m_nu, dtype=float)
+        self.Tnu0 = 0.7137658555036082 * Tcmb0
+        self.nu_y = self.m_nu / (8.617333262e-5 * self.Tnu0)
+        self.neff_per_nu = Neff / len(self.m_nu)
+        self.Onu0 = self.Ogamma0 * self._nu_rel(0.0)
+        self.Ode0 = 1.0 - Om0 - self.Ogamma0 - self.Onu0
+
+    def _nu_rel(self, z):
+        prefac = 0.22710731766       # 7/8 (4/11)^(4/3)
+        p, invp, k = 1.83, 0.54644808743, 0.3173
+        z = np.asarray(z, dtype=float)
+        curr = self.nu_y[:, None] / (1.0 + np.atleast_1d(z))[None, :]
+        rel = (1.0 + (k * curr) ** p) ** invp
+        out = prefac * self.neff_per_nu * rel.sum(axis=0)
+        return out if z.ndim else float(out[0])
+
+    def inv_efunc(self, z):
+        zp1 = 1.0 + np.asarray(z, dtype=float)
+        org = self.Ogamma0 * (1.0 + self._nu_rel(z))
+        return 1.0 / np.sqrt(zp1 ** 3 * (org * zp1 + self.Om0) + self.Ode0)
+
+    def luminosity_distance(self, z):
+        """Mpc; composite Simpson on 2049 nodes per redshift."""
+        z = np.atleast_1d(np.asarray(z, dtype=float))
+        out = np.empty_like(z)
+        for i, zi in enumerate(z):
+            x = np.linspace(0.0, zi, 2049)
+            y = self.inv_efunc(x)
+            hstep = x[1] - x[0] if zi > 0 else 0.0
+            integ = hstep / 3.0 * (y[0] + y[-1] + 4 * y[1:-1:2].sum() + 2 * y[2:-1:2].sum())
+            out[i] = (1.0 + zi) * 299792.458 / self.H0 * integ
+        return out
+
+    def z_at_luminosity_distance(self, d):
+        lo, hi = 0.0, 1.0
+        while self.luminosity_distance(hi)[0] < d:
+            hi *= 2.0
+        for _ in range(100):
+            mid = 0.5 * (lo + hi)
+            if self.luminosity_distance(mid)[0] < d:
+                lo = mid
+            else:
+                hi = mid
+        return 0.5 * (lo + hi)
+
+
+def get_cosmo_grids(distance_min, distance_max, cosmology=None, n=50):
+    """(dist_grid, z_grid) with the layout of nmma/core/conversion.py:49-55."""
+    cosmology = cosmology or FlatLambdaCDM(**PLANCK18)
+    zmin = cosmology.z_at_luminosity_distance(distance_min)
+    zmax = cosmology.z_at_luminosity_distance(distance_max)
+    z_grid = np.geomspace(zmin, zmax, n)
+    return cosmology.luminosity_distance(z_grid), z_grid

@@ -1,0 +1,155 @@
+"""EM likelihood plugin (``nmma/em/em_likelihood.py``): ``EMTransientLikelihood``
+wrapping ``MultiFilterTransient`` -- same constructors, attributes and per-sample
+``log_likelihood(parameters)`` as the reference, plus the batched entry point
+``log_likelihood_batch(theta)`` that evaluates a whole live-point set in one launch.
+
+``OpticalLightCurve`` (the <=0.2.x name) is exported as an alias.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..core.base import LOGL_FLOOR, NMMALikelihood, fixed_value, is_constraint
+from . import utils
+
+
+class MultiFilterTransient:
+    """em_likelihood.py:266-354 (+ BasicEMTransient :136-263) on the GPU."""
+
+    def __init__(self, filters, light_curve_model, light_curve_data, systematics_handler, priors,
+                 detection_limit, verbose):
+        self.observed_filters = list(filters)
+        known = set(getattr(light_curve_model, "filters", None) or []) | \
+            {f for f in self.observed_filters if f not in utils.FILTER_AVERAGES}
+        self.model_filter_mapping, self.obs_average_mapping = utils.get_filter_name_mapping(
+            self.observed_filters, known)
+        self.light_curve_model = light_curve_model
+        self.light_curve_model.check_vs_priors(priors)
+        (self.light_curve_times, self.light_curves,
+         self.light_curve_uncertainties, self.trigger_time) = light_curve_data
+        systematics_handler.reset(self.light_curve_model.model_times, priors)
+        self.systematics_handler = systematics_handler
+        self.verbose = verbose
+        self.set_detection_limit(detection_limit)
+        self.priors = priors
+        self._engine, self._names = None, None
+
+    def set_detection_limit(self, detection_limit):
+        self.detection_limit = utils.set_filter_associated_dict(detection_limit, self.observed_filters)
+        self._engine = None
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} (light_curve_model={self.light_curve_model})"
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None          # rebuilt lazily per process (core/mpi_setup.py:614-636)
+        return state
+
+    # ---- theta layout -------------------------------------------------------------------
+    def sampling_layout(self):
+        """(names, fixed): sampled columns of theta and fixed parameter values, from the priors."""
+        names, fixed = [], {}
+        for key, prior in self.priors.items():
+            if is_constraint(prior):
+                continue
+            val = fixed_value(prior)
+            if val is None:
+                names.append(key)
+            else:
+                fixed[key] = val
+        return names, fixed
+
+    def engine(self, names=None):
+        from ..engine import EMEngine
+        if names is None:
+            names = self._names or self.sampling_layout()[0]
+        names = list(names)
+        if self._engine is None or names != self._names:
+            if self._engine is not None:
+                self._engine.close()
+            _, fixed = self.sampling_layout()
+            fixed = {k: v for k, v in fixed.items() if k not in names}
+            model = self.light_curve_model
+            obs = [f for f in self.observed_filters if len(self.light_curve_times[f]) > 0]
+            sources = utils.resolve_sources(obs, model.gpu_filters,
+                                            known_filters=set(self.model_filter_mapping.values()))
+            self._engine = EMEngine(
+                parameter_names=names, fixed=fixed,
+                data=(self.light_curve_times, self.light_curves, self.light_curve_uncertainties),
+                observed_filters=obs, sources=sources, detection_limit=self.detection_limit,
+                systematics=self.systematics_handler.kernel_spec(), **model.engine_kwargs())
+            self._names = names
+        return self._engine
+
+    # ---- evaluation -------------------------------------------------------------------
+    def log_likelihood(self, parameters):
+        """One parameter dict -> float (em_likelihood.py:186-204)."""
+        names = self._names or self.sampling_layout()[0]
+        names = [n for n in names if n in parameters] if self._names is None else names
+        eng = self.engine(names)
+        theta = np.array([[float(parameters[n]) for n in eng.parameter_names]])
+        val = float(eng.loglike(theta)[0])
+        if self.verbose:
+            print(parameters, val)
+        return -np.inf if val == LOGL_FLOOR else val
+
+    def log_likelihood_batch(self, theta, names=None):
+        """theta[B, D] (numpy or torch CUDA tensor; columns = ``names`` or the sampled prior
+        keys) -> logL[B] with the reference's floor already applied."""
+        return self.engine(names).loglike(theta)
+
+    def final_diagnostics(self, bestfit_params, args, result=None):
+        return self.light_curve_model.gen_detector_lc(dict(bestfit_params))
+
+
+class EMTransientLikelihood(NMMALikelihood):
+    """A generic EM transient likelihood object (em_likelihood.py:42-133)."""
+
+    def __init__(self, light_curve_model, light_curve_data, systematics_handler, priors, filters=None,
+                 detection_limit=np.inf, verbose=False, **kwargs):
+        if not filters:
+            filters = list(light_curve_data[0].keys())
+        sub_model = MultiFilterTransient(filters, light_curve_model, light_curve_data, systematics_handler,
+                                         priors, detection_limit, verbose)
+        super().__init__(sub_model, priors, **kwargs)
+
+    def setup_submodel_conversion(self):
+        self.conv_functions.append(self.sub_model.light_curve_model.parameter_conversion)
+
+    def sanity_checks(self):
+        return self.sub_model.light_curve_model.good_parameters
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} based on {self.sub_model.__repr__()}"
+
+    def log_likelihood(self, parameters=None):
+        if parameters is None:
+            parameters = self.parameters
+        return float(super().log_likelihood(dict(parameters)))
+
+    def log_likelihood_batch(self, theta, names=None):
+        """Batched ``log_likelihood``: every row of ``theta`` is one parameter vector.
+        Conversions (KNtheta <- inclination_EM, log10 aliases), z(d_L), distance modulus,
+        systematics and the floor are all applied on the device."""
+        if self.constraints:
+            raise NotImplementedError("Constraint priors are evaluated per sample by the sampler; "
+                                      "use log_likelihood() or filter theta beforehand")
+        return self.sub_model.log_likelihood_batch(theta, names)
+
+    def parameter_names(self):
+        return self.sub_model.sampling_layout()[0]
+
+    def posterior_conversion(self, posterior_samples):
+        """em_likelihood.py:122-131."""
+        if "log10_mej_dyn" in posterior_samples and "log10_mej_wind" in posterior_samples:
+            posterior_samples["log10_mej"] = np.log10(10 ** posterior_samples["log10_mej_wind"]
+                                                      + 10 ** posterior_samples["log10_mej_dyn"])
+        return posterior_samples
+
+    def final_diagnostics(self, bestfit_params, args, result=None):
+        return self.sub_model.final_diagnostics(bestfit_params, args, result)
+
+
+#: legacy (<= 0.2.x) name used by BASELINE.json's north_star
+OpticalLightCurve = EMTransientLikelihood

@@ -1,0 +1,129 @@
+"""On-disk formats of the EM path.
+
+* ``save_svd_model`` / ``load_svd_model``: the flat tensor file (one ``.npz``) this
+  framework reads -- ``{filter}/W1,b1,W2,b2,VA,mins,maxs,tt,param_mins,param_maxs,n_coeff``.
+* ``convert_reference_model``: reads the reference's own layout
+  (``{model}.joblib`` + ``{model}[_tf]/{filter}.keras|.h5``, nmma/em/model.py:593-696)
+  when joblib and keras/h5py are importable, and writes the flat file.
+* ``load_em_observations``: the ``time filter mag mag_error`` text photometry format
+  (nmma/em/io.py:116-144; ISO-T times or MJD floats).
+"""
+from __future__ import annotations
+
+import os
+from datetime import datetime, timezone
+
+import numpy as np
+
+_KEYS = ("W1", "b1", "W2", "b2", "VA", "mins", "maxs", "tt", "param_mins", "param_maxs")
+
+
+def save_svd_model(path, svd_model, model_parameters=None):
+    flat = {}
+    for filt, t in svd_model.items():
+        n_c = int(t["n_coeff"])
+        for k in _KEYS:
+            a = np.asarray(t[k])
+            if k == "VA":
+                a = a[:, :n_c]
+            flat[f"{filt}/{k}"] = a
+        flat[f"{filt}/n_coeff"] = np.int64(n_c)
+    if model_parameters is not None:
+        flat["__model_parameters__"] = np.array(list(model_parameters))
+    np.savez_compressed(path, **flat)
+
+
+def load_svd_model(path):
+    """Returns ``(svd_model, model_parameters or None)``."""
+    svd, params = {}, None
+    with np.load(path, allow_pickle=False) as z:
+        for name in z.files:
+            if name == "__model_parameters__":
+                params = [str(x) for x in z[name]]
+                continue
+            filt, key = name.rsplit("/", 1)
+            svd.setdefault(filt, {})[key] = z[name]
+    for filt, t in svd.items():
+        t["n_coeff"] = int(t["n_coeff"])
+        for k in ("W1", "b1", "W2", "b2"):
+            t[k] = np.ascontiguousarray(t[k], dtype=np.float32)
+        for k in ("VA", "mins", "maxs", "tt", "param_mins", "param_maxs"):
+            t[k] = np.ascontiguousarray(t[k], dtype=np.float64)
+    return svd, params
+
+
+def _dense_weights_from_h5(path):
+    """Kernel/bias pairs of a two-layer Keras model saved as legacy HDF5."""
+    import h5py
+    out = []
+    with h5py.File(path, "r") as f:
+        grp = f["model_weights"] if "model_weights" in f else f
+
+        def visit(name, obj):
+            if isinstance(obj, h5py.Dataset) and name.endswith(("kernel:0", "bias:0", "kernel", "bias")):
+                out.append((name, np.array(obj)))
+        grp.visititems(visit)
+    kernels = sorted((n, a) for n, a in out if "kernel" in n)
+    biases = sorted((n, a) for n, a in out if "bias" in n)
+    kernels.sort(key=lambda na: na[1].shape[0] != min(k[1].shape[0] for k in kernels))
+    (_, w1), (_, w2) = kernels
+    b1 = next(a for _, a in biases if a.shape[0] == w1.shape[1])
+    b2 = next(a for _, a in biases if a.shape[0] == w2.shape[1] and a is not b1)
+    return w1, b1, w2, b2
+
+
+def convert_reference_model(svd_path, model, out_path, filters=None, interpolation_type="tensorflow"):
+    """Read the reference's model files and write the flat tensor file."""
+    import joblib
+    core = "_".join(c for c in model.split("_") if c != "tf")
+    meta = joblib.load(os.path.join(svd_path, f"{core}.joblib"))
+    meta = {k.replace("_", ":"): v for k, v in meta.items()}          # model.py:604-606
+    spec = "_tf" if interpolation_type == "tensorflow" else ""
+    svd = {}
+    for filt in (filters or list(meta)):
+        base = os.path.join(svd_path, f"{model}{spec}", filt.replace(":", "_"))
+        if os.path.isfile(base + ".keras"):
+            import keras
+            net = keras.saving.load_model(base + ".keras", compile=False)
+            dense = [l for l in net.layers if l.get_weights()]
+            (w1, b1), (w2, b2) = (l.get_weights() for l in dense)
+        elif os.path.isfile(base + ".h5"):
+            w1, b1, w2, b2 = _dense_weights_from_h5(base + ".h5")
+        else:
+            raise FileNotFoundError(f"no .keras/.h5 network for filter {filt} under {base}")
+        m = meta[filt]
+        svd[filt] = dict(W1=np.float32(w1), b1=np.float32(b1), W2=np.float32(w2), b2=np.float32(b2),
+                         VA=np.asarray(m["VA"], float), mins=np.asarray(m["mins"], float),
+                         maxs=np.asarray(m["maxs"], float), tt=np.asarray(m["tt"], float),
+                         param_mins=np.asarray(m["param_mins"], float),
+                         param_maxs=np.asarray(m["param_maxs"], float), n_coeff=int(m["n_coeff"]))
+    save_svd_model(out_path, svd)
+    return svd
+
+
+def _to_mjd(token):
+    try:
+        return float(token)
+    except ValueError:
+        dt = datetime.fromisoformat(token).replace(tzinfo=timezone.utc)
+        return dt.timestamp() / 86400.0 + 40587.0
+
+
+def load_em_observations(path, filters=None):
+    """``{filter: {"time": mjd[], "mag": [], "mag_error": []}}`` sorted by time
+    (rows: ``time filter mag mag_error``; ``inf`` error marks an upper limit)."""
+    rows = {}
+    with open(path) as fh:
+        for line in fh:
+            parts = line.split()
+            if len(parts) < 4 or parts[0].startswith("#"):
+                continue
+            t, filt, mag, err = _to_mjd(parts[0]), parts[1], float(parts[2]), float(parts[3])
+            if filters is not None and filt not in filters:
+                continue
+            rows.setdefault(filt, []).append((t, mag, err))
+    out = {}
+    for filt, r in rows.items():
+        a = np.array(sorted(r))
+        out[filt] = {"time": a[:, 0], "mag": a[:, 1], "mag_error": a[:, 2]}
+    return out

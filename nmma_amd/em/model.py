@@ -1,0 +1,243 @@
+"""Light-curve model plugin API (``nmma/em/model.py:175-408``) and the SVD surrogate
+model (:535-731) evaluated on the GPU.
+
+``SVDLightCurveModel`` keeps the reference's constructor and attributes
+(``model, model_parameters, filters, model_times, good_parameters, svd_mag_model``) and
+its methods (``check_vs_priors, parameter_conversion, gen_detector_lc,
+generate_lightcurve, em_parameter_setup``); the arithmetic of ``calc_svd_lc`` /
+``eval_svd_model`` / ``combine_detector_data`` runs in the HIP kernels through
+:class:`nmma_amd.engine.EMEngine`.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ..core.conversion import get_cosmo_grids, observation_angle_conversion
+from . import io as em_io
+
+#: surrogate inputs per model family, order matters (nmma/em/model.py:29-125)
+model_parameters_dict = {
+    "Bu2019nsbh": ["log10_mej_dyn", "log10_mej_wind", "KNtheta"],
+    "Bu2019lm": ["log10_mej_dyn", "log10_mej_wind", "KNphi", "KNtheta"],
+    "Bu2019lm_sparse": ["log10_mej_dyn", "log10_mej_wind"],
+    "Ka2017": ["log10_mej", "log10_vej", "log10_Xlan"],
+    "Bu2022mv": ["log10_mej_dyn", "vej_dyn", "log10_mej_wind", "vej_wind", "KNtheta"],
+    "Bu2022Ye": ["log10_mej_dyn", "vej_dyn", "Yedyn", "log10_mej_wind", "vej_wind", "KNtheta"],
+    "Bu2023Ye": ["log10_mej_dyn", "vej_dyn", "Yedyn", "log10_mej_wind", "vej_wind", "Yewind", "KNtheta"],
+    "LANL2022": ["log10_mej_dyn", "vej_dyn", "log10_mej_wind", "vej_wind", "KNtheta"],
+    "AnBa2022_sparse": ["mrp", "xmix"],
+    "AnBa2022_log": ["log10_mtot", "log10_mni", "vej", "log10_mrp", "xmix"],
+    "AnBa2022_linear": ["mtot", "mni", "vej", "mrp", "xmix"],
+}
+for _n in ("LANLTP1", "LANLTP2", "LANLTS1", "LANLTS2"):
+    model_parameters_dict[_n] = list(model_parameters_dict["LANL2022"])
+
+
+class LightCurveModelContainer:
+    """Parent class of light-curve models (model.py:175-408): the host-side protocol."""
+
+    extinction_law = "P92_SMC_host"
+
+    def __init__(self, model, filters=None, model_parameters=None, sample_times=None):
+        if model_parameters is None:
+            assert model in model_parameters_dict, f"{model} unknown, please pass model_parameters"
+            self.model_parameters = list(model_parameters_dict[model])
+        else:
+            self.model_parameters = list(model_parameters)
+        self.model = model
+        if isinstance(filters, str):
+            filters = filters.split(",")
+        self.filters = filters
+        self.good_parameters = True
+        self.cosmo_grid = None
+        self.model_times = np.asarray(sample_times, float) if sample_times is not None else self.setup_model_times()
+
+    def __repr__(self):
+        return self.__class__.__name__ + f"(model={self.model})"
+
+    def setup_model_times(self, tmin=0.01, tmax=14.0, nsteps=150):
+        return np.geomspace(tmin, tmax, nsteps)
+
+    def check_vs_priors(self, priors):
+        """model.py:247-267: warn about missing parameters; build the z(d_L) grid once."""
+        for key in self.model_parameters:
+            if key not in priors and key != "KNtheta":
+                print(f"Parameter {key} not found in priors, might fail.")
+        if "redshift" not in priors and "luminosity_distance" in priors:
+            pr = priors["luminosity_distance"]
+            lo, hi = getattr(pr, "minimum", None), getattr(pr, "maximum", None)
+            if lo is not None and hi is not None and hi > lo and self.cosmo_grid is None:
+                self.cosmo_grid = get_cosmo_grids(lo, hi, getattr(pr, "cosmology", None))
+
+    def sanity_checks(self, parameters):
+        self.good_parameters = True
+
+    def parameter_conversion(self, parameters):
+        """model.py:272-286."""
+        new = observation_angle_conversion(parameters)
+        for key in self.model_parameters:
+            if key not in new:
+                if key.lstrip("log10_") in new.keys():
+                    new[key] = np.log10(new[key.lstrip("log10_")])
+                elif "log10_" + key in new.keys():
+                    new[key] = 10 ** new["log10_" + key]
+        self.sanity_checks(new)
+        return new
+
+    @property
+    def citation(self):
+        return {self.model: []}
+
+
+class SVDLightCurveModel(LightCurveModelContainer):
+    """SVD surrogate light-curve model on the GPU (reference: model.py:535-731).
+
+    ``svd_path`` may be (i) a flat ``.npz`` written by :func:`nmma_amd.em.io.save_svd_model`,
+    (ii) a directory holding ``{model}.npz``, or (iii) the reference's own layout
+    (``{model}.joblib`` + per-filter ``.keras/.h5``), converted on the fly when
+    joblib + keras/h5py are importable.  ``svd_mag_model`` (a dict of tensors) may also
+    be passed directly.
+    """
+
+    def __init__(self, model, svd_path=None, svd_mag_ncoeff=None, svd_lbol_ncoeff=None,
+                 interpolation_type="keras", model_parameters=None, filters=None, sample_times=None,
+                 local_only=True, svd_mag_model=None, cosmo_grid=None, ebv_coeff=None, device=0,
+                 **em_model_kwargs):
+        comps = model.split("_")
+        if "tf" in comps:
+            comps.remove("tf")
+        core = "_".join(comps)
+        self.mag_ncoeff = svd_mag_ncoeff
+        self.lbol_ncoeff = svd_lbol_ncoeff
+        self.interpolation_type = interpolation_type
+        if interpolation_type not in ("keras", "tensorflow", "torch", "jax"):
+            raise ValueError("nmma_amd evaluates the neural-network surrogates only "
+                             "(--interpolation-type keras/tensorflow); GP surrogates are out of scope")
+        self.svd_path = svd_path
+        file_params = None
+        if svd_mag_model is None:
+            svd_mag_model, file_params = self._load(core, svd_path, filters, interpolation_type)
+        self.svd_mag_model = {k.replace("_", ":") if "::" not in k and "__" in k else k: v
+                              for k, v in svd_mag_model.items()}
+        self.svd_lbol_model = None
+        if model_parameters is None and file_params is not None and core not in model_parameters_dict:
+            model_parameters = file_params
+        super().__init__(core, filters, model_parameters, sample_times)
+        if self.filters is None:
+            self.filters = list(self.svd_mag_model.keys())
+        missing = [f for f in self.filters if f not in self.svd_mag_model]
+        if missing:
+            print(f"Warning: no surrogate for filters {missing}; they evaluate to +inf "
+                  "(nmma/em/lightcurve_generation.py:168-169)")
+        self.cosmo_grid = cosmo_grid
+        self.ebv_coeff = ebv_coeff
+        self.device = device
+        self._lc_engine, self._lc_names = None, None
+
+    @staticmethod
+    def _load(core, svd_path, filters, interpolation_type):
+        if svd_path is None:
+            raise ValueError("svd_path (or svd_mag_model) is required: model download is out of scope")
+        if os.path.isfile(svd_path):
+            return em_io.load_svd_model(svd_path)
+        flat = os.path.join(svd_path, f"{core}.npz")
+        if os.path.isfile(flat):
+            return em_io.load_svd_model(flat)
+        if os.path.isfile(os.path.join(svd_path, f"{core}.joblib")):
+            itype = "tensorflow" if os.path.isdir(os.path.join(svd_path, f"{core}_tf")) else interpolation_type
+            return em_io.convert_reference_model(svd_path, core, flat, filters, itype), None
+        raise ValueError(f"Model file not found under {svd_path}")
+
+    def setup_model_times(self):
+        return next(iter(self.svd_mag_model.values()))["tt"]
+
+    def __repr__(self):
+        return super().__repr__() + f"(model={self.model}, svd_path={self.svd_path})"
+
+    # ---- engine plumbing ------------------------------------------------------------
+    @property
+    def gpu_filters(self):
+        """model filters that have a surrogate (the others are all-inf in the reference)."""
+        return [f for f in self.filters if f in self.svd_mag_model]
+
+    def engine_kwargs(self):
+        return dict(svd_model=self.svd_mag_model, model_filters=self.gpu_filters,
+                    model_parameters=self.model_parameters,
+                    sample_times=None if self._default_times() else self.model_times,
+                    cosmo_grid=self.cosmo_grid, ebv_coeff=self.ebv_coeff, device=self.device,
+                    n_coeff=self.mag_ncoeff)
+
+    def _default_times(self):
+        tt = next(iter(self.svd_mag_model.values()))["tt"]
+        return len(self.model_times) == len(tt) and np.array_equal(self.model_times, tt)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_lc_engine"], state["_lc_names"] = None, None      # GPU handles never travel
+        return state
+
+    # ---- reference API: per-sample light curves ---------------------------------------
+    def gen_detector_lc(self, parameters=None, sample_times=None):
+        """(obs_times[NS], {filt: mag_app[NS]}) -- model.py:352-404.  ``parameters`` may hold
+        scalars (one light curve) or equal-length arrays (a batch: mags are [B, NS])."""
+        from ..engine import EMEngine
+        import torch
+        if sample_times is not None and not np.array_equal(sample_times, self.model_times):
+            self.model_times = np.asarray(sample_times, float)
+            self._lc_engine = None
+        names = sorted(k for k, v in parameters.items() if np.ndim(v) <= 1 and _is_number(v))
+        if self._lc_engine is None or names != self._lc_names:
+            if self._lc_engine is not None:
+                self._lc_engine.close()
+            self._lc_engine = EMEngine(parameter_names=names, **self.engine_kwargs())
+            self._lc_names = names
+        cols = [np.atleast_1d(np.asarray(parameters[k], float)) for k in names]
+        n = max(len(c) for c in cols)
+        theta = np.stack([np.broadcast_to(c, (n,)) for c in cols], axis=1)
+        tobs, mag = self._lc_engine.lightcurves(torch.as_tensor(theta))
+        tobs, mag = tobs.cpu().numpy(), mag.cpu().numpy()
+        scalar = all(np.ndim(parameters[k]) == 0 for k in names)
+        lc = {}
+        gi = {f: i for i, f in enumerate(self.gpu_filters)}
+        for f in self.filters:
+            if f in gi:
+                lc[f] = mag[0, gi[f]] if scalar else mag[:, gi[f]]
+            else:
+                lc[f] = np.full(tobs.shape[1] if scalar else tobs.shape, np.inf)
+        return (tobs[0] if scalar else tobs), lc
+
+    def generate_lightcurve(self, sample_times, parameters, filters="all"):
+        """Absolute-magnitude light curves (model.py:707-728): the detector-frame result with
+        distance / redshift / timeshift neutralised."""
+        p = dict(parameters)
+        p.update(luminosity_distance=1e-5, timeshift=0.0, Ebv=0.0)
+        p.pop("redshift", None)
+        grid, self.cosmo_grid = self.cosmo_grid, None
+        try:
+            self._lc_engine = None
+            _, lc = self.gen_detector_lc(p, sample_times)
+        finally:
+            self.cosmo_grid = grid
+            self._lc_engine = None
+        if filters not in ("all", None):
+            lc = {f: lc[f] for f in filters}
+        return lc
+
+
+def _is_number(v):
+    try:
+        np.asarray(v, dtype=float)
+        return True
+    except (TypeError, ValueError):
+        return False
+
+
+def create_light_curve_model_from_args(model_name, args, filters=None, sample_times=None):
+    """Factory with the reference's shape (model.py:1591-1614) for SVD models."""
+    return SVDLightCurveModel(
+        model_name, svd_path=getattr(args, "svd_path", None),
+        svd_mag_ncoeff=getattr(args, "svd_mag_ncoeff", None),
+        interpolation_type=getattr(args, "interpolation_type", "keras"),
+        filters=filters, sample_times=sample_times, local_only=True)

@@ -1,0 +1,72 @@
+"""schwimmbad-style pool whose ``map`` evaluates a whole list of parameter vectors in ONE
+kernel launch -- the batching seam of the reference's samplers
+(``nmma/core/mpi_setup.py:282-285, :298-303, :339, :651-654``: ``sampler.pool`` /
+``queue_size`` / ``mapper = pool.map``; pool API = ``map``, ``size``, ``is_master()``,
+context manager).
+
+Usage with dynesty / parallel-bilby style drivers::
+
+    pool = GPUPool(likelihood, queue_size=4096)
+    sampler = dynesty.NestedSampler(pool.log_likelihood, prior_transform, ndim,
+                                    pool=pool, queue_size=pool.size, use_pool={"loglikelihood": True})
+
+``pool.map(pool.log_likelihood, thetas)`` recognises its own callable and sends the list
+to the GPU as one batch; any other function is mapped serially on the host.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class GPUPool:
+    def __init__(self, likelihood, queue_size=4096, names=None):
+        self.likelihood = likelihood
+        self.size = int(queue_size)
+        self.names = names
+        self.n_batches = 0
+        self.n_evals = 0
+
+    # ---- schwimmbad surface
+    def is_master(self):
+        return True
+
+    def is_worker(self):
+        return False
+
+    def wait(self, callback=None):
+        return None
+
+    def close(self):
+        return None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    # ---- the batched callable
+    def log_likelihood(self, theta):
+        """One vector -> float (what the sampler thinks it maps)."""
+        return float(self.log_likelihood_many([theta])[0])
+
+    def log_likelihood_many(self, thetas):
+        theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
+        out = self.likelihood.log_likelihood_batch(theta, self.names)
+        self.n_batches += 1
+        self.n_evals += len(theta)
+        return np.asarray(out)
+
+    def map(self, func, iterable, callback=None):
+        items = list(iterable)
+        if not items:
+            return []
+        if getattr(func, "__self__", None) is self and getattr(func, "__func__", None) is GPUPool.log_likelihood:
+            res = list(self.log_likelihood_many(items))
+        else:
+            res = [func(it) for it in items]
+        if callback is not None:
+            for r in res:
+                callback(r)
+        return res

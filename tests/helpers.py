@@ -25,3 +25,31 @@ def oracle_from_case(case, **kw):
 def rel_err(got, want):
     got, want = np.asarray(got, float), np.asarray(want, float)
     return np.abs(got - want) / np.maximum(1.0, np.abs(want))
+
+
+class SimplePrior:
+    """Minimal stand-in for a bilby prior (bilby is not installed in this image)."""
+
+    def __init__(self, minimum=None, maximum=None, peak=None):
+        self.minimum, self.maximum = minimum, maximum
+        if peak is not None:
+            self.peak = peak
+
+
+def plugin_from_case(case, device=0, verbose=False):
+    """The reference-shaped objects (model, systematics handler, likelihood) for a case."""
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"],
+                               model_parameters=case["model_parameters"], sample_times=case["sample_times"],
+                               cosmo_grid=case["cosmo_grid"], device=device)
+    times, mags, sigmas = case["data"]
+    kw = case["systematics_ref"]
+    handler = FilterSystematicsHandler(case["observed_filters"], systematics_file=kw["systematics_file"],
+                                       error_budget=kw["error_budget"], light_curve_times=times)
+    lik = EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, priors,
+                                filters=case["observed_filters"], detection_limit=case["detection_limit"],
+                                verbose=verbose)
+    return model, handler, lik
