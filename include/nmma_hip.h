@@ -172,6 +172,12 @@ int64_t nmma_em_flops_per_eval(const nmma_em_handle* h);   /* SURVEY.md section 
 int32_t nmma_em_last_launch_geometry(const nmma_em_handle* h, int32_t* grid_x, int32_t* grid_y,
                                      int32_t* block, int32_t* tile_samples, int32_t* lds_bytes);
 
+/* Diagnostics: run nmma_em_loglike once and return 128 shader-clock stamps taken inside
+ * workgroup 0 (entries 2k, 2k+1: MFMA role around the MLP of work item k; 64+2k, 64+2k+1:
+ * VALU role around the downstream phase of item k-1; 64, 65: prologue).  Synchronous. */
+int32_t nmma_em_debug_timeline(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                               double* out_dev, int64_t* stamps_host);
+
 /* HIP-event timing of the dominant kernel on the launch stream: between begin and end
  * every nmma_em_loglike call brackets its fused per-filter kernel with two events. */
 int32_t nmma_em_profile_begin(nmma_em_handle* h, int32_t max_launches);

@@ -17,6 +17,17 @@ __host__ __device__ constexpr int rec_floats(int kp) { return 256 + 64 * kp + 16
 
 enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2 };
 
+// One work item of em_logl: (observed filter o, its ks-th source model filter m), with
+// everything the downstream phase needs about it (copied to LDS once per workgroup).
+struct ItemDesc {
+    int32_t o, ks, m, nsrc;
+    int32_t G, d0, nf, kind;
+    int32_t jlo, jhi, identity, same_grid;
+    double lim, e_const, ebvc, pad;
+    int32_t pad2[4];
+};
+static_assert(sizeof(ItemDesc) == 24 * 4, "ItemDesc must be ITEM_WORDS words");
+
 struct EmDev {
     // dims
     int32_t M, NP, KP, NH_pad, HB, NC, NT, NS, D, O;
@@ -24,7 +35,7 @@ struct EmDev {
     int32_t st_uniform, pad0;     // sample_times equally spaced: bracket guess by division
     double st0, st_inv_dt;
     // surrogate
-    const float* wrec;        // [M][HB + 1][rec_floats(KP)]   (+1 zero record: branch-free prefetch)
+    const float* wrec;        // [M][HB + NPAD_REC][rec_floats(KP)]   (zero records: branch-free prefetch)
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
     const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
@@ -56,6 +67,14 @@ struct EmDev {
     const int32_t* nsrc;      // [O]
     const int32_t* src;       // [O][3]
     const int32_t* group;     // [O]  lanes cooperating on one sample (power of two <= 64)
+    // packed per-model-filter static tables staged in LDS by em_logl:
+    //   [VA NT*NC f64 | span NT f64 | mins NT f64 | s1_dx NS f64 | s1_off NS f64 | s1_idx NS i32 | b2 16 f32], 1-KiB padded
+    const unsigned char* tab;
+    int32_t tab_bytes, tab_off_span, tab_off_mins, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
+    const ItemDesc* item_desc;   // [n_items]
+    // work items of em_logl: (observed filter, source index, model filter, n sources) x n_items
+    const int32_t* items;
+    int32_t n_items, n_sys_slots;
     // systematics
     const int32_t* sys_kind;  // [O]
     const double* sys_const;  // [O]

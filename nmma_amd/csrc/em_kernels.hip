@@ -1,29 +1,38 @@
 // em_kernels.hip -- gfx950 kernels of the batched EM light-curve log-likelihood.
 //
-// One launch of em_fused<R, WPB, KP> evaluates, for a tile of TS = 16*R parameter vectors
-// and ONE observed filter (blockIdx.y), the whole per-filter chain of the reference:
+// em_logl<R, KP>  (the hot path: nmma_em_loglike)
+//   One 8-wave workgroup owns a tile of TS = 16*R parameter vectors and walks the work
+//   items (observed filter, source model filter) of the likelihood.  The waves are
+//   specialised, one of each kind per SIMD:
+//     waves 0-3  "MFMA waves": the surrogate MLP of item k+1
+//                x = (theta - pmin)/(pmax - pmin)          lightcurve_generation.py:193-194
+//                c = Dense(relu)(x) -> Dense  (fp32)       lightcurve_generation.py:198
+//     waves 4-7  "VALU waves": everything downstream of the coefficients of item k (fp64)
+//                mag = (VA[:, :NC] @ c)*(maxs-mins)+mins   lightcurve_generation.py:214-216
+//                stage-1 lerp onto sample_times, +inf out  lightcurve_generation.py:177
+//                t_obs = t*(1+z)+timeshift, app = mag+ext+distmod-2.5log10(1+z)  model.py:374-404
+//                stage-2 lerp onto the data epochs         em_likelihood.py:313-335
+//                truncated-Gaussian / logsf terms, sum     em_likelihood.py:224-256, :337-352
+//   so the f32 MFMA pipe and the f64 VALU pipe of every SIMD work concurrently; the two
+//   roles meet at one workgroup barrier per item (coefficients handed over in LDS,
+//   double-buffered).  The final sum over filters and the floor (core/base.py:82, :180)
+//   happen in the same launch.
 //
-//   x = (theta - pmin)/(pmax - pmin)              lightcurve_generation.py:193-194
-//   c = Dense(relu)(x) -> Dense                   lightcurve_generation.py:198 (Keras fp32)
-//   mag = (VA[:, :NC] @ c) * (maxs - mins) + mins lightcurve_generation.py:214-216 (fp64)
-//   stage-1 lerp onto sample_times, +inf outside  lightcurve_generation.py:177 -> utils.py:642-645
-//   t_obs = t*(1+z)+timeshift, app = mag+ext+distmod-2.5log10(1+z)   model.py:374, :381-404
-//   stage-2 lerp onto the data epochs, +inf outside                   em_likelihood.py:313-335
-//   sum of truncated-Gaussian / logsf terms                          em_likelihood.py:224-256
+//   MLP on the matrix cores: both Dense layers chained without a transpose -- layer 1
+//   produces H^T[hidden 16 x sample 16] whose accumulator registers ARE the B operands of
+//   layer 2 (C^T[coef 16 x sample 16] += W2^T[coef x 4 hidden] H^T).  Each MFMA wave owns
+//   a contiguous run of hidden units and streams its pre-swizzled weight records
+//   straight from L2 into a ring of VGPRs PF records deep (no LDS: nothing is shared
+//   between waves).  Hidden units are always reduced as NSLICE = 8 partial sums in slice
+//   order, so the fp32 result does not depend on the launch geometry.
 //
-// Phase A (the FLOPs): both Dense layers on the f32 MFMA pipe, chained without a
-// transpose: layer 1 produces H^T[hidden 16 x sample 16] whose accumulator registers ARE
-// the B operands of layer 2 (C^T[coef 16 x sample 16] += W2^T[coef x 4 hidden] H^T).
-// Each wave owns a contiguous run of hidden units and streams its pre-swizzled weight
-// records straight from L2 into VGPRs (no LDS: nothing is shared between waves).
-// Phase B (fp64 VALU): lane groups walk the ragged data of the filter; every datum
-// brackets its epoch on the redshifted grid and reconstructs ONLY the light-curve nodes
-// it interpolates between (2, or 4 when sample_times differ from the SVD grid) from the
-// LDS-resident basis rows -- same arithmetic per node as the dense reconstruction.
-// MODE_LC (gen_detector_lc for plots/tests) reconstructs the whole curve instead.
+//   Downstream: lane groups walk the ragged data of a filter; every datum brackets its
+//   epoch on the redshifted grid and reconstructs ONLY the light-curve nodes it
+//   interpolates between (2, or 4 when sample_times differ from the SVD grid) -- the
+//   same arithmetic per node as the dense reconstruction.
 //
-// em_combine adds the per-filter partial sums in the reference's order and applies the
-// floor (core/base.py:82, :180-181).
+// em_fused<MODE, R, WPB, KP>  (auxiliary outputs: coefficients, full light curves for
+//   gen_detector_lc) shares the MLP scheme with all waves on the MFMA pipe first.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -45,11 +54,15 @@ __device__ __forceinline__ gcf32p as_global(const float* p) { return (gcf32p)(ui
 __device__ __forceinline__ gcf64p as_global(const double* p) { return (gcf64p)(uintptr_t)p; }
 __device__ __forceinline__ gci32p as_global(const int* p) { return (gci32p)(uintptr_t)p; }
 
-// relu on an MFMA result through a builtin the compiler can see: v_med3_f32(x, 0, +inf).
-// (An inline-asm v_max is invisible to hipcc's hazard recogniser -- it left only 1 wait
-// state between the asm's VGPR write and the MFMA reading it as SrcB, and the R=1/KP=2
-// instantiation read stale operands.)
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// relu on an MFMA result as ONE integer VALU op: for IEEE-754 bit patterns max_i32(bits, 0)
+// is x for x >= +0 and +0 for every negative value (and -0).  A float max costs two ops
+// (hipcc canonicalises MFMA outputs first), and in the one-wave-per-SIMD MLP loop every
+// filler instruction beyond ~5 per MFMA gap delays the next MFMA issue.  (NaN inputs are
+// caught before the MLP: S_BAD.)
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
 // Opaque identity: stops InstCombine from folding phi(load, load) into load(phi(addr)),
 // which would move every prefetched weight load back to its use (no latency hiding).
@@ -59,490 +72,672 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 // Hidden units are always split into NSLICE partial sums added in slice order, so the
 // fp32 result does not depend on the launch geometry (R, WPB) chosen for a batch size.
 constexpr int NSLICE = 8;
-
-// Byte offsets of the LDS carve-up (computed by the host with lds_layout()).
-struct LdsOff {
-    int32_t part, cd, xs, praw, scal, sysv, stl, s1i, s1dx, s1of, va, span, mins, mag, est, total;
-    int32_t SB;        // MODE_LC: samples per dense reconstruction sub-batch
-    int32_t nf_max;    // widest averaged filter (est buffer row length), 0 if none
-};
+// zero records appended to every model filter's weight stream (deepest prefetch ring + 1)
+constexpr int NPAD_REC = 9;
+// row stride (floats) of the LDS partial-sum tiles: 16 coefficients + 1 pad (bank spread)
+constexpr int PSTR = 17;
+// per-model-filter static tables staged in LDS by em_logl (LDS-DMA, 1 KiB per wave-instruction)
+constexpr int TAB_MAX_BYTES = 40 * 1024;
+// 32-bit words of one work-item descriptor of em_logl (see em_device.h: ItemDesc)
+constexpr int ITEM_WORDS = 24;
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 
-__host__ inline LdsOff lds_layout(int mode, int R, int NC, int NT, int NS, int kmax, int nf_avg_max) {
+enum ScalIdx { S_ZP1 = 0, S_TS = 1, S_DMOD = 2, S_RC = 3, S_EBV = 4, S_BAD = 5, S_IZP1 = 6 };
+
+// ---------------------------------------------------------------------------------------
+// Surrogate MLP on the f32 MFMA pipe for NSL consecutive hidden slices of one wave.
+//   rec   : first weight record of this wave's run (records are contiguous per wave)
+//   xB    : layer-1 B operands, lane l holds x[sample rb*16 + (l&15)][param 4*kp + (l>>4)]
+//   part  : LDS [NSLICE][R][16 sample][PSTR] partial sums (coef fastest); slices slice0 .. slice0+NSL-1
+// PF records are kept in flight in a register ring (loads of record g+PF are issued while
+// record g is consumed); HBS (records per slice) must be a multiple of PF.
+// ---------------------------------------------------------------------------------------
+template <int R, int KP, int PF, int NSL>
+__device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP], const int HBS, const int lane,
+                                           float* __restrict__ part, const int slice0) {
+    constexpr int RECF = rec_floats(KP);
+    const int boff = 256 + 64 * KP + (lane >> 4) * 4;
+    f32x4 ra2[PF], rbias[PF];
+    float ra1[PF][KP];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        gcf32p r = rec + (size_t)u * RECF;
+        ra2[u] = *reinterpret_cast<gcf32x4p>(r + lane * 4);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = r[256 + kp * 64 + lane];
+        rbias[u] = *reinterpret_cast<gcf32x4p>(r + boff);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        opaque(ra2[u]); opaque(rbias[u]);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) opaque(ra1[u][kp]);
+    }
+    // layer-1 pre-activations of record 0
+    f32x4 d[R];
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) {
+        d[rb] = rbias[0];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+            d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[0][kp], xB[rb][kp], d[rb], 0, 0, 0);
+    }
+    gcf32p rn = rec + (size_t)PF * RECF;   // next record to fetch
+#pragma unroll 1
+    for (int sl = 0; sl < NSL; ++sl) {
+        f32x4 acc[R][2];
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) { acc[rb][0] = f32x4{0, 0, 0, 0}; acc[rb][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 1
+        for (int i0 = 0; i0 < HBS; i0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int nu = (u + 1) % PF;
+                // relu of this record's hidden units: the B operands of layer 2
+                f32x4 h[R];
+#pragma unroll
+                for (int rb = 0; rb < R; ++rb) {
+                    h[rb][0] = relu1(d[rb][0]); h[rb][1] = relu1(d[rb][1]);
+                    h[rb][2] = relu1(d[rb][2]); h[rb][3] = relu1(d[rb][3]);
+                }
+                // layer 1 of the NEXT record (independent of the layer-2 chain below)
+#pragma unroll
+                for (int rb = 0; rb < R; ++rb) {
+                    d[rb] = rbias[nu];
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp)
+                        d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[nu][kp], xB[rb][kp], d[rb], 0, 0, 0);
+                }
+                const f32x4 a2 = ra2[u];
+                // refill slot u with the record PF ahead (NPAD_REC zero records pad every filter)
+                ra2[u] = *reinterpret_cast<gcf32x4p>(rn + lane * 4);
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = rn[256 + kp * 64 + lane];
+                rbias[u] = *reinterpret_cast<gcf32x4p>(rn + boff);
+                rn += RECF;
+                // layer 2: C^T[coef][sample] += W2^T[coef][4 hidden] * H^T[4 hidden][sample]
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int rb = 0; rb < R; ++rb)
+                        acc[rb][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[r], h[rb][r], acc[rb][r & 1], 0, 0, 0);
+                // keep every refill load inside its own step: without this fence the machine
+                // scheduler sinks all PF refills to the end of the unrolled body and the next
+                // iteration opens with s_waitcnt vmcnt(0) (whole L2 latency exposed per PF records)
+                // order inside the step: relu (VALU) | layer-1 MFMAs | refill loads | layer-2 MFMAs, so the
+                // VALU->MFMA wait states are covered by the layer-1 MFMAs instead of s_nops
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * R, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, R * KP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * R, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // partial C^T of this hidden slice -> LDS
+        const int slice = slice0 + sl;
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) {
+            const f32x4 s = acc[rb][0] + acc[rb][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = s[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sum of a double over lane groups of G = 16, 32 or 64 lanes with DPP moves (VALU only).
+// The total lands in every lane of the group's LAST 16-lane row (lanes G-16 .. G-1).
+// Fixed addition order => deterministic.
+// ---------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double group_sum(double v, const int G) {
+    v += dpp_mov_f64<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141, 0xf>(v);    // row_half_mirror
+    v += dpp_mov_f64<0x140, 0xf>(v);    // row_mirror: every lane holds its row's sum
+    if (G >= 32) v += dpp_mov_f64<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    if (G >= 64) v += dpp_mov_f64<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// Per-sample scalars of em_parameter_setup (model.py:288-303) + conversions, for the
+// sample whose theta row is `row`; written to scal[8] / praw[8] of that sample.
+__device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row, double* praw, double* scal,
+                                               double& chk) {
+    for (int p = 0; p < NMMA_MAX_PARAMS; ++p) praw[p] = (p < P.NP) ? apply_slot(P.model_param[p], row) : 0.0;
+    const double d_l = apply_slot(P.lumdist, row);
+    double z = 0.0;
+    if (P.redshift_mode == NMMA_Z_SLOT) {
+        z = apply_slot(P.redshift, row);
+    } else if (P.redshift_mode == NMMA_Z_GRID) {
+        z = interp_np(d_l, P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
+    }
+    scal[S_ZP1] = 1 + z;
+    scal[S_IZP1] = 1.0 / (1 + z);   // only seeds the bracket guess (exactly re-checked)
+    scal[S_TS] = apply_slot(P.timeshift, row);
+    scal[S_DMOD] = distance_modulus(d_l);
+    scal[S_RC] = redshift_correction(z);
+    scal[S_EBV] = P.has_ebv ? apply_slot(P.ebv, row) : 0.0;
+    chk = d_l + z + scal[S_TS] + scal[S_EBV];
+    for (int p = 0; p < P.NP; ++p) chk += praw[p];
+}
+
+// =======================================================================================
+// em_logl: the hot path
+// =======================================================================================
+// workgroup of em_logl: 4 MFMA-role waves + NVW VALU-role waves
+constexpr int NVW = 8;
+constexpr int LOGL_THREADS = 64 * (4 + NVW);
+
+struct LdsW {
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, total;
+    int32_t nf_max;
+};
+
+__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items) {
     const int TS = 16 * R;
-    LdsOff L{};
+    LdsW L{};
     int off = 0;
-    L.part = off; off = align16(off + NSLICE * TS * 16 * 4);
-    L.cd = off;   off = align16(off + TS * NC * 8);
-    L.xs = off;   off = align16(off + TS * 8 * 4);
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
-    L.sysv = off; off = align16(off + TS * (kmax > 0 ? kmax : 1) * 8);
-    L.stl = off;  off = align16(off + NS * 8);      // sample times
-    L.s1i = off;  off = align16(off + NS * 4);      // stage-1 tables of the current model filter
-    L.s1dx = off; off = align16(off + NS * 8);
-    L.s1of = off; off = align16(off + NS * 8);
-    L.SB = 0;
-    L.va = L.span = L.mins = L.mag = off;
-    if (mode == MODE_LOGL) {
-        L.va = off;   off = align16(off + NT * NC * 8);   // basis rows of the current model filter
-        L.span = off; off = align16(off + NT * 8);
-        L.mins = off; off = align16(off + NT * 8);
-    } else if (mode == MODE_LC) {
-        int SB = TS;   // dense buffer: as many samples as fit ~32 KiB
-        while (SB > 1 && SB * NT * 8 > 32 * 1024) SB >>= 1;
-        L.SB = SB;
-        L.mag = off;  off = align16(off + SB * NT * 8);
-    }
+    L.stl = off;  off = align16(off + NS * 8);
+    L.part = off; off = align16(off + 2 * NSLICE * TS * PSTR * 4);   // double-buffered
+    L.chi = off;  off = align16(off + TS * 8);
+    L.gp = off;   off = align16(off + TS * 8);
+    L.bad = off;  off = align16(off + TS * 4);
+    L.cdl = off;  off = align16(off + NVW * 4 * 16 * 8);           // per VALU wave: 4 slots x 16 coefficients
+    L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
+    off = (off + 1023) / 1024 * 1024;
+    L.tab = off;  off = align16(off + 2 * tab_bytes);               // double-buffered static tables
     L.total = off;
     return L;
 }
 
-enum ScalIdx { S_ZP1 = 0, S_TS = 1, S_DMOD = 2, S_RC = 3, S_EBV = 4, S_BAD = 5, S_IZP1 = 6 };
-
-template <int MODE, int R, int WPB, int KP>
-__global__ __launch_bounds__(64 * WPB, 3) void em_fused(
-    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
-    const LdsOff L, double* __restrict__ chi_out, double* __restrict__ gp_out,
-    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out) {
+template <int R, int KP>
+__global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
+    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
+    long long* __restrict__ dbg) {
     constexpr int TS = 16 * R;
-    constexpr int NTHR = 64 * WPB;
+    constexpr int PF = (R == 1) ? 8 : 4;
     constexpr int RECF = rec_floats(KP);
+    constexpr int NV = 64 * NVW;      // VALU-role threads
 
-    constexpr int mode = MODE;
     const EmDev& P = *Pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* part = reinterpret_cast<float*>(smem + L.part);
-    double* cd = reinterpret_cast<double*>(smem + L.cd);
-    float* xs = reinterpret_cast<float*>(smem + L.xs);
     double* praw = reinterpret_cast<double*>(smem + L.praw);
     double* scal = reinterpret_cast<double*>(smem + L.scal);
-    double* sysv = reinterpret_cast<double*>(smem + L.sysv);
     double* stl = reinterpret_cast<double*>(smem + L.stl);
-    int* s1i = reinterpret_cast<int*>(smem + L.s1i);
-    double* s1dx = reinterpret_cast<double*>(smem + L.s1dx);
-    double* s1of = reinterpret_cast<double*>(smem + L.s1of);
-    double* val = reinterpret_cast<double*>(smem + L.va);
-    double* spanl = reinterpret_cast<double*>(smem + L.span);
-    double* minsl = reinterpret_cast<double*>(smem + L.mins);
-    double* magb = reinterpret_cast<double*>(smem + L.mag);
+    float* part = reinterpret_cast<float*>(smem + L.part);
+    double* chi_tot = reinterpret_cast<double*>(smem + L.chi);
+    double* gp_tot = reinterpret_cast<double*>(smem + L.gp);
+    int* bad = reinterpret_cast<int*>(smem + L.bad);
     double* estb = reinterpret_cast<double*>(smem + L.est);
+    unsigned char* tabl = smem + L.tab;
+    double* cdl = reinterpret_cast<double*>(smem + L.cdl);
+    const ItemDesc* itab = reinterpret_cast<const ItemDesc*>(smem + L.itab);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long tile0 = (long)blockIdx.x * TS;
-    const int o = blockIdx.y;  // observed filter (MODE_LOGL) / model filter (other modes)
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
-    const int kmax = P.kmax > 0 ? P.kmax : 1;
+    const int W = P.n_items;
+    gci32p items = as_global(P.items);
 
-    // ------------------------------------------------------------------ prologue
-    // per-sample scalars: em_parameter_setup (model.py:288-303) + conversions
-    if (tid < TS) {
-        long b = tile0 + tid;
-        if (b >= B) b = B - 1;
-        const double* row = theta + b * ld;
-        for (int p = 0; p < NMMA_MAX_PARAMS; ++p)
-            praw[tid * 8 + p] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
-        const double d_l = apply_slot(P.lumdist, row);
-        double z = 0.0;
-        if (P.redshift_mode == NMMA_Z_SLOT) {
-            z = apply_slot(P.redshift, row);
-        } else if (P.redshift_mode == NMMA_Z_GRID) {
-            z = interp_np(d_l, P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
-        }
-        scal[tid * 8 + S_ZP1] = 1 + z;
-        scal[tid * 8 + S_IZP1] = 1.0 / (1 + z);   // only seeds the bracket guess (exactly re-checked)
-        scal[tid * 8 + S_TS] = apply_slot(P.timeshift, row);
-        scal[tid * 8 + S_DMOD] = distance_modulus(d_l);
-        scal[tid * 8 + S_RC] = redshift_correction(z);
-        scal[tid * 8 + S_EBV] = P.has_ebv ? apply_slot(P.ebv, row) : 0.0;
-        // a non-finite input makes the reference return the floor (NaN propagates through
-        // relu/np.dot to every magnitude); v_med3 would swallow the NaN, so flag it here.
-        double chk = d_l + z + scal[tid * 8 + S_TS] + scal[tid * 8 + S_EBV];
-        for (int p = 0; p < NP; ++p) chk += praw[tid * 8 + p];
-        if (mode == MODE_LOGL) {
-            const int nn = P.sys_nn[o];
-            const int so = P.sys_off[o];
-            for (int k = 0; k < nn; ++k) {
-                const double v = apply_slot(P.sys_slots[so + k], row);
-                sysv[tid * kmax + k] = v;
-                chk += v;
+    if (wave < 4) {
+        // ============================ MFMA role ============================
+        // layer-1 operands straight from theta (no dependency on the other role's prologue)
+        double xraw[R][KP];
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) {
+            long b = tile0 + rb * 16 + (lane & 15);
+            if (b >= B) b = B - 1;
+            const double* row = theta + b * ld;
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                const int p = 4 * kp + (lane >> 4);
+                xraw[rb][kp] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
             }
         }
-        scal[tid * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
-    }
-    for (int j = tid; j < NS; j += NTHR) stl[j] = P.st[j];
-
-    const int nsrc = (mode == MODE_LOGL) ? P.nsrc[o] : 1;
-
-    for (int ks = 0; ks < nsrc; ++ks) {
-        const int m = (mode == MODE_LOGL) ? P.src[o * NMMA_MAX_SOURCES + ks] : o;
-        __syncthreads();  // praw ready (ks = 0) / previous source fully consumed
-
-        // normalised surrogate inputs, cast to fp32 as Keras does
-        for (int idx = tid; idx < TS * 8; idx += NTHR) {
-            const int p = idx & 7;
-            float v = 0.f;
-            if (p < NP) v = (float)((praw[idx] - P.pmin[m * NP + p]) / P.pspan[m * NP + p]);
-            xs[idx] = v;
-        }
-        // static tables of this model filter -> LDS (consumed after later barriers)
-        const bool identity = P.s1_range[m * 4 + 2] != 0;
-        {
-            gci32p gi1 = as_global(P.s1_idx) + (size_t)m * NS;
-            for (int j = tid; j < NS; j += NTHR) s1i[j] = gi1[j];
-            if (!identity) {
-                gcf64p gdx = as_global(P.s1_dx) + (size_t)m * NS, gof = as_global(P.s1_off) + (size_t)m * NS;
-                for (int j = tid; j < NS; j += NTHR) { s1dx[j] = gdx[j]; s1of[j] = gof[j]; }
-            }
-            if (mode == MODE_LOGL) {
-                gcf64p gva = as_global(P.VA) + (size_t)m * NT * NC;
-                for (int j = tid; j < NT * NC; j += NTHR) val[j] = gva[j];
-                gcf64p gsp = as_global(P.span) + (size_t)m * NT, gmn = as_global(P.mins) + (size_t)m * NT;
-                for (int j = tid; j < NT; j += NTHR) { spanl[j] = gsp[j]; minsl[j] = gmn[j]; }
-            }
-        }
-        __syncthreads();
-
-        // -------------------------------------------------------------- phase A: MLP on MFMA
-        {
+        const int HBS = P.HB / NSLICE;
+        for (int k = 0; k < W; ++k) {
+            const int m = items[4 * k + 2];
             float xB[R][KP];
 #pragma unroll
             for (int rb = 0; rb < R; ++rb)
 #pragma unroll
-                for (int kp = 0; kp < KP; ++kp)
-                    xB[rb][kp] = xs[(rb * 16 + (lane & 15)) * 8 + 4 * kp + (lane >> 4)];
-
-            constexpr int SPW = NSLICE / WPB;          // slices handled by this wave
-            const int HBS = P.HB / NSLICE;             // hidden blocks (records) per slice
-            gcf32p rec = as_global(P.wrec) + ((size_t)m * (P.HB + 2) + (size_t)wave * SPW * HBS) * RECF;
-            const int boff = 256 + 64 * KP + (lane >> 4) * 4;
-
-            // record 0: layer-1 pre-activations; record 1 in flight
-            f32x4 a2_cur = *reinterpret_cast<gcf32x4p>(rec + lane * 4);
-            f32x4 d[R];
-            {
-                float a1[KP];
-#pragma unroll
-                for (int kp = 0; kp < KP; ++kp) a1[kp] = rec[256 + kp * 64 + lane];
-                const f32x4 bias = *reinterpret_cast<gcf32x4p>(rec + boff);
-#pragma unroll
-                for (int rb = 0; rb < R; ++rb) {
-                    d[rb] = bias;
-#pragma unroll
-                    for (int kp = 0; kp < KP; ++kp)
-                        d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kp], xB[rb][kp], d[rb], 0, 0, 0);
+                for (int kp = 0; kp < KP; ++kp) {
+                    const int p = 4 * kp + (lane >> 4);
+                    xB[rb][kp] = (p < NP) ? (float)((xraw[rb][kp] - P.pmin[m * NP + p]) / P.pspan[m * NP + p]) : 0.f;
                 }
-            }
-            f32x4 a2_nxt = *reinterpret_cast<gcf32x4p>(rec + RECF + lane * 4);
-            float a1_nxt[KP];
-#pragma unroll
-            for (int kp = 0; kp < KP; ++kp) a1_nxt[kp] = rec[RECF + 256 + kp * 64 + lane];
-            f32x4 b_nxt = *reinterpret_cast<gcf32x4p>(rec + RECF + boff);
-            opaque(a2_cur); opaque(a2_nxt); opaque(b_nxt);
-#pragma unroll
-            for (int kp = 0; kp < KP; ++kp) opaque(a1_nxt[kp]);
-
-            int g = 0;   // record index within this wave's contiguous run
-            for (int sl = 0; sl < SPW; ++sl) {
-                f32x4 acc[R][2];
-#pragma unroll
-                for (int rb = 0; rb < R; ++rb) { acc[rb][0] = f32x4{0, 0, 0, 0}; acc[rb][1] = f32x4{0, 0, 0, 0}; }
-                for (int i = 0; i < HBS; ++i, ++g) {
-                    // relu of this record's hidden units: the B operands of layer 2
-                    f32x4 h[R];
-#pragma unroll
-                    for (int rb = 0; rb < R; ++rb) {
-                        h[rb][0] = relu1(d[rb][0]); h[rb][1] = relu1(d[rb][1]);
-                        h[rb][2] = relu1(d[rb][2]); h[rb][3] = relu1(d[rb][3]);
-                    }
-                    // layer 1 of the NEXT record (independent of the layer-2 chain below)
-#pragma unroll
-                    for (int rb = 0; rb < R; ++rb) {
-                        d[rb] = b_nxt;
-#pragma unroll
-                        for (int kp = 0; kp < KP; ++kp)
-                            d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_nxt[kp], xB[rb][kp], d[rb], 0, 0, 0);
-                    }
-                    const f32x4 a2 = a2_cur;
-                    a2_cur = a2_nxt;
-                    // prefetch record g+2 (two zero records pad the end of every filter)
-                    gcf32p rn = rec + (size_t)(g + 2) * RECF;
-                    a2_nxt = *reinterpret_cast<gcf32x4p>(rn + lane * 4);
-#pragma unroll
-                    for (int kp = 0; kp < KP; ++kp) a1_nxt[kp] = rn[256 + kp * 64 + lane];
-                    b_nxt = *reinterpret_cast<gcf32x4p>(rn + boff);
-                    // layer 2: C^T[coef][sample] += W2^T[coef][4 hidden] * H^T[4 hidden][sample]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int rb = 0; rb < R; ++rb)
-                            acc[rb][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[r], h[rb][r], acc[rb][r & 1], 0, 0, 0);
-                }
-                // partial C^T of this hidden slice -> LDS
-                const int slice = wave * SPW + sl;
-#pragma unroll
-                for (int rb = 0; rb < R; ++rb) {
-                    const f32x4 s = acc[rb][0] + acc[rb][1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        part[((slice * R + rb) * 16 + (lane >> 4) * 4 + r) * 16 + (lane & 15)] = s[r];
-                }
-            }
+            gcf32p rec = as_global(P.wrec) + ((size_t)m * (P.HB + NPAD_REC) + (size_t)wave * 2 * HBS) * RECF;
+            if (dbg && blockIdx.x == 0 && tid == 0) dbg[2 * k] = clock64();
+            mlp_slices<R, KP, PF, 2>(rec, xB, HBS, lane, part + (k & 1) * (NSLICE * TS * PSTR), wave * 2);
+            if (dbg && blockIdx.x == 0 && tid == 0) dbg[2 * k + 1] = clock64();
+            __syncthreads();     // barrier k: coefficients of item k published, buffer of item k-1 free
         }
-        __syncthreads();
+        __syncthreads();         // barrier W (the other role finishes item W-1 before it)
+        return;
+    }
 
-        // slice reduction (fixed order) + bias of the second Dense -> fp64 coefficients
-        for (int idx = tid; idx < TS * 16; idx += NTHR) {
-            const int rb = idx >> 8, rem = idx & 255, coef = rem >> 4, sidx = rem & 15;
-            float c = 0.f;
-#pragma unroll
-            for (int w = 0; w < NSLICE; ++w) c += part[((w * R + rb) * 16 + coef) * 16 + sidx];
-            c += P.b2[m * 16 + coef];
-            if (coef < NC) {
-                const int s = rb * 16 + sidx;
-                cd[s * NC + coef] = (double)c;
-                if (mode == MODE_COEFF && tile0 + s < B)
-                    coeff_out[((tile0 + s) * P.M + m) * NC + coef] = c;
-            }
+    // ================================ VALU role ================================
+    // Few instructions, long dependency chains: give them the issue slot whenever they are
+    // ready; the MFMA waves (lower priority) soak up every other cycle of the SIMD.
+    __builtin_amdgcn_s_setprio(3);
+    const int vt = tid - 256;
+    const int vwave = wave - 4;
+    if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
+    // ---- prologue: per-sample scalars, accumulators, sample-time grid
+    if (vt < TS) {
+        long b = tile0 + vt;
+        if (b >= B) b = B - 1;
+        const double* row = theta + b * ld;
+        double chk;
+        sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
+        for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+        scal[vt * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+        chi_tot[vt] = 0.0; gp_tot[vt] = 0.0; bad[vt] = 0;
+    }
+    for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
+    {
+        gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
+        int* dst = reinterpret_cast<int*>(smem + L.itab);
+        for (int j = vt; j < W * ITEM_WORDS; j += NV) dst[j] = src[j];
+    }
+
+    // Static tables of a model filter (basis rows, span, mins, stage-1 lerp tables) are
+    // copied global -> LDS by LDS-DMA one item ahead, into the other half of a double buffer:
+    // no registers, and the L2 latency hides behind the phase of the previous item.
+    const int tab_bytes = P.tab_bytes;                 // multiple of 1 KiB (one wave-instruction)
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+    auto tab_dma = [&](int k) {
+        const int m = items[4 * k + 2];
+        gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)m * tab_bytes);
+        lds_p dst = (lds_p)(tabl + (k & 1) * tab_bytes);
+        for (int c = vwave; c * 1024 < tab_bytes; c += NVW)
+            __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, dst + c * 1024, 16, 0, 0);
+    };
+    tab_dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
+    __syncthreads();             // barrier 0
+
+    const bool uniform = P.st_uniform != 0;
+    const double st0 = P.st0, inv_dt = P.st_inv_dt;
+    gcf64p g_dt = as_global(P.dt), g_dm = as_global(P.dm), g_dsig = as_global(P.dsig);
+    gcf64p g_sigtot = as_global(P.dsigtot), g_logsig = as_global(P.dlogsig);
+
+    auto item_phase = [&](auto nct_tag, const int k) {
+        constexpr int NCT = decltype(nct_tag)::value;
+        const ItemDesc& it = itab[k];
+        const int o = it.o, ks = it.ks, nsrc = it.nsrc;
+        const float* pbuf = part + (k & 1) * (NSLICE * TS * PSTR);
+        const int jlo = it.jlo, jhi = it.jhi;
+        const bool identity = it.identity != 0, same_grid = it.same_grid != 0;
+        const double ebvc = it.ebvc;
+        const int G = it.G;                       // lanes per sample, power of two in [16, 64]
+        const int gpb = NV / G;
+        const int g = vt / G, gi = vt - g * G;
+        const int d0 = it.d0;
+        const int nf = it.nf;
+        const int kind = it.kind;
+        const double lim = it.lim;
+        const double e_const = it.e_const;
+        const int npass = (TS + gpb - 1) / gpb;
+        const unsigned char* tb = tabl + (k & 1) * tab_bytes;
+        const double* va_m = reinterpret_cast<const double*>(tb);
+        const double* span_m = reinterpret_cast<const double*>(tb + P.tab_off_span);
+        const double* mins_m = reinterpret_cast<const double*>(tb + P.tab_off_mins);
+        const double* s1dx = reinterpret_cast<const double*>(tb + P.tab_off_s1dx);
+        const double* s1of = reinterpret_cast<const double*>(tb + P.tab_off_s1of);
+        const int* s1i = reinterpret_cast<const int*>(tb + P.tab_off_s1i);
+        const float* b2l = reinterpret_cast<const float*>(tb + P.tab_off_b2);
+        const bool dbg_on = dbg && blockIdx.x == 0 && vt == 0 && k == W - 1;
+        if (dbg_on) dbg[96] = clock64();
+        // the lane's first datum is the same for every sample: keep it in registers
+        double c_t = 0, c_m = 0, c_sd = 0, c_sig = 0, c_lsig = 0;
+        if (gi < nf) {
+            const int di = d0 + gi;
+            c_t = g_dt[di]; c_m = g_dm[di]; c_sd = g_dsig[di];
+            if (kind == NMMA_SYS_CONST) { c_sig = g_sigtot[di]; c_lsig = g_logsig[di]; }
         }
-        if constexpr (MODE == MODE_COEFF) return;
-        __syncthreads();
+        // (ordinary loads retired before the DMA is issued: a later wait on them would
+        //  otherwise drain the DMA queue as well)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_t), "+v"(c_m), "+v"(c_sd), "+v"(c_sig), "+v"(c_lsig)::"memory");
+        if (k + 1 < W) tab_dma(k + 1);            // next item's tables: in flight during this phase
+        if (dbg_on) dbg[97] = clock64();
 
-        // -------------------------------------------------------------- phase B
-        const int jlo = P.s1_range[m * 4 + 0], jhi = P.s1_range[m * 4 + 1];
-        const double ebvc = P.has_ebv ? P.ebv_coeff[m] : 0.0;
-
-        if constexpr (MODE == MODE_LC) {
-            // dense reconstruction in sub-batches of SB samples (gen_detector_lc, model.py:352-404)
-            const int SB = L.SB;
-            gcf64p VAt = as_global(P.VAt) + (size_t)m * NC * NT;
-            for (int sb0 = 0; sb0 < TS; sb0 += SB) {
-                for (int t = tid; t < NT; t += NTHR) {
-                    const double sp = P.span[m * NT + t], mn = P.mins[m * NT + t];
-                    for (int s = 0; s < SB; ++s) {
-                        const double* c = cd + (sb0 + s) * NC;
-                        double a = VAt[t] * c[0];
-                        for (int j = 1; j < NC; ++j) a = fma(VAt[j * NT + t], c[j], a);
-                        magb[s * NT + t] = a * sp + mn;
-                    }
-                }
-                __syncthreads();
-                for (int idx = tid; idx < SB * NS; idx += NTHR) {
-                    const int sl = idx / NS, j = idx - sl * NS;
-                    const int s = sb0 + sl;
-                    const long b = tile0 + s;
-                    if (b >= B) continue;
-                    const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
-                    const double ebv = scal[s * 8 + S_EBV];
-                    const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
-                    double v = dinf();
-                    if (j >= jlo && j <= jhi && jhi > jlo) {
-                        const double* magrow = magb + sl * NT;
-                        const int i1 = s1i[j];
-                        if (identity) {
-                            v = magrow[i1];
-                        } else {
-                            const double y0 = magrow[i1], y1 = magrow[i1 + 1 < NT ? i1 + 1 : NT - 1];
-                            const double slope = (y1 - y0) / s1dx[j];
-                            v = slope * s1of[j] + y0;
-                        }
-                        if (ext != 0.0) v = v + ext;
-                        v = (v + scal[s * 8 + S_DMOD]) + scal[s * 8 + S_RC];
-                    }
-                    mag_out[(b * P.M + m) * NS + j] = v;
-                    if (m == 0) tobs_out[b * NS + j] = stl[j] * zp1 + tsh;
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- MODE_LOGL: lane groups walk the ragged data of observed filter o
-        // (instantiated for <= 10 coefficients, the reference default, and for up to 16)
-        auto logl_phase = [&](auto nct_tag) {
-            constexpr int NCT = decltype(nct_tag)::value;
-            const int G = P.group[o];
-            const int gpb = NTHR / G;           // groups per block
-            const int g = tid / G, gi = tid - g * G;
-            const int d0 = P.doff[o], d1 = P.doff[o + 1];
-            const int nf = d1 - d0;
-            const int kind = P.sys_kind[o];
-            const double lim = P.lim[o];
-            const double e_const = P.sys_const[o];
-            const bool uniform = P.st_uniform != 0;
-            const double st0 = P.st0, inv_dt = P.st_inv_dt;
-            const int npass = (TS + gpb - 1) / gpb;
-            gcf64p g_dt = as_global(P.dt), g_dm = as_global(P.dm), g_dsig = as_global(P.dsig);
-            gcf64p g_sigtot = as_global(P.dsigtot), g_logsig = as_global(P.dlogsig);
-            // the lane's first datum is the same for every sample: keep it in registers
-            double c_t = 0, c_m = 0, c_sd = 0, c_sig = 0, c_lsig = 0;
-            if (gi < nf) {
-                const int di = d0 + gi;
-                c_t = g_dt[di]; c_m = g_dm[di]; c_sd = g_dsig[di];
-                if (kind == NMMA_SYS_CONST) { c_sig = g_sigtot[di]; c_lsig = g_logsig[di]; }
-            }
-            for (int pass = 0; pass < npass; ++pass) {
-                const int sl = pass * gpb + g;
-                const bool active = sl < TS;
-                const int s = active ? sl : 0;
-                const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
-                const double dmod = scal[s * 8 + S_DMOD], rc = scal[s * 8 + S_RC];
-                const double ebv = scal[s * 8 + S_EBV], izp1 = scal[s * 8 + S_IZP1];
-                const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
-                const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
-                // this sample's SVD coefficients (shared by the whole lane group)
-                // fast path (NC <= 10): coefficients in registers; generic path re-reads LDS
-                constexpr int NREG = (NCT <= 10) ? NCT : 1;
-                double cc[NREG];
-                const double* cl = cd + s * NC;
-                if constexpr (NCT <= 10) {
+        for (int pass = 0; pass < npass; ++pass) {
+            const int sl = pass * gpb + g;
+            const bool active = sl < TS;
+            const int s = active ? sl : 0;
+            // slice reduction (fixed order) + bias of the second Dense: lane gi < 16 owns
+            // coefficient gi and hands it to its group through LDS (same wave: LDS is in order)
+            if (gi < 16) {
+                const int rb = s >> 4, sidx = s & 15;
+                float cmine = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NCT; ++j) cc[j] = (j < NC) ? cl[j] : 0.0;
-                }
-
-                // absolute magnitude at SVD-grid node i: (VA[i,:] . c) * span[i] + mins[i]
-                auto mag_abs = [&](int i) -> double {
-                    const double* row = val + i * NC;
-                    double a;
-                    if constexpr (NCT <= 10) {
-                        a = row[0] * cc[0];
+                for (int w = 0; w < NSLICE; ++w) cmine += pbuf[((w * R + rb) * 16 + sidx) * PSTR + gi];
+                cmine += b2l[gi];
+                cdl[(vwave * (64 / 16) + (lane >> 4)) * 16 + gi] = (double)cmine;   // row: 16-lane slot of this wave
+            }
+            const double* crow = cdl + (vwave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;     // the group's first slot
+            // NCT > 0: exactly NCT coefficients, kept in registers; NCT == 0: any NC, re-read from LDS
+            constexpr int NREG = NCT > 0 ? NCT : 1;
+            double cc[NREG];
+            if constexpr (NCT > 0) {
 #pragma unroll
-                        for (int j = 1; j < NCT; ++j)
-                            if (j < NC) a = fma(row[j], cc[j], a);
+                for (int j = 0; j < NCT; ++j) cc[j] = crow[j];
+            }
+
+            if (dbg_on && pass == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[98] = clock64(); }
+            const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
+            const double dmod = scal[s * 8 + S_DMOD], rc = scal[s * 8 + S_RC];
+            const double ebv = scal[s * 8 + S_EBV], izp1 = scal[s * 8 + S_IZP1];
+            const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
+            const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
+            long brow = tile0 + s;
+            if (brow >= B) brow = B - 1;
+            const double* row = theta + brow * ld;
+
+            // absolute magnitude at SVD-grid node i: (VA[i,:] . c) * span[i] + mins[i]
+            auto mag_abs = [&](int i) -> double {
+                const double* vr = va_m + i * NC;
+                double a;
+                if constexpr (NCT > 0) {
+                    a = vr[0] * cc[0];
+#pragma unroll
+                    for (int j = 1; j < NCT; ++j) a = fma(vr[j], cc[j], a);
+                } else {
+                    a = vr[0] * crow[0];
+                    for (int j = 1; j < NC; ++j) a = fma(vr[j], crow[j], a);
+                }
+                return a * span_m[i] + mins_m[i];
+            };
+            // apparent magnitude at sample node j (stage-1 lerp + model.py:374-404)
+            auto app_mag = [&](int j) -> double {
+                const int i1 = s1i[j];
+                double v;
+                if (identity) {
+                    v = mag_abs(i1);
+                } else {
+                    const double y0 = mag_abs(i1);
+                    const double y1 = mag_abs(i1 + 1 < NT ? i1 + 1 : NT - 1);
+                    const double slope = (y1 - y0) / s1dx[j];
+                    v = slope * s1of[j] + y0;
+                }
+                if (ext != 0.0) v = v + ext;
+                return (v + dmod) + rc;
+            };
+
+            double chi = 0.0, gp = 0.0;
+            if (active) {
+                for (int dd = gi; dd < nf; dd += G) {
+                    const int di = d0 + dd;
+                    double t, mobs, sd, sig, lsig;
+                    if (dd == gi) { t = c_t; mobs = c_m; sd = c_sd; sig = c_sig; lsig = c_lsig; }
+                    else {
+                        t = g_dt[di]; mobs = g_dm[di]; sd = g_dsig[di]; sig = 0; lsig = 0;
+                        if (kind == NMMA_SYS_CONST) { sig = g_sigtot[di]; lsig = g_logsig[di]; }
+                    }
+                    // stage-2: np.interp(t, t_obs[jlo..jhi], app, left=right=+inf); straight-line:
+                    // bracket (clamped), both nodes reconstructed, result selected at the end
+                    const bool inside = (jhi > jlo) && t >= t_lo && t <= t_hi;
+                    int lo;   // t_obs[lo] <= t < t_obs[lo+1]  (lo = jhi-1 when t == t_obs[jhi])
+                    if (uniform) {
+                        lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                        lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
                     } else {
-                        a = row[0] * cl[0];
-                        for (int j = 1; j < NC; ++j) a = fma(row[j], cl[j], a);
-                    }
-                    return a * spanl[i] + minsl[i];
-                };
-                // apparent magnitude at sample node j (stage-1 lerp + model.py:374-404)
-                auto app_mag = [&](int j) -> double {
-                    const int i1 = s1i[j];
-                    double v;
-                    if (identity) {
-                        v = mag_abs(i1);
-                    } else {
-                        const double y0 = mag_abs(i1);
-                        const double y1 = mag_abs(i1 + 1 < NT ? i1 + 1 : NT - 1);
-                        const double slope = (y1 - y0) / s1dx[j];
-                        v = slope * s1of[j] + y0;
-                    }
-                    if (ext != 0.0) v = v + ext;
-                    return (v + dmod) + rc;
-                };
-
-                double chi = 0.0, gp = 0.0;
-                if (active) {
-                    for (int dd = gi; dd < nf; dd += G) {
-                        const int di = d0 + dd;
-                        double t, mobs, sd, sig, lsig;
-                        if (dd == gi) { t = c_t; mobs = c_m; sd = c_sd; sig = c_sig; lsig = c_lsig; }
-                        else {
-                            t = g_dt[di]; mobs = g_dm[di]; sd = g_dsig[di]; sig = 0; lsig = 0;
-                            if (kind == NMMA_SYS_CONST) { sig = g_sigtot[di]; lsig = g_logsig[di]; }
+                        lo = jlo;
+                        int hi = jhi;
+                        while (inside && hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
                         }
-                        // stage-2: np.interp(t, t_obs[jlo..jhi], app, left=right=+inf)
-                        double est;
-                        if (!(jhi > jlo) || t < t_lo || t > t_hi || t != t) {
-                            est = (t != t) ? t : dinf();
-                        } else if (t == t_hi) {
-                            est = app_mag(jhi);
+                    }
+                    if (lo > jhi - 1) lo = jhi - 1;
+                    if (lo < 0) lo = 0;
+                    int hi1 = lo + 1 < NS ? lo + 1 : lo;
+                    double x0 = stl[lo] * zp1 + tsh, x1 = stl[hi1] * zp1 + tsh;
+                    // exact re-check of the guessed bracket (normally no iteration)
+                    while (inside && ((x0 > t && lo > jlo) || (x1 <= t && lo < jhi - 1))) {
+                        lo += (x0 > t) ? -1 : 1;
+                        hi1 = lo + 1;
+                        x0 = stl[lo] * zp1 + tsh; x1 = stl[hi1] * zp1 + tsh;
+                    }
+                    const double y0 = app_mag(lo), y1 = app_mag(hi1);
+                    double est = lerp_np(t, x0, x1, y0, y1);
+                    if (x0 == t) est = y0;
+                    if (x1 == t) est = y1;          // also the exact right edge (np.interp: fp[-1])
+                    if (!inside) est = (t != t) ? t : dinf();
+                    if (dbg_on && pass == 0) { asm volatile("" : "+v"(est)); dbg[99] = clock64(); }
+                    if (nsrc > 1) {  // averaged band: (a + b [+ c]) / n  (utils.py:566-584)
+                        double acc_e = est;
+                        if (ks > 0) acc_e = estb[s * L.nf_max + dd] + est;
+                        if (ks < nsrc - 1) { estb[s * L.nf_max + dd] = acc_e; continue; }
+                        est = acc_e / (double)nsrc;
+                    }
+                    // systematics (systematics.py:279-296) and combined sigma (em_likelihood.py:341)
+                    double e = e_const;
+                    if (kind != NMMA_SYS_CONST) {
+                        const nmma_slot* sv = P.sys_slots + P.sys_off[o];
+                        if (kind == NMMA_SYS_PARAM) {
+                            e = apply_slot(sv[0], row);
                         } else {
-                            // bracket: t_obs[lo] <= t < t_obs[lo+1]
-                            int lo;
-                            if (uniform) {
-                                lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
-                                lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
-                                while (lo < jhi - 1 && stl[lo + 1] * zp1 + tsh <= t) ++lo;
-                                while (lo > jlo && stl[lo] * zp1 + tsh > t) --lo;
-                            } else {
-                                lo = jlo;
-                                int hi = jhi;
-                                while (hi - lo > 1) {
-                                    const int mid = (lo + hi) >> 1;
-                                    if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
-                                }
-                            }
-                            const double x0 = stl[lo] * zp1 + tsh;
-                            const double y0 = app_mag(lo);
-                            if (x0 == t) {
-                                est = y0;
-                            } else {
-                                const double x1 = stl[lo + 1] * zp1 + tsh;
-                                const double y1 = app_mag(lo + 1);
-                                est = lerp_np(t, x0, x1, y0, y1);
+                            const int K = P.sys_nn[o];
+                            const int ni = P.sys_nidx[di];
+                            if (ni < 0) e = apply_slot(sv[0], row);
+                            else if (ni >= K - 1) e = apply_slot(sv[K - 1], row);
+                            else {
+                                const double v0 = apply_slot(sv[ni], row), v1 = apply_slot(sv[ni + 1], row);
+                                const double sl2 = (v1 - v0) / P.sys_ndx[di];
+                                e = sl2 * P.sys_noff[di] + v0;
                             }
                         }
-                        if (nsrc > 1) {  // averaged band: (a + b [+ c]) / n  (utils.py:566-584)
-                            double acc_e = est;
-                            if (ks > 0) acc_e = estb[s * L.nf_max + dd] + est;
-                            if (ks < nsrc - 1) { estb[s * L.nf_max + dd] = acc_e; continue; }
-                            est = acc_e / (double)nsrc;
-                        }
-                        // systematics (systematics.py:279-296) and combined sigma (em_likelihood.py:341)
-                        double e = e_const;
-                        if (kind != NMMA_SYS_CONST) {
-                            const double* v = sysv + s * kmax;
-                            if (kind == NMMA_SYS_PARAM) {
-                                e = v[0];
-                            } else {
-                                const int K = P.sys_nn[o];
-                                const int ni = P.sys_nidx[di];
-                                if (ni < 0) e = v[0];
-                                else if (ni >= K - 1) e = v[K - 1];
-                                else { const double sl2 = (v[ni + 1] - v[ni]) / P.sys_ndx[di]; e = sl2 * P.sys_noff[di] + v[ni]; }
-                            }
-                            sig = sqrt(sd * sd + e * e);
-                            lsig = log(sig);
-                        }
-                        if (sig - sig == 0.0) {   // np.isfinite(data_sigma): detection
-                            chi += detection_term(mobs, est, sig, lsig, lim);
-                        } else {                  // infinite error: upper limit
-                            gp += upper_limit_term(mobs, est, e);
-                        }
+                        sig = sqrt(sd * sd + e * e);
+                        lsig = log(sig);
                     }
-                }
-                if (nsrc > 1 && ks < nsrc - 1) continue;  // uniform per block
-                // group reduction (G lanes, same wave); inactive groups carry zeros
-                for (int off = G >> 1; off > 0; off >>= 1) {
-                    chi += __shfl_xor(chi, off);
-                    gp += __shfl_xor(gp, off);
-                }
-                if (active && gi == 0 && tile0 + s < B) {
-                    if (scal[s * 8 + S_BAD] != 0.0) chi = dnan();
-                    chi_out[(long)o * B + tile0 + s] = chi;
-                    gp_out[(long)o * B + tile0 + s] = gp;
+                    if (sig - sig == 0.0) {   // np.isfinite(data_sigma): detection
+                        chi += detection_term(mobs, est, sig, lsig, lim);
+                    } else {                  // infinite error: upper limit
+                        gp += upper_limit_term(mobs, est, e);
+                    }
                 }
             }
-        };
-        if constexpr (MODE == MODE_LOGL) {
-            if (NC <= 10) logl_phase(std::integral_constant<int, 10>{});
-            else logl_phase(std::integral_constant<int, NMMA_MAX_COEFF>{});
+            if (dbg_on && pass == 0) { asm volatile("" : "+v"(chi), "+v"(gp)); dbg[100] = clock64(); }
+            if (ks < nsrc - 1) continue;      // uniform: more sources of this band to come
+            // group reduction by DPP (no LDS round trips); the sum lands in the group's LAST row
+            chi = group_sum(chi, G);
+            gp = group_sum(gp, G);
+            if (active && gi == G - 16) {
+                // running sums over observed filters, in filter order (em_likelihood.py:337-352)
+                chi_tot[s] += chi;
+                gp_tot[s] += gp;
+                if (chi != chi) bad[s] = 1;
+                if (chi_parts != nullptr && tile0 + s < B) {
+                    chi_parts[(long)o * B + tile0 + s] = (scal[s * 8 + S_BAD] != 0.0) ? dnan() : chi;
+                    gp_parts[(long)o * B + tile0 + s] = gp;
+                }
+            }
+            if (dbg_on && pass == 0) dbg[101] = clock64();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of the next item's tables has landed
+        if (dbg_on) dbg[102] = clock64();
+    };
+
+    for (int k = 1; k <= W; ++k) {
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[64 + 2 * k] = clock64();
+        if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k - 1);   // the reference default
+        else item_phase(std::integral_constant<int, 0>{}, k - 1);
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[64 + 2 * k + 1] = clock64();
+        __syncthreads();         // barrier k
+    }
+    // ---- sum over filters + floor (core/base.py:178-182)
+    if (vt < TS && tile0 + vt < B) {
+        double tot = chi_tot[vt] + gp_tot[vt];
+        const bool isbad = always_floor != 0 || bad[vt] != 0 || scal[vt * 8 + S_BAD] != 0.0;
+        if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+        out[tile0 + vt] = tot;
     }
 }
 
-// Sum over observed filters in the reference's order and floor non-finite results
-// (em_likelihood.py:337-352; core/base.py:178-182).
-__global__ void em_combine(const double* __restrict__ chi, const double* __restrict__ gp, long B, int O,
-                           int always_floor, double* __restrict__ out) {
-    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double c = 0.0, g = 0.0;
-    bool bad = always_floor != 0;
-    for (int o = 0; o < O; ++o) {
-        const double x = chi[(long)o * B + b];
-        if (x != x) bad = true;
-        c += x;
-        g += gp[(long)o * B + b];
+// =======================================================================================
+// em_fused: auxiliary outputs (MODE_COEFF: surrogate coefficients; MODE_LC: full
+// detector-frame light curves, gen_detector_lc model.py:352-404), one model filter per
+// blockIdx.y, all WPB waves on the MLP first.
+// =======================================================================================
+struct LdsOff {
+    int32_t part, cd, praw, scal, stl, mag, total;
+    int32_t SB;        // MODE_LC: samples per dense reconstruction sub-batch
+};
+
+__host__ inline LdsOff lds_layout(int mode, int R, int NC, int NT, int NS) {
+    const int TS = 16 * R;
+    LdsOff L{};
+    int off = 0;
+    L.part = off; off = align16(off + NSLICE * TS * PSTR * 4);
+    L.cd = off;   off = align16(off + TS * NC * 8);
+    L.praw = off; off = align16(off + TS * 8 * 8);
+    L.scal = off; off = align16(off + TS * 8 * 8);
+    L.stl = off;  off = align16(off + NS * 8);
+    L.SB = 0;
+    L.mag = off;
+    if (mode == MODE_LC) {
+        int SB = TS;   // dense buffer: as many samples as fit ~32 KiB
+        while (SB > 1 && SB * NT * 8 > 32 * 1024) SB >>= 1;
+        L.SB = SB;
+        off = align16(off + SB * NT * 8);
     }
-    double tot = c + g;
-    if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
-    out[b] = tot;
+    L.total = off;
+    return L;
+}
+
+template <int MODE, int R, int WPB, int KP>
+__global__ __launch_bounds__(64 * WPB, 2) void em_fused(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff L,
+    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out) {
+    constexpr int TS = 16 * R;
+    constexpr int NTHR = 64 * WPB;
+    constexpr int RECF = rec_floats(KP);
+    constexpr int SPW = NSLICE / WPB;
+
+    const EmDev& P = *Pp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* part = reinterpret_cast<float*>(smem + L.part);
+    double* cd = reinterpret_cast<double*>(smem + L.cd);
+    double* praw = reinterpret_cast<double*>(smem + L.praw);
+    double* scal = reinterpret_cast<double*>(smem + L.scal);
+    double* stl = reinterpret_cast<double*>(smem + L.stl);
+    double* magb = reinterpret_cast<double*>(smem + L.mag);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long tile0 = (long)blockIdx.x * TS;
+    const int m = blockIdx.y;  // model filter
+    const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
+
+    if (tid < TS) {
+        long b = tile0 + tid;
+        if (b >= B) b = B - 1;
+        double chk;
+        sample_scalars(P, theta + b * ld, praw + tid * 8, scal + tid * 8, chk);
+    }
+    for (int j = tid; j < NS; j += NTHR) stl[j] = P.st[j];
+    __syncthreads();
+
+    // ---- MLP
+    {
+        float xB[R][KP];
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                const int p = 4 * kp + (lane >> 4);
+                const int s = rb * 16 + (lane & 15);
+                xB[rb][kp] = (p < NP) ? (float)((praw[s * 8 + p] - P.pmin[m * NP + p]) / P.pspan[m * NP + p]) : 0.f;
+            }
+        const int HBS = P.HB / NSLICE;
+        gcf32p rec = as_global(P.wrec) + ((size_t)m * (P.HB + NPAD_REC) + (size_t)wave * SPW * HBS) * RECF;
+        mlp_slices<R, KP, 4, SPW>(rec, xB, HBS, lane, part, wave * SPW);
+    }
+    __syncthreads();
+
+    // slice reduction (fixed order) + bias of the second Dense -> fp64 coefficients
+    for (int idx = tid; idx < TS * 16; idx += NTHR) {
+        const int rb = idx >> 8, rem = idx & 255, coef = rem >> 4, sidx = rem & 15;
+        float c = 0.f;
+#pragma unroll
+        for (int w = 0; w < NSLICE; ++w) c += part[((w * R + rb) * 16 + sidx) * PSTR + coef];
+        c += P.b2[m * 16 + coef];
+        if (coef < NC) {
+            const int s = rb * 16 + sidx;
+            cd[s * NC + coef] = (double)c;
+            if (MODE == MODE_COEFF && tile0 + s < B) coeff_out[((tile0 + s) * P.M + m) * NC + coef] = c;
+        }
+    }
+    if constexpr (MODE == MODE_COEFF) return;
+    __syncthreads();
+
+    // ---- dense reconstruction in sub-batches of SB samples
+    const int jlo = P.s1_range[m * 4 + 0], jhi = P.s1_range[m * 4 + 1];
+    const bool identity = P.s1_range[m * 4 + 2] != 0;
+    const double ebvc = P.has_ebv ? P.ebv_coeff[m] : 0.0;
+    gci32p s1i = as_global(P.s1_idx) + (size_t)m * NS;
+    gcf64p s1dx = as_global(P.s1_dx) + (size_t)m * NS, s1of = as_global(P.s1_off) + (size_t)m * NS;
+    gcf64p VAt = as_global(P.VAt) + (size_t)m * NC * NT;
+    const int SB = L.SB;
+    for (int sb0 = 0; sb0 < TS; sb0 += SB) {
+        for (int t = tid; t < NT; t += NTHR) {
+            const double sp = P.span[m * NT + t], mn = P.mins[m * NT + t];
+            for (int s = 0; s < SB; ++s) {
+                const double* c = cd + (sb0 + s) * NC;
+                double a = VAt[t] * c[0];
+                for (int j = 1; j < NC; ++j) a = fma(VAt[j * NT + t], c[j], a);
+                magb[s * NT + t] = a * sp + mn;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < SB * NS; idx += NTHR) {
+            const int sl = idx / NS, j = idx - sl * NS;
+            const int s = sb0 + sl;
+            const long b = tile0 + s;
+            if (b >= B) continue;
+            const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
+            const double ebv = scal[s * 8 + S_EBV];
+            const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
+            double v = dinf();
+            if (j >= jlo && j <= jhi && jhi > jlo) {
+                const double* magrow = magb + sl * NT;
+                const int i1 = s1i[j];
+                if (identity) {
+                    v = magrow[i1];
+                } else {
+                    const double y0 = magrow[i1], y1 = magrow[i1 + 1 < NT ? i1 + 1 : NT - 1];
+                    const double slope = (y1 - y0) / s1dx[j];
+                    v = slope * s1of[j] + y0;
+                }
+                if (ext != 0.0) v = v + ext;
+                v = (v + scal[s * 8 + S_DMOD]) + scal[s * 8 + S_RC];
+            }
+            mag_out[(b * P.M + m) * NS + j] = v;
+            if (m == 0) tobs_out[b * NS + j] = stl[j] * zp1 + tsh;
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace nmma

@@ -329,6 +329,17 @@ class EMEngine:
                                                C.c_void_p(c.data_ptr()), self._stream()), "nmma_em_coefficients")
         return c
 
+    def debug_timeline(self, theta):
+        """In-kernel shader-clock stamps of workgroup 0 (see nmma_em_debug_timeline)."""
+        import torch
+        t = self._dev_theta(theta)
+        out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        torch.cuda.synchronize()
+        stamps = (C.c_int64 * 128)()
+        L.check(self._lib.nmma_em_debug_timeline(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                                 C.c_void_p(out.data_ptr()), stamps), "nmma_em_debug_timeline")
+        return np.array(stamps[:], dtype=np.int64)
+
     def last_launch_geometry(self):
         v = [C.c_int32() for _ in range(5)]
         L.check(self._lib.nmma_em_last_launch_geometry(self._handle, *[C.byref(x) for x in v]),

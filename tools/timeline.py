@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Print the in-kernel timeline of workgroup 0 (cycles relative to the first stamp)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmma_amd import synthetic as syn
+from tests import cases
+from tests.helpers import engine_from_case
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+NH = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+case = cases._base(n_hidden=NH)
+eng = engine_from_case(case)
+th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
+for _ in range(3):
+    eng.loglike(th)
+st = eng.debug_timeline(th)
+t0 = min(x for x in st if x > 0)
+W = 6
+print("MFMA role: item  start  end  dur")
+for k in range(W):
+    print(f"   A({k}) {st[2*k]-t0:8d} {st[2*k+1]-t0:8d}  {st[2*k+1]-st[2*k]:7d}")
+print("VALU role: prologue", st[64]-t0, st[65]-t0, st[65]-st[64])
+for k in range(1, W + 1):
+    print(f"   B({k-1}) {st[64+2*k]-t0:8d} {st[64+2*k+1]-t0:8d}  {st[64+2*k+1]-st[64+2*k]:7d}")
+eng.close()
+
+print("inside B(W-1): datum loads", st[97]-st[96], "| coef", st[98]-st[97], "| est", st[99]-st[98], "| terms", st[100]-st[99], "| reduce+write", st[101]-st[100], "| tail", st[102]-st[101], "| total", st[102]-st[96])
