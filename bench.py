@@ -34,6 +34,19 @@ BATCH_PER_GPU = 4096
 N_THETA_SETS = 8
 
 
+def _measured_traffic():
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["bytes_per_launch"]
+    except Exception:
+        return None
+
+
+TRAFFIC = _measured_traffic()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +97,7 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
+    os.environ["NMMA_PROFILE_STRIDE"] = "4"     # HIP events around every 4th launch of the timed region
     eng.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -107,7 +121,6 @@ def main():
         geom = eng.last_launch_geometry()
         evals = world * B * args.steps
         fused_ms = prof["fused_ms_total"] / max(1, prof["n_launches"])
-        comb_ms = prof["combine_ms_total"] / max(1, prof["n_launches"])
         achieved = eng.flops_per_eval * B / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None
         line = {
             "metric": "log-likelihood evals/sec (Bu2019lm, AT2017gfo filters)",
@@ -123,8 +136,10 @@ def main():
                        "launch": geom},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
-                         "traffic": None, "kernel": "em_fused", "kernel_ms": fused_ms,
-                         "combine_kernel_ms": comb_ms, "flops_per_eval": eng.flops_per_eval},
+                         "traffic": TRAFFIC, "kernel": "em_logl", "kernel_ms": fused_ms,
+                         "kernel_launches_timed": prof["n_launches"], "flops_per_eval": eng.flops_per_eval,
+                         "traffic_unit": "bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
+                                         "rocprofv3 --pmc, profiles/r01_*)"},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
@@ -154,14 +169,14 @@ def cpu_baseline(case, budget_s):
     for r in rows[:20]:
         lik.log_likelihood(r)
     n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < len(rows):
-        lik.log_likelihood(rows[n])
+    while time.perf_counter() - t0 < budget_s:
+        lik.log_likelihood(rows[n % len(rows)])
         n += 1
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits()
     return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the 4096 live points of the same workload, one parameter vector per call "
+            "sample": f"{n} evaluations cycling through the 4096 live points of the same workload, one parameter vector per call "
                       f"({dt:.1f} s, numpy fp32 MLP + scipy.stats as in the reference)"}
 
 

@@ -97,22 +97,28 @@ template <int R, int KP, int PF, int NSL>
 __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP], const int HBS, const int lane,
                                            float* __restrict__ part, const int slice0) {
     constexpr int RECF = rec_floats(KP);
-    const int boff = 256 + 64 * KP + (lane >> 4) * 4;
+    constexpr int RECB = RECF * 4;
+    // Buffer loads: the per-lane byte offsets are loop-invariant VGPRs and the record offset
+    // is ONE scalar, bumped by SALU -- no VALU address arithmetic competes with the MFMAs.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(uintptr_t)rec, 0, (NSL * HBS + NPAD_REC) * RECB, 0x00020000);
+    const int off_a2 = lane * 16;
+    const int off_a1 = (256 + lane) * 4;
+    const int off_b = (256 + 64 * KP + (lane >> 4) * 4) * 4;
+    auto ld4 = [&](int voff, int soff) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    };
+    auto ld1 = [&](int voff, int soff) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    };
     f32x4 ra2[PF], rbias[PF];
     float ra1[PF][KP];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        gcf32p r = rec + (size_t)u * RECF;
-        ra2[u] = *reinterpret_cast<gcf32x4p>(r + lane * 4);
+        ra2[u] = ld4(off_a2, u * RECB);
 #pragma unroll
-        for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = r[256 + kp * 64 + lane];
-        rbias[u] = *reinterpret_cast<gcf32x4p>(r + boff);
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        opaque(ra2[u]); opaque(rbias[u]);
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) opaque(ra1[u][kp]);
+        for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, u * RECB);
+        rbias[u] = ld4(off_b, u * RECB);
     }
     // layer-1 pre-activations of record 0
     f32x4 d[R];
@@ -123,7 +129,7 @@ __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP],
         for (int kp = 0; kp < KP; ++kp)
             d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[0][kp], xB[rb][kp], d[rb], 0, 0, 0);
     }
-    gcf32p rn = rec + (size_t)PF * RECF;   // next record to fetch
+    int soff = PF * RECB;   // byte offset of the next record to fetch (scalar)
 #pragma unroll 1
     for (int sl = 0; sl < NSL; ++sl) {
         f32x4 acc[R][2];
@@ -151,22 +157,21 @@ __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP],
                 }
                 const f32x4 a2 = ra2[u];
                 // refill slot u with the record PF ahead (NPAD_REC zero records pad every filter)
-                ra2[u] = *reinterpret_cast<gcf32x4p>(rn + lane * 4);
+                ra2[u] = ld4(off_a2, soff);
 #pragma unroll
-                for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = rn[256 + kp * 64 + lane];
-                rbias[u] = *reinterpret_cast<gcf32x4p>(rn + boff);
-                rn += RECF;
+                for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, soff);
+                rbias[u] = ld4(off_b, soff);
+                soff += RECB;
                 // layer 2: C^T[coef][sample] += W2^T[coef][4 hidden] * H^T[4 hidden][sample]
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int rb = 0; rb < R; ++rb)
                         acc[rb][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[r], h[rb][r], acc[rb][r & 1], 0, 0, 0);
-                // keep every refill load inside its own step: without this fence the machine
-                // scheduler sinks all PF refills to the end of the unrolled body and the next
-                // iteration opens with s_waitcnt vmcnt(0) (whole L2 latency exposed per PF records)
                 // order inside the step: relu (VALU) | layer-1 MFMAs | refill loads | layer-2 MFMAs, so the
-                // VALU->MFMA wait states are covered by the layer-1 MFMAs instead of s_nops
+                // VALU->MFMA wait states are covered by the layer-1 MFMAs instead of s_nops; the fence
+                // keeps every refill inside its own step (otherwise the scheduler sinks all PF refills to
+                // the end of the unrolled body and the next iteration opens with s_waitcnt vmcnt(0))
                 __builtin_amdgcn_sched_group_barrier(0x002, 4 * R, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, R * KP, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
@@ -424,6 +429,8 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
             const int sl = pass * gpb + g;
             const bool active = sl < TS;
             const int s = active ? sl : 0;
+            // waves whose groups are all beyond the tile have nothing to do in this pass (uniform)
+            if (pass * gpb + (vwave * 64) / G >= TS) continue;
             // slice reduction (fixed order) + bias of the second Dense: lane gi < 16 owns
             // coefficient gi and hands it to its group through LDS (same wave: LDS is in order)
             if (gi < 16) {

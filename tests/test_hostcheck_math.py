@@ -1,0 +1,98 @@
+"""The scalar fp64 numerics the HIP kernels inline (nmma_amd/csrc/em_math.h), compiled for
+the host and checked against numpy / scipy -- the semantics the reference relies on."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import special, stats
+
+from tests.hostcheck import build as hc_build
+
+
+@pytest.fixture(scope="module")
+def hc():
+    lib = C.CDLL(hc_build.build())
+    d, i, pd = C.c_double, C.c_int, C.POINTER(C.c_double)
+    sig = {"hc_interp_np": [d, pd, pd, i, d, d], "hc_lerp_np": [d] * 5, "hc_ndtr": [d], "hc_log_ndtr": [d],
+           "hc_log_gauss_mass_neginf": [d], "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
+           "hc_apply_slot": [i, i, d, pd], "hc_distance_modulus": [d], "hc_redshift_correction": [d]}
+    for name, args in sig.items():
+        getattr(lib, name).restype = d
+        getattr(lib, name).argtypes = args
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_interp_matches_numpy(hc):
+    rng = np.random.default_rng(0)
+    xp = np.sort(rng.uniform(0, 20, 37))
+    fp = rng.normal(size=37)
+    xs = np.concatenate([rng.uniform(-2, 22, 400), xp, [xp[0], xp[-1], np.nextafter(xp[-1], 30)]])
+    for left, right in ((np.inf, np.inf), (fp[0], fp[-1]), (-1.5, 2.5)):
+        want = np.interp(xs, xp, fp, left=left, right=right)
+        got = np.array([hc.hc_interp_np(x, _p(xp), _p(fp), len(xp), left, right) for x in xs])
+        assert np.array_equal(got, want)          # bit-exact, including the exact-node branches
+    assert np.isnan(hc.hc_interp_np(np.nan, _p(xp), _p(fp), len(xp), 0.0, 0.0))
+
+
+def test_lerp_nan_fallbacks_match_numpy(hc):
+    for (x0, x1, y0, y1, x) in ((0, 1, np.inf, 3.0, 0.25), (0, 1, 2.0, np.inf, 0.75), (0, 1, np.inf, np.inf, 0.5),
+                                (0, 1, 1.0, 2.0, 0.3)):
+        want = np.interp(x, [x0, x1], [y0, y1])
+        got = hc.hc_lerp_np(x, x0, x1, y0, y1)
+        assert (np.isnan(want) and np.isnan(got)) or got == want
+
+
+def test_log_ndtr_and_ndtr_match_scipy(hc):
+    xs = np.concatenate([np.linspace(-38, 8, 1201), [-1.0, -1.0000001, 0.0, 1e-300, 37.0]])
+    got = np.array([hc.hc_log_ndtr(x) for x in xs])
+    # host stand-in for erfcx (exp(t^2)*erfc(t)) limits this to ~1e-11; the device uses ocml erfcx
+    np.testing.assert_allclose(got, special.log_ndtr(xs), rtol=5e-11, atol=0)
+    got = np.array([hc.hc_ndtr(x) for x in xs])
+    np.testing.assert_allclose(got, special.ndtr(xs), rtol=2e-15, atol=1e-300)
+
+
+def test_detection_term_matches_truncnorm(hc):
+    rng = np.random.default_rng(1)
+    m, est = rng.normal(18, 1.5, 500), rng.normal(18, 1.5, 500)
+    sig = rng.uniform(0.05, 2.0, 500)
+    for lim in (np.inf, 30.0, 19.0, 17.0):
+        want = stats.truncnorm.logpdf(m, -np.inf, (lim - est) / sig, loc=est, scale=sig)
+        got = np.array([hc.hc_detection_term(a, b, c, np.log(c), lim) for a, b, c in zip(m, est, sig)])
+        assert np.array_equal(np.isneginf(got), np.isneginf(want))
+        fin = np.isfinite(want)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-11)
+    # infinite / NaN model magnitude -> NaN (the reference then returns the floor)
+    for lim in (np.inf, 20.0):
+        for est_bad in (np.inf, np.nan):
+            assert np.isnan(hc.hc_detection_term(18.0, est_bad, 0.3, np.log(0.3), lim))
+            with np.errstate(invalid="ignore"):
+                assert np.isnan(stats.truncnorm.logpdf(18.0, -np.inf, (lim - est_bad) / 0.3, loc=est_bad, scale=0.3))
+
+
+def test_upper_limit_term_matches_norm_logsf(hc):
+    rng = np.random.default_rng(2)
+    m, est = rng.normal(18, 2, 300), rng.normal(18, 2, 300)
+    sig = rng.uniform(0.1, 2.0, 300)
+    want = stats.norm.logsf(m, est, sig)
+    got = np.array([hc.hc_upper_limit_term(a, b, c) for a, b, c in zip(m, est, sig)])
+    np.testing.assert_allclose(got, want, rtol=1e-11)
+    assert hc.hc_upper_limit_term(18.0, np.inf, 1.0) == 0.0 == stats.norm.logsf(18.0, np.inf, 1.0)
+    assert np.isnan(hc.hc_upper_limit_term(18.0, np.nan, 1.0))
+
+
+def test_slots_and_distance(hc):
+    row = np.array([0.7, 40.0, -2.0, 0.3])
+    assert hc.hc_apply_slot(0, 1, 0.0, _p(row)) == 0.7 * 180.0 / np.pi
+    assert hc.hc_apply_slot(0, 2, 0.0, _p(row)) == 0.7 / 180.0 * np.pi
+    assert hc.hc_apply_slot(1, 3, 0.0, _p(row)) == pytest.approx(np.log10(40.0), rel=1e-15)
+    assert hc.hc_apply_slot(2, 4, 0.0, _p(row)) == pytest.approx(10 ** -2.0, rel=1e-15)
+    assert hc.hc_apply_slot(-1, 0, 3.5, _p(row)) == 3.5
+    tj = 2.8
+    assert hc.hc_apply_slot(0, 5, 0.0, _p(np.array([tj]))) == min(tj, np.pi - tj) * 180.0 / np.pi
+    assert hc.hc_apply_slot(3, 6, 0.0, _p(row)) == pytest.approx(np.arccos(0.3) * 180 / np.pi, rel=1e-15)
+    assert hc.hc_distance_modulus(40.0) == pytest.approx(5.0 * (5 + np.log10(40.0)), rel=1e-15)
+    assert hc.hc_redshift_correction(0.01) == pytest.approx(-2.5 * np.log10(1.01), rel=1e-14)
