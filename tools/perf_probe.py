@@ -42,8 +42,16 @@ for rnd in range(2):
         g = eng.last_launch_geometry()
         t_c = timeit(lambda: eng.coefficients(th))
         t_lc = timeit(lambda: eng.lightcurves(th))
+        th_host = np.ascontiguousarray(theta)
+        import time as _t
+        eng.loglike(th_host)
+        t0 = _t.perf_counter()
+        for _ in range(20):
+            eng.loglike(th_host)
+        t_h = (_t.perf_counter() - t0) / 20 * 1e6
         fl = eng.flops_per_eval * B
         print(f"round {rnd} tile {tile:4s} B={B}: loglike {t_l:7.1f} us  coeff(phaseA) {t_c:7.1f} us  lightcurves {t_lc:7.1f} us"
               f"  | grid {g['grid_x']}x{g['grid_y']}x{g['block']} lds {g['lds_bytes']}"
-              f"  | loglike {fl / t_l / 1e6:6.1f} TF/s  phaseA {fl / t_c / 1e6:6.1f} TF/s")
+              f"  | loglike {fl / t_l / 1e6:6.1f} TF/s  phaseA {fl / t_c / 1e6:6.1f} TF/s"
+              f"  | host-buffer call {t_h:7.1f} us = {B / t_h:6.2f} Mevals/s PCIe-inclusive")
         eng.close()
