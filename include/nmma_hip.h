@@ -57,6 +57,14 @@ enum nmma_redshift_mode {
     NMMA_Z_GRID = 2       /* z = interp(d_L; dist_grid, z_grid)  (model.py:262-265)           */
 };
 
+enum nmma_model_kind {
+    NMMA_MODEL_SVD = 0,       /* SVDLightCurveModel: surrogate tensors required (model.py:535-731)   */
+    NMMA_MODEL_ME2017 = 1,    /* SimpleKilonovaLightCurveModel("Me2017"): analytic, needs filter_nu0
+                                 (model.py:1280-1337, lightcurve_generation.py:566-652)              */
+    NMMA_MODEL_EXTERNAL = 2   /* light curves supplied per call (nmma_em_loglike_lc): GRB afterglow,
+                                 combined models (model.py:1342-1510)                               */
+};
+
 enum nmma_sys_kind {
     NMMA_SYS_CONST = 0,   /* FilterSystematicsHandler.from_budget (systematics.py:51,:203-210) */
     NMMA_SYS_PARAM = 1,   /* from_param / from_single_params      (systematics.py:279-286)     */
@@ -70,6 +78,11 @@ enum nmma_sys_kind {
 typedef struct nmma_em_config {
     int32_t abi_version;          /* NMMA_ABI_VERSION */
     int32_t device;               /* HIP device ordinal */
+
+    int32_t model_kind;           /* enum nmma_model_kind; the surrogate tensors below are used by
+                                     NMMA_MODEL_SVD only (pass NULL / 0 otherwise, with n_tt = 0)    */
+    const double* filter_nu0;     /* [M] observer-frame filter frequencies in Hz (NMMA_MODEL_ME2017;
+                                     c / lambda, model.py:226) or NULL                              */
 
     /* ---- SVD surrogate: eval_svd_model, nmma/em/lightcurve_generation.py:180-217 ---- */
     int32_t n_model_filters;      /* M  */
@@ -161,6 +174,26 @@ int32_t nmma_em_loglike_parts(nmma_em_handle* h, const double* theta_dev, int64_
  * obs_times_dev[B][NS], mag_dev[B][M][NS] apparent magnitudes (+inf outside the SVD grid). */
 int32_t nmma_em_lightcurves(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                             double* obs_times_dev, double* mag_dev, void* stream);
+
+/* Source-frame absolute-magnitude light curves lc_dev[B][M][NS] of the handle's own model
+ * (generate_lightcurve: model.py:707-728 for SVD, :1321-1337 for Me2017). */
+int32_t nmma_em_model_lightcurves(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                                  double* lc_dev, void* stream);
+
+/* Likelihood from SUPPLIED source-frame light curves lc_dev[B][M][NS] on the handle's
+ * sample_times (+inf / NaN where a model has no value): the tail of the reference path from
+ * combine_detector_data on (model.py:381-404; em_likelihood.py:305-352).  Used for models whose
+ * curve comes from elsewhere (NMMA_MODEL_EXTERNAL) and for combined models after nmma_lc_stack. */
+int32_t nmma_em_loglike_lc(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
+                           const double* lc_dev, double* out_dev, void* stream);
+
+/* Flux addition of n_models light-curve sets lc_k[B][M][NS] given on the handle's sample_times
+ * (CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes, model.py:1440-1448,
+ * :1486-1510): interior non-finite nodes of every model are interpolated between its finite
+ * neighbours first (autocomplete_data with its finite mask), then
+ * out = -2.5 * logsumexp_k(-0.4 ln10 * lc_k) / ln10.  lc_dev_sets is a HOST array of device pointers. */
+int32_t nmma_lc_stack(nmma_em_handle* h, const double* const* lc_dev_sets, int32_t n_models, int64_t B,
+                      double* out_dev, void* stream);
 
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,

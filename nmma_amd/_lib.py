@@ -23,6 +23,7 @@ LOGL_FLOOR = -1.7976931348623157e308
 OP_IDENT, OP_RAD2DEG, OP_DEG2RAD, OP_LOG10, OP_POW10, OP_THETAJN2DEG, OP_COSTHETAJN2DEG = range(7)
 Z_ZERO, Z_SLOT, Z_GRID = range(3)
 SYS_CONST, SYS_PARAM, SYS_NODES = range(3)
+MODEL_SVD, MODEL_ME2017, MODEL_EXTERNAL = range(3)
 
 
 class NMMAHipError(RuntimeError):
@@ -50,6 +51,7 @@ class EmConfig(C.Structure):
     """Mirror of ``struct nmma_em_config`` (field order must match the header)."""
     _fields_ = [
         ("abi_version", C.c_int32), ("device", C.c_int32),
+        ("model_kind", C.c_int32), ("filter_nu0", _pd),
         ("n_model_filters", C.c_int32), ("n_params", C.c_int32), ("n_hidden", C.c_int32),
         ("n_coeff", C.c_int32), ("n_tt", C.c_int32),
         ("W1", _pf), ("b1", _pf), ("W2", _pf), ("b2", _pf),
@@ -82,6 +84,10 @@ PROTOTYPES = {
                                           C.c_void_p, C.c_void_p]),
     "nmma_em_lightcurves": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "nmma_em_model_lightcurves": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_em_loglike_lc": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_em_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "nmma_em_debug_timeline": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,

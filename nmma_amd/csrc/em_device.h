@@ -15,7 +15,7 @@ namespace nmma {
 // records linearly with 16-byte loads (no LDS staging: every wave owns its hidden slice).
 __host__ __device__ constexpr int rec_floats(int kp) { return 256 + 64 * kp + 16; }
 
-enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2 };
+enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2, MODE_LC_ABS = 3 };
 
 // One work item of em_logl: (observed filter o, its ks-th source model filter m), with
 // everything the downstream phase needs about it (copied to LDS once per workgroup).
@@ -72,6 +72,8 @@ struct EmDev {
     const unsigned char* tab;
     int32_t tab_bytes, tab_off_span, tab_off_mins, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
     const ItemDesc* item_desc;   // [n_items]
+    int32_t lc_nf_max, model_kind;   // widest observed filter; enum nmma_model_kind
+    const double* nu0;           // [M] filter frequencies (Hz) for analytic blackbody models
     // work items of em_logl: (observed filter, source index, model filter, n sources) x n_items
     const int32_t* items;
     int32_t n_items, n_sys_slots;

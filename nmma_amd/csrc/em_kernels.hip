@@ -622,7 +622,7 @@ __host__ inline LdsOff lds_layout(int mode, int R, int NC, int NT, int NS) {
     L.stl = off;  off = align16(off + NS * 8);
     L.SB = 0;
     L.mag = off;
-    if (mode == MODE_LC) {
+    if (mode == MODE_LC || mode == MODE_LC_ABS) {
         int SB = TS;   // dense buffer: as many samples as fit ~32 KiB
         while (SB > 1 && SB * NT * 8 > 32 * 1024) SB >>= 1;
         L.SB = SB;
@@ -737,11 +737,367 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
                     const double slope = (y1 - y0) / s1dx[j];
                     v = slope * s1of[j] + y0;
                 }
-                if (ext != 0.0) v = v + ext;
-                v = (v + scal[s * 8 + S_DMOD]) + scal[s * 8 + S_RC];
+                if constexpr (MODE == MODE_LC) {
+                    if (ext != 0.0) v = v + ext;
+                    v = (v + scal[s * 8 + S_DMOD]) + scal[s * 8 + S_RC];
+                }
             }
             mag_out[(b * P.M + m) * NS + j] = v;
-            if (m == 0) tobs_out[b * NS + j] = stl[j] * zp1 + tsh;
+            if (MODE == MODE_LC && m == 0) tobs_out[b * NS + j] = stl[j] * zp1 + tsh;
+        }
+        __syncthreads();
+    }
+}
+
+// =======================================================================================
+// em_lc_loglike: likelihood from SUPPLIED source-frame light curves lc[B][M][NS] (absolute
+// magnitudes on the handle's sample_times, +inf / NaN where the model has no value) --
+// the generic tail of the reference path for models whose light curve is produced by
+// another kernel (Me2017) or by the caller (GRB afterglow, combined models):
+//   combine_detector_data (model.py:381-404), sanity_check (em_likelihood.py:305-311),
+//   autocomplete_data with its finite mask (utils.py:626-645), band_log_likelihood (:337-352).
+// One wave per parameter vector; lanes stride over the data of each observed filter.
+// =======================================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+    v = group_sum(v, 64);
+    // total sits in the last row; broadcast lane 63
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void em_lc_loglike(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
+    const double* __restrict__ lc, const int lds_per_wave, const int always_floor, double* __restrict__ out,
+    double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
+    const EmDev& P = *Pp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long b = (long)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int NS = P.NS, M = P.M;
+    // per-wave LDS: app[NS] | estacc[nf_max] | praw[8] | scal[8]
+    double* app = reinterpret_cast<double*>(smem + (size_t)wave * lds_per_wave);
+    double* estacc = app + NS;
+    double* praw = estacc + P.lc_nf_max;
+    double* scal = praw + 8;
+    const double* row = theta + b * ld;
+    if (lane == 0) {
+        double chk;
+        sample_scalars(P, row, praw, scal, chk);
+        for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+        scal[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double zp1 = scal[S_ZP1], tsh = scal[S_TS], dmod = scal[S_DMOD], rc = scal[S_RC], ebv = scal[S_EBV];
+    bool bad = always_floor != 0 || scal[S_BAD] != 0.0;
+
+    // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
+    for (int m = 0; m < M; ++m) {
+        const double* cur = lc + ((size_t)b * M + m) * NS;
+        int nfin = 0;
+        for (int j = lane; j < NS; j += 64) { const double v = cur[j]; nfin += (v - v == 0.0) ? 1 : 0; }
+        nfin = (int)wave_sum((double)nfin);
+        if (nfin < 2) bad = true;
+    }
+
+    double chi_tot = 0.0, gp_tot = 0.0;
+    for (int k = 0; k < P.n_items; ++k) {
+        const ItemDesc& it = P.item_desc[k];
+        const int o = it.o, ks = it.ks, m = it.m, nsrc = it.nsrc, d0 = it.d0, nf = it.nf, kind = it.kind;
+        const double lim = it.lim, e_const = it.e_const;
+        const double ext = (ebv != 0.0) ? it.ebvc * ebv : 0.0;
+        // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
+        const double* cur = lc + ((size_t)b * M + m) * NS;
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < NS; j += 64) {
+            double v = cur[j];
+            if (ext != 0.0) v = v + ext;
+            app[j] = (v + dmod) + rc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double chi = 0.0, gp = 0.0;
+        for (int dd = lane; dd < nf; dd += 64) {
+            const int di = d0 + dd;
+            const double t = P.dt[di];
+            // np.interp over the FINITE nodes only, left = right = +inf (utils.py:634-645)
+            double est = dinf();
+            if (t != t) {
+                est = t;
+            } else if (NS >= 1 && t >= P.st[0] * zp1 + tsh && t <= P.st[NS - 1] * zp1 + tsh) {
+                int lo = 0, hi = NS - 1;          // t_obs[lo] <= t <= t_obs[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (P.st[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+                }
+                if (P.st[hi] * zp1 + tsh <= t) lo = hi;      // t on the last node
+                int jl = lo;                                  // nearest finite node at or left of t
+                while (jl >= 0 && !(app[jl] - app[jl] == 0.0)) --jl;
+                int jr = lo + 1;                              // nearest finite node right of t
+                while (jr < NS && !(app[jr] - app[jr] == 0.0)) ++jr;
+                if (jl >= 0) {
+                    const double x0 = P.st[jl] * zp1 + tsh;
+                    if (x0 == t) est = app[jl];
+                    else if (jr < NS) est = lerp_np(t, x0, P.st[jr] * zp1 + tsh, app[jl], app[jr]);
+                }
+            }
+            if (nsrc > 1) {
+                double acc_e = est;
+                if (ks > 0) acc_e = estacc[dd] + est;
+                if (ks < nsrc - 1) { estacc[dd] = acc_e; continue; }
+                est = acc_e / (double)nsrc;
+            }
+            const double sd = P.dsig[di];
+            double e = e_const, sig, lsig;
+            if (kind == NMMA_SYS_CONST) {
+                sig = P.dsigtot[di]; lsig = P.dlogsig[di];
+            } else {
+                const nmma_slot* sv = P.sys_slots + P.sys_off[o];
+                if (kind == NMMA_SYS_PARAM) {
+                    e = apply_slot(sv[0], row);
+                } else {
+                    const int K = P.sys_nn[o];
+                    const int ni = P.sys_nidx[di];
+                    if (ni < 0) e = apply_slot(sv[0], row);
+                    else if (ni >= K - 1) e = apply_slot(sv[K - 1], row);
+                    else {
+                        const double v0 = apply_slot(sv[ni], row), v1 = apply_slot(sv[ni + 1], row);
+                        e = ((v1 - v0) / P.sys_ndx[di]) * P.sys_noff[di] + v0;
+                    }
+                }
+                sig = sqrt(sd * sd + e * e);
+                lsig = log(sig);
+            }
+            const double mobs = P.dm[di];
+            if (sig - sig == 0.0) chi += detection_term(mobs, est, sig, lsig, lim);
+            else gp += upper_limit_term(mobs, est, e);
+        }
+        if (ks < nsrc - 1) continue;
+        chi = wave_sum(chi);
+        gp = wave_sum(gp);
+        chi_tot += chi;
+        gp_tot += gp;
+        if (chi != chi) bad = true;
+        if (chi_parts != nullptr && lane == 0) {
+            chi_parts[(long)o * B + b] = chi;
+            gp_parts[(long)o * B + b] = gp;
+        }
+    }
+    if (lane == 0) {
+        double tot = chi_tot + gp_tot;
+        if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+        out[b] = tot;
+    }
+}
+
+// =======================================================================================
+// me2017_lc: the Me2017 analytic kilonova (eff_metzger_lc, lightcurve_generation.py:566-652;
+// blackbody magnitudes :43-58; flux_to_ABmag utils.py:793-811) -- BASELINE config 1.
+// One wave per parameter vector: the 299 mass layers are spread over the lanes, the
+// explicit-Euler time loop is sequential, the per-step layer sum and the photosphere
+// argmin are wave reductions.  Output: source-frame absolute magnitudes lc[B][M][NS].
+// =======================================================================================
+namespace me17 {
+constexpr double msun = 1.988409870698051e33, c_cgs = 2.99792458e10, h_cgs = 6.62607015e-27, kb = 1.380649e-16;
+constexpr double sigSB = 5.6703744191844314e-05, D10pc = 10 * 3.085677581491367e18, day = 86400.0;
+constexpr int MPREC = 300, NL = MPREC - 1, LPL = 5;   // layers per lane (5 * 64 >= 299)
+}  // namespace me17
+
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, const double* __restrict__ theta,
+                                                 const long B, const long ld, const int lds_per_wave,
+                                                 double* __restrict__ lc) {
+    using namespace me17;
+    const EmDev& P = *Pp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long b = (long)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int NS = P.NS, M = P.M;
+    double* eth = reinterpret_cast<double*>(smem + (size_t)wave * lds_per_wave);
+    double* tpw = eth + NS;      // (t/day)^-1.3
+    double* lsum = tpw + NS;     // sum over layers of lum[:, j]
+    double* rph = lsum + NS;     // photosphere radius
+    double* tobs = rph + NS;     // effective temperature
+    double* vml = tobs + NS;     // vm per layer [MPREC]
+    const double* row = theta + b * ld;
+
+    const double M0 = pow(10.0, apply_slot(P.model_param[0], row)) * msun;
+    const double v0 = pow(10.0, apply_slot(P.model_param[1], row)) * c_cgs;
+    const double beta = apply_slot(P.model_param[2], row);
+    const double kappa_r = pow(10.0, apply_slot(P.model_param[3], row));
+    double z = 0.0;
+    if (P.redshift_mode == NMMA_Z_SLOT) z = apply_slot(P.redshift, row);
+    else if (P.redshift_mode == NMMA_Z_GRID)
+        z = interp_np(apply_slot(P.lumdist, row), P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
+
+    // per-node time factors (thermalisation efficiency, Barnes+16 eq. 34)
+    for (int j = lane; j < NS; j += 64) {
+        const double td = P.st[j];
+        const double f = 2 * 0.17 * pow(td, 0.74);
+        eth[j] = 0.36 * (exp(-0.56 * td) + log(1.0 + f) / f);
+        tpw[j] = pow((td * day) / day, -1.3);
+        lsum[j] = 0.0;
+        rph[j] = 0.0;
+    }
+    // mass layers: m = geomspace(1e-8, M0/msun, 300)
+    const double ls = log10(1e-8), le = log10(M0 / msun);
+    const double step = (le - ls) / (MPREC - 1);
+    auto mlayer = [&](int i) -> double {
+        if (i == 0) return 1e-8;
+        if (i == MPREC - 1) return M0 / msun;
+        return pow(10.0, i * step + ls);
+    };
+    double mms[LPL], vm[LPL], xn0[LPL], xr[LPL], dmm[LPL], ene[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; ++q) {
+        const int i = lane + 64 * q;
+        const double mi = mlayer(i < MPREC ? i : MPREC - 1);
+        const double mn = mlayer(i + 1 < MPREC ? i + 1 : MPREC - 1);
+        mms[q] = mi * msun;
+        double v = v0 * pow(mi * msun / M0, -1.0 / beta);
+        if (v > c_cgs) v = c_cgs;
+        vm[q] = v;
+        xn0[q] = (1 - 2 * 0.1) * 2 * atan(1e-8 / mi) / kPi;
+        xr[q] = 1.0 - xn0[q];
+        dmm[q] = (mn - mi) * msun;
+        ene[q] = 0.0;
+        if (i < MPREC) vml[i] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int j = 0; j < NS - 1; ++j) {
+        const double t = P.st[j] * day, dt = P.st[j + 1] * day - t;
+        const double edotr = 2.1e10 * eth[j] * tpw[j];
+        const double en = exp(-t / 900.0);
+        double part = 0.0, best = dinf();
+        int besti = NL;
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < NL) {
+                const double xn = xn0[q] * en;
+                const double edot = 3.2e14 * xn + edotr;
+                const double kappa = 0.4 * (1.0 - xn - xr[q]) + kappa_r * xr[q];
+                const double tdiff = 0.08 * kappa * mms[q] * 3 / (vm[q] * c_cgs * t * beta);
+                const double tv = t * vm[q];
+                const double tau = mms[q] * kappa / (4 * kPi * (tv * tv));
+                const double lum_j = ene[q] / (tdiff + t * (vm[q] / c_cgs));
+                part += lum_j * dmm[q];
+                ene[q] += dt * (edot - (ene[q] / t) - lum_j);
+                const double dtau = fabs(tau - 1);
+                if (dtau < best) { best = dtau; besti = i; }
+            }
+        }
+        part = wave_sum(part);
+        wave_argmin(best, besti);
+        if (lane == 0) { lsum[j] = part; rph[j] = vml[besti] * t; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // effective temperature; non-finite entries filled as autocomplete_data(..., "linear") does
+    for (int j = lane; j < NS; j += 64) {
+        const double ltot = fabs(lsum[j] / 1e20 / 1e20);
+        tobs[j] = 1e10 * pow(ltot / (4 * kPi * (rph[j] * rph[j]) * sigSB), 0.25);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int nfin = 0;
+    for (int j = lane; j < NS; j += 64) nfin += (tobs[j] - tobs[j] == 0.0) ? 1 : 0;
+    nfin = (int)wave_sum((double)nfin);
+    for (int j = lane; j < NS; j += 64) {
+        double tv = tobs[j];
+        if (nfin < 2) {
+            tv = dinf();
+        } else if (!(tv - tv == 0.0)) {
+            int jl = j - 1, jr = j + 1;
+            while (jl >= 0 && !(tobs[jl] - tobs[jl] == 0.0)) --jl;
+            while (jr < NS && !(tobs[jr] - tobs[jr] == 0.0)) ++jr;
+            const double x = P.st[j];
+            if (jl >= 0 && jr < NS) {
+                tv = lerp_np(x, P.st[jl], P.st[jr], tobs[jl], tobs[jr]);
+            } else if (jl < 0) {           // left of the first finite node: slope of the first two
+                int j1 = jr + 1;
+                while (j1 < NS && !(tobs[j1] - tobs[j1] == 0.0)) ++j1;
+                tv = tobs[jr] + (tobs[j1] - tobs[jr]) / (P.st[j1] - P.st[jr]) * (x - P.st[jr]);
+            } else {                       // right of the last finite node: slope of the last two
+                int j0 = jl - 1;
+                while (j0 >= 0 && !(tobs[j0] - tobs[j0] == 0.0)) --j0;
+                tv = tobs[jl] + (tobs[jl] - tobs[j0]) / (P.st[jl] - P.st[j0]) * (x - P.st[jl]);
+            }
+        }
+        if (tv <= 0.0) tv = dnan();
+        double inv = 1.0 / tv;
+        if (!(inv - inv == 0.0)) inv = dinf();
+        eth[j] = inv;                      // reuse: 1/T per node
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // blackbody AB magnitudes per filter (host-frame frequency nu_0 * (1 + z))
+    for (int f = 0; f < M; ++f) {
+        const double nu = P.nu0[f] * (1 + z);
+        int npos = 0;
+        for (int j = lane; j < NS; j += 64) {
+            double ex = h_cgs * nu * eth[j] / kb;
+            if (ex > 700) ex = 700;        // np.clip(., None, 700); NaN passes through
+            const double F = 2.0 * h_cgs / (c_cgs * c_cgs) * (nu * nu * nu) / expm1(ex) * rph[j] * rph[j] / (D10pc * D10pc);
+            tpw[j] = F;
+            npos += (F > 0) ? 1 : 0;
+        }
+        npos = (int)wave_sum((double)npos);
+        double* dst = lc + ((size_t)b * M + f) * NS;
+        for (int j = lane; j < NS; j += 64) {
+            const double F = tpw[j];
+            double mag = dinf();
+            if (npos < 2) mag = dnan();
+            else if (F > 0) mag = -2.5 * log10(F) + (-48.6);
+            dst[j] = mag;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Detector-frame transform of supplied source-frame curves (gen_detector_lc, model.py:352-404)
+__global__ void lc_to_detector(const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B,
+                               const long ld, const double* __restrict__ lc, double* __restrict__ tobs_out,
+                               double* __restrict__ mag_out) {
+    const EmDev& P = *Pp;
+    const long b = blockIdx.x;
+    if (b >= B) return;
+    __shared__ double praw[8], scal[8];
+    __shared__ int nfin_s;
+    const int NS = P.NS, M = P.M;
+    if (threadIdx.x == 0) { double chk; sample_scalars(P, theta + b * ld, praw, scal, chk); }
+    __syncthreads();
+    const double ebv = scal[S_EBV];
+    for (int m = 0; m < M; ++m) {
+        if (threadIdx.x == 0) nfin_s = 0;
+        __syncthreads();
+        const double* cur = lc + ((size_t)b * M + m) * NS;
+        int n = 0;
+        for (int j = threadIdx.x; j < NS; j += blockDim.x) { const double v = cur[j]; n += (v - v == 0.0) ? 1 : 0; }
+        atomicAdd(&nfin_s, n);
+        __syncthreads();
+        const double ext = (ebv != 0.0 && P.has_ebv) ? P.ebv_coeff[m] * ebv : 0.0;
+        for (int j = threadIdx.x; j < NS; j += blockDim.x) {
+            double v = cur[j];
+            if (ext != 0.0) v = v + ext;
+            v = (v + scal[S_DMOD]) + scal[S_RC];
+            mag_out[((size_t)b * M + m) * NS + j] = nfin_s >= 2 ? v : dinf();
+            if (m == 0) tobs_out[b * NS + j] = P.st[j] * scal[S_ZP1] + scal[S_TS];
         }
         __syncthreads();
     }

@@ -94,10 +94,20 @@ class MultiFilterTransient:
             print(parameters, val)
         return -np.inf if val == LOGL_FLOOR else val
 
-    def log_likelihood_batch(self, theta, names=None):
+    def log_likelihood_batch(self, theta, names=None, external_lc=None):
         """theta[B, D] (numpy or torch CUDA tensor; columns = ``names`` or the sampled prior
-        keys) -> logL[B] with the reference's floor already applied."""
-        return self.engine(names).loglike(theta)
+        keys) -> logL[B] with the reference's floor already applied.  For combined models
+        ``external_lc`` maps external sub-model names to their light-curve tensors."""
+        eng = self.engine(names)
+        model = self.light_curve_model
+        if hasattr(model, "stacked_lightcurves_abs"):       # CombinedLightCurveModelContainer
+            import torch
+            th = torch.as_tensor(np.asarray(theta)) if not isinstance(theta, torch.Tensor) else theta
+            th = th.to(f"cuda:{eng.device}", dtype=torch.float64)
+            lc = model.stacked_lightcurves_abs(th, eng.parameter_names, external_lc, stack_engine=eng)
+            out = eng.loglike_lc(th, lc)
+            return out if isinstance(theta, torch.Tensor) else out.cpu().numpy()
+        return eng.loglike(theta)
 
     def final_diagnostics(self, bestfit_params, args, result=None):
         return self.light_curve_model.gen_detector_lc(dict(bestfit_params))
@@ -128,14 +138,14 @@ class EMTransientLikelihood(NMMALikelihood):
             parameters = self.parameters
         return float(super().log_likelihood(dict(parameters)))
 
-    def log_likelihood_batch(self, theta, names=None):
+    def log_likelihood_batch(self, theta, names=None, external_lc=None):
         """Batched ``log_likelihood``: every row of ``theta`` is one parameter vector.
         Conversions (KNtheta <- inclination_EM, log10 aliases), z(d_L), distance modulus,
         systematics and the floor are all applied on the device."""
         if self.constraints:
             raise NotImplementedError("Constraint priors are evaluated per sample by the sampler; "
                                       "use log_likelihood() or filter theta beforehand")
-        return self.sub_model.log_likelihood_batch(theta, names)
+        return self.sub_model.log_likelihood_batch(theta, names, external_lc)
 
     def parameter_names(self):
         return self.sub_model.sampling_layout()[0]

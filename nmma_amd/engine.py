@@ -101,7 +101,8 @@ class EMEngine:
 
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
-                 detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None):
+                 detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
+                 model_kind="svd", filter_nu0=None):
         self._handle = None
         lib = L.load_library()
         fixed = dict(fixed or {})
@@ -112,38 +113,55 @@ class EMEngine:
         self.observed_filters = list(observed_filters)
         self.device = int(device)
 
-        first = svd_model[model_filters[0]]
-        n_p = int(np.asarray(first["W1"]).shape[0])
-        n_h = int(np.asarray(first["W1"]).shape[1])
-        nc_trained = int(first["n_coeff"])
-        # lightcurve_generation.py:182-185; with a Keras net the output width is fixed
-        n_c = min(int(n_coeff), nc_trained) if n_coeff else nc_trained
-        if n_c != int(np.asarray(first["W2"]).shape[1]):
-            raise L.NMMAHipError("svd_mag_ncoeff must equal the network's output width "
-                                 "(nmma/em/lightcurve_generation.py:182-198)")
-        n_t = len(first["tt"])
-        if len(model_parameters) != n_p:
-            raise L.NMMAHipError("model_parameters do not match the surrogate input width")
-        for f in model_filters:
-            t = svd_model[f]
-            if (np.asarray(t["W1"]).shape != (n_p, n_h) or np.asarray(t["W2"]).shape != (n_h, n_c)
-                    or len(t["tt"]) != n_t):
-                raise L.NMMAHipError(f"filter {f}: surrogate shapes differ between filters")
-        stack = lambda k, conv: conv(np.stack([np.asarray(svd_model[f][k]) for f in model_filters]))
-        W1, b1, W2, b2 = (stack(k, _f32) for k in ("W1", "b1", "W2", "b2"))
-        VA = _f64(np.stack([np.asarray(svd_model[f]["VA"])[:, :n_c] for f in model_filters]))
-        mins, maxs, tt = (stack(k, _f64) for k in ("mins", "maxs", "tt"))
-        pmin, pmax = stack("param_mins", _f64), stack("param_maxs", _f64)
-        self.n_params, self.n_hidden, self.n_coeff, self.n_tt = n_p, n_h, n_c, n_t
-
+        kinds = {"svd": L.MODEL_SVD, "me2017": L.MODEL_ME2017, "external": L.MODEL_EXTERNAL}
+        if model_kind not in kinds:
+            raise L.NMMAHipError(f"unknown model_kind {model_kind!r}")
+        self.model_kind = model_kind
         cfg = L.EmConfig()
-        keep = [W1, b1, W2, b2, VA, mins, maxs, tt, pmin, pmax]
+        keep = []
         cfg.abi_version, cfg.device = L.ABI_VERSION, self.device
-        cfg.n_model_filters, cfg.n_params, cfg.n_hidden = len(model_filters), n_p, n_h
-        cfg.n_coeff, cfg.n_tt = n_c, n_t
-        cfg.W1, cfg.b1, cfg.W2, cfg.b2 = (_ptr(a, C.c_float) for a in (W1, b1, W2, b2))
-        cfg.VA, cfg.mins, cfg.maxs, cfg.tt = (_ptr(a, C.c_double) for a in (VA, mins, maxs, tt))
-        cfg.param_mins, cfg.param_maxs = _ptr(pmin, C.c_double), _ptr(pmax, C.c_double)
+        cfg.model_kind = kinds[model_kind]
+        cfg.n_model_filters = len(model_filters)
+        if model_kind == "svd":
+            first = svd_model[model_filters[0]]
+            n_p = int(np.asarray(first["W1"]).shape[0])
+            n_h = int(np.asarray(first["W1"]).shape[1])
+            nc_trained = int(first["n_coeff"])
+            # lightcurve_generation.py:182-185; with a Keras net the output width is fixed
+            n_c = min(int(n_coeff), nc_trained) if n_coeff else nc_trained
+            if n_c != int(np.asarray(first["W2"]).shape[1]):
+                raise L.NMMAHipError("svd_mag_ncoeff must equal the network's output width "
+                                     "(nmma/em/lightcurve_generation.py:182-198)")
+            n_t = len(first["tt"])
+            if len(model_parameters) != n_p:
+                raise L.NMMAHipError("model_parameters do not match the surrogate input width")
+            for f in model_filters:
+                t = svd_model[f]
+                if (np.asarray(t["W1"]).shape != (n_p, n_h) or np.asarray(t["W2"]).shape != (n_h, n_c)
+                        or len(t["tt"]) != n_t):
+                    raise L.NMMAHipError(f"filter {f}: surrogate shapes differ between filters")
+            stack = lambda k, conv: conv(np.stack([np.asarray(svd_model[f][k]) for f in model_filters]))
+            W1, b1, W2, b2 = (stack(k, _f32) for k in ("W1", "b1", "W2", "b2"))
+            VA = _f64(np.stack([np.asarray(svd_model[f]["VA"])[:, :n_c] for f in model_filters]))
+            mins, maxs, tt = (stack(k, _f64) for k in ("mins", "maxs", "tt"))
+            pmin, pmax = stack("param_mins", _f64), stack("param_maxs", _f64)
+            keep += [W1, b1, W2, b2, VA, mins, maxs, tt, pmin, pmax]
+            cfg.n_params, cfg.n_hidden = n_p, n_h
+            cfg.n_coeff, cfg.n_tt = n_c, n_t
+            cfg.W1, cfg.b1, cfg.W2, cfg.b2 = (_ptr(a, C.c_float) for a in (W1, b1, W2, b2))
+            cfg.VA, cfg.mins, cfg.maxs, cfg.tt = (_ptr(a, C.c_double) for a in (VA, mins, maxs, tt))
+            cfg.param_mins, cfg.param_maxs = _ptr(pmin, C.c_double), _ptr(pmax, C.c_double)
+        else:
+            if sample_times is None:
+                raise L.NMMAHipError("sample_times are required for non-SVD models")
+            n_p, n_h, n_c, n_t = len(model_parameters), 0, 0, 0
+            tt = None
+            cfg.n_params = n_p
+            if filter_nu0 is not None:
+                nu0 = _f64([filter_nu0[f] for f in model_filters])
+                keep.append(nu0)
+                cfg.filter_nu0 = _ptr(nu0, C.c_double)
+        self.n_params, self.n_hidden, self.n_coeff, self.n_tt = n_p, n_h, n_c, n_t
 
         if sample_times is not None:
             st = _f64(sample_times)
@@ -319,6 +337,40 @@ class EMEngine:
                                               C.c_void_p(tobs.data_ptr()), C.c_void_p(mag.data_ptr()),
                                               self._stream()), "nmma_em_lightcurves")
         return tobs, mag
+
+    def model_lightcurves(self, theta):
+        """Source-frame absolute magnitudes lc[B, M, NS] of the handle's model (generate_lightcurve)."""
+        import torch
+        t = self._dev_theta(theta)
+        lc = torch.empty((t.shape[0], len(self.model_filters), self.n_sample_times), dtype=torch.float64,
+                         device=t.device)
+        L.check(self._lib.nmma_em_model_lightcurves(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                                    C.c_void_p(lc.data_ptr()), self._stream()),
+                "nmma_em_model_lightcurves")
+        return lc
+
+    def loglike_lc(self, theta, lc):
+        """logL from supplied source-frame light curves lc[B, M, NS] (torch CUDA tensor)."""
+        import torch
+        t = self._dev_theta(theta)
+        lc = lc.to(device=t.device, dtype=torch.float64).contiguous()
+        if tuple(lc.shape) != (t.shape[0], len(self.model_filters), self.n_sample_times):
+            raise L.NMMAHipError(f"lc must be [B, M, NS] = {(t.shape[0], len(self.model_filters), self.n_sample_times)}")
+        out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        L.check(self._lib.nmma_em_loglike_lc(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
+                                             C.c_void_p(lc.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()),
+                "nmma_em_loglike_lc")
+        return out
+
+    def stack(self, lcs):
+        """Flux-add light-curve sets [B, M, NS] (CombinedLightCurveModelContainer.stack_magnitudes)."""
+        import torch
+        lcs = [x.to(dtype=torch.float64).contiguous() for x in lcs]
+        out = torch.empty_like(lcs[0])
+        ptrs = (C.c_void_p * len(lcs))(*[C.c_void_p(x.data_ptr()) for x in lcs])
+        L.check(self._lib.nmma_lc_stack(self._handle, ptrs, len(lcs), lcs[0].shape[0], C.c_void_p(out.data_ptr()),
+                                        self._stream()), "nmma_lc_stack")
+        return out
 
     def coefficients(self, theta):
         """SVD coefficients c[B, M, NC] (fp32), the surrogate output (lightcurve_generation.py:198)."""

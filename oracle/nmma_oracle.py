@@ -453,3 +453,76 @@ def log_likelihood_batch(lik: OracleLikelihood, names, theta):
     for i, row in enumerate(theta):
         out[i] = lik.log_likelihood(dict(zip(names, (float(v) for v in row))))
     return out
+
+
+# ---------------------------------------------------------------------------
+# a12: combined models (flux addition)
+# ---------------------------------------------------------------------------
+class OracleCombinedModel:
+    """CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes
+    (nmma/em/model.py:1411-1459, :1486-1510) for sub-models that share filters."""
+
+    def __init__(self, models):
+        self.lc_models = list(models)
+        self.filters = list(self.lc_models[0].filters)
+        self.model_times = np.array(sorted(set().union(*[m.model_times for m in self.lc_models])))
+        self.good_parameters = True
+
+    def parameter_conversion(self, parameters):
+        for m in self.lc_models:
+            parameters = m.parameter_conversion(parameters)
+        return parameters
+
+    def gen_detector_lc(self, parameters, sample_times=None):
+        from scipy.special import logsumexp
+        per_model, times = [], []
+        for m in self.lc_models:
+            t, lc = m.gen_detector_lc(parameters, sample_times)
+            if not lc:
+                return t, lc
+            per_model.append(lc)
+            times.append(t)
+        connected = np.array(sorted(set().union(*times))) if sample_times is None else times[-1]
+        joint = [{f: autocomplete_data(connected, t, v, extrapolate=np.inf) for f, v in lc.items()}
+                 for t, lc in zip(times, per_model)]
+        ln10 = np.log(10)
+        out = {}
+        for f in self.filters:
+            terms = [-2.0 / 5.0 * ln10 * np.array(j[f]) for j in joint if f in j]
+            out[f] = (-5.0 / 2.0 * logsumexp(terms, axis=0) / ln10) if terms else np.full_like(connected, np.inf)
+        return connected, out
+
+
+class OraclePowerLawModel:
+    """Synthetic stand-in for a GRB afterglow (the real one is third-party afterglowpy):
+    abs mag = grb_mag0 + 2.5 * grb_slope * log10(t / 1 day), defined for t >= t_start."""
+
+    model_parameters = ["grb_mag0", "grb_slope"]
+
+    def __init__(self, filters, sample_times, cosmo_grid=None, t_start=0.3, colour=0.15):
+        self.filters, self.model_times = list(filters), np.asarray(sample_times, float)
+        self.cosmo_grid, self.t_start, self.colour = cosmo_grid, t_start, colour
+        self.good_parameters = True
+
+    def parameter_conversion(self, parameters):
+        return parameters
+
+    def abs_lightcurves(self, parameters, sample_times):
+        with np.errstate(divide="ignore"):
+            base = parameters["grb_mag0"] + 2.5 * parameters["grb_slope"] * np.log10(sample_times)
+        lc = {}
+        for k, f in enumerate(self.filters):
+            v = base + self.colour * k
+            lc[f] = np.where(sample_times >= self.t_start, v, np.inf)
+        return lc
+
+    def gen_detector_lc(self, parameters, sample_times=None):
+        st = self.model_times if sample_times is None else sample_times
+        lc = self.abs_lightcurves(parameters, st)
+        d_l = parameters.get("luminosity_distance", 1e-5)
+        z = redshift_from_parameters(parameters, self.cosmo_grid)
+        obs = st * (1 + z) + parameters.get("timeshift", 0.0)
+        rc = -2.5 * np.log10(1 + z)
+        out = {f: (v + distance_modulus_nmma(d_l) + rc) if np.isfinite(v).sum() >= 2 else np.full_like(obs, np.inf)
+               for f, v in lc.items()}
+        return obs, out

@@ -1,0 +1,29 @@
+"""CPU: the Me2017 (config 1) and combined-model (config 3 shape) oracles against the golden
+vectors produced by the reference's own source."""
+import numpy as np
+
+from oracle import nmma_oracle as orc
+from tests import cases, cases_combined, cases_me2017
+
+
+def test_me2017_oracle_matches_golden():
+    case = cases_me2017.case_me2017()
+    gold = cases.load_golden("me2017")
+    lik = cases_me2017.oracle_likelihood(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:32])
+    np.testing.assert_allclose(got, gold["logl"][:32], rtol=1e-12)
+    p = lik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in case["theta"][0]))))
+    tobs, lc = lik.model.gen_detector_lc(p)
+    np.testing.assert_allclose(tobs, gold["s0_obs_times"], rtol=1e-15)
+    for k, f in enumerate(case["filters"]):
+        want = gold[f"s0_app_{k}"]
+        assert np.array_equal(np.isfinite(lc[f]), np.isfinite(want))
+        np.testing.assert_allclose(lc[f][np.isfinite(want)], want[np.isfinite(want)], rtol=1e-13)
+
+
+def test_combined_oracle_matches_golden():
+    case = cases_combined.case_combined()
+    gold = cases.load_golden("combined")
+    lik, _ = cases_combined.oracle_likelihood(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
+    np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)

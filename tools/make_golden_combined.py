@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
+CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
+sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
+is third-party and absent).  Output: tests/golden/combined.npz."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import nmma_oracle as orc  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+from tests import cases_combined  # noqa: E402
+from tools.make_golden import _KerasStandIn  # noqa: E402
+
+
+def main():
+    case = cases_combined.case_combined()
+    ref = ref_harness.reference_modules()
+    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in case["filters"]]
+    ref.utils.M4OPT_INSTALLED = False
+    grid = case["cosmo_grid"]
+    zfun = lambda p: np.interp(p["luminosity_distance"], grid[0], grid[1])
+
+    kn = object.__new__(ref.model.SVDLightCurveModel)
+    svd_ref = {}
+    for f, t in case["svd"].items():
+        d = {k: t[k] for k in ("param_mins", "param_maxs", "mins", "maxs", "tt", "n_coeff", "VA")}
+        d["model"] = _KerasStandIn(t)
+        svd_ref[f] = d
+    kn.model, kn.model_parameters, kn.filters = case["model"], list(case["model_parameters"]), list(case["filters"])
+    kn.svd_mag_model, kn.mag_ncoeff, kn.lbol_ncoeff, kn.good_parameters = svd_ref, None, None, True
+    kn.default_filts, kn.lambdas, kn.nu_0s = list(case["filters"]), np.ones(9), np.ones(9)
+    kn.model_times, kn.redshift_func = case["sample_times"], zfun
+    kn.check_vs_priors = lambda priors: None
+
+    helper = orc.OraclePowerLawModel(case["filters"], case["sample_times"])
+
+    class PowerLawGRB(ref.model.LightCurveModelContainer):
+        def __init__(self):
+            self.model, self.model_parameters = "PLGRB", ["grb_mag0", "grb_slope"]
+            self.filters, self.default_filts = list(case["filters"]), list(case["filters"])
+            self.lambdas = self.nu_0s = np.ones(9)
+            self.good_parameters, self.model_times, self.redshift_func = True, case["sample_times"], zfun
+
+        def check_vs_priors(self, priors):
+            pass
+
+        def generate_lightcurve(self, sample_times, parameters):
+            self.em_parameter_setup(parameters)
+            return helper.abs_lightcurves(parameters, sample_times)
+
+    comb = ref.model.CombinedLightCurveModelContainer([kn, PowerLawGRB()])
+    times, mags, sigmas = case["data"]
+    priors = ref.base.PriorDict({n: object() for n in case["names"]})
+    handler = ref.systematics.FilterSystematicsHandler(list(case["filters"]), error_budget=1.0,
+                                                       light_curve_times=times)
+    lik = ref.em_likelihood.EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors,
+                                                  filters=list(case["filters"]), detection_limit=np.inf)
+    names, theta = case["names"], case["theta"]
+    logl = np.array([lik.log_likelihood(dict(zip(names, (float(v) for v in row)))) for row in theta])
+    olik, _ = cases_combined.oracle_likelihood(case)
+    ol = orc.log_likelihood_batch(olik, names, theta)
+    floor = logl == orc.LOGL_FLOOR
+    assert np.array_equal(ol == orc.LOGL_FLOOR, floor)
+    rel = np.max(np.abs(ol[~floor] - logl[~floor]) / np.maximum(1, np.abs(logl[~floor])))
+    print(f"combined: B={len(theta)} floor={floor.sum()} logL range ({logl[~floor].min():.2f}, {logl[~floor].max():.2f})"
+          f" oracle-vs-reference max rel diff {rel:.3e}")
+    out = {"logl": logl}
+    for i in range(3):
+        p = lik.parameter_conversion(dict(zip(names, (float(v) for v in theta[i]))))
+        tobs, lc = comb.gen_detector_lc(p)
+        out[f"s{i}_obs_times"] = np.asarray(tobs, float)
+        for k, f in enumerate(case["filters"]):
+            out[f"s{i}_app_{k}"] = np.asarray(lc[f], float)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "combined.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
