@@ -24,7 +24,7 @@ struct ItemDesc {
     int32_t G, d0, nf, kind;
     int32_t jlo, jhi, identity, same_grid;
     double lim, e_const, ebvc, pad;
-    int32_t pad2[4];
+    int32_t fast, has_ul, pad2[2];
 };
 static_assert(sizeof(ItemDesc) == 24 * 4, "ItemDesc must be ITEM_WORDS words");
 
@@ -68,9 +68,10 @@ struct EmDev {
     const int32_t* src;       // [O][3]
     const int32_t* group;     // [O]  lanes cooperating on one sample (power of two <= 64)
     // packed per-model-filter static tables staged in LDS by em_logl:
-    //   [VA NT*NC f64 | span NT f64 | mins NT f64 | s1_dx NS f64 | s1_off NS f64 | s1_idx NS i32 | b2 16 f32], 1-KiB padded
+    //   [rows NT x RS f64 (VA row | span | mins, RS = NC+2 rounded up to even) | s1_dx NS f64 | s1_off NS f64 |
+    //    s1_idx NS i32 | b2 16 f32], 1-KiB padded
     const unsigned char* tab;
-    int32_t tab_bytes, tab_off_span, tab_off_mins, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
+    int32_t tab_bytes, tab_row_stride, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
     const ItemDesc* item_desc;   // [n_items]
     int32_t lc_nf_max, model_kind;   // widest observed filter; enum nmma_model_kind
     const double* nu0;           // [M] filter frequencies (Hz) for analytic blackbody models
