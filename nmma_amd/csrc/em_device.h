@@ -36,6 +36,7 @@ struct EmDev {
     double st0, st_inv_dt;
     // surrogate
     const float* wrec;        // [M][HB + NPAD_REC][rec_floats(KP)]   (zero records: branch-free prefetch)
+    int32_t wrec_bytes;
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
     const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
@@ -43,6 +44,7 @@ struct EmDev {
     const double* span;       // [M][NT]   maxs - mins
     const double* pmin;       // [M][NP]
     const double* pspan;      // [M][NP]   param_maxs - param_mins
+    const double* pinv;       // [M][NP]   1 / pspan (em_logl normalises with one multiply)
     const double* ebv_coeff;  // [M]
     // stage-1 interpolation tables (sample_times <- tt), static per model filter
     const double* st;         // [NS] sample times

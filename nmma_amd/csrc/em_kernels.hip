@@ -72,6 +72,8 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 // Hidden units are always split into NSLICE partial sums added in slice order, so the
 // fp32 result does not depend on the launch geometry (R, WPB) chosen for a batch size.
 constexpr int NSLICE = 8;
+// likelihood-role waves of an em_logl workgroup (next to its NMW MFMA-role waves)
+constexpr int NVW = 8;
 // zero records appended to every model filter's weight stream (deepest prefetch ring + 1)
 constexpr int NPAD_REC = 9;
 // row stride (floats) of the LDS partial-sum tiles: 16 coefficients + 1 pad (bank spread)
@@ -192,6 +194,178 @@ __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP],
 }
 
 // ---------------------------------------------------------------------------------------
+// Role hand-off of em_logl through three LDS counters instead of workgroup barriers, so the
+// two roles never wait for each other unless the data dependency is real:
+//   sync[0] += 1 by every MFMA wave after its partial sums of an item are in LDS;
+//   sync[1] += 1 by every likelihood wave after each of its phases (prologue, item 0, ...).
+// LDS instructions of one wave execute in order, so "data writes, then counter add" by the
+// producer and "counter read, then data reads" by the consumer need no further fence.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) int* lds_ip;
+__device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((lds_ip)cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sync_wait(int* cnt, const int target) {
+    while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA role of em_logl: ONE continuous stream of weight records over all work items.
+// Wave `wave` of NMW owns NSL = NSLICE/NMW hidden slices of every item; its records of
+// consecutive items are chained into a single prefetch ring (the refills issued during the
+// last PF records of an item already fetch the first PF records of the next one), so the
+// L2 latency is paid once per launch instead of once per item.  Layer-1 pre-activations
+// run one record ahead and therefore switch to the next item's normalised inputs on the
+// last record of an item.  Partial sums of item k go to buffer k % NBUF of `part`; the role
+// only waits for the likelihood role when that buffer still holds item k - NBUF.
+// ---------------------------------------------------------------------------------------
+constexpr int NBUF = 3;
+
+template <int R, int KP, int PF, int NMW>
+__device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], const int wave, const int lane,
+                                          float* __restrict__ part, int* sync, long long* __restrict__ dbg) {
+    constexpr int RECF = rec_floats(KP);
+    constexpr int RECB = RECF * 4;
+    constexpr int NSL = NSLICE / NMW;
+    constexpr int TS = 16 * R;
+    const int W = P.n_items, NP = P.NP;
+    const int HBS = P.HB / NSLICE;
+    const int CPS = HBS / PF;                      // chunks per slice
+    const int CPI = NSL * CPS;                     // chunks per item (this wave)
+    gci32p items = as_global(P.items);
+    gcf64p pmin = as_global(P.pmin), pinv = as_global(P.pinv);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(uintptr_t)P.wrec, 0, P.wrec_bytes, 0x00020000);
+    const int off_a2 = lane * 16;
+    const int off_a1 = (256 + lane) * 4;
+    const int off_b = (256 + 64 * KP + (lane >> 4) * 4) * 4;
+    auto ld4 = [&](int voff, int soff) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    };
+    auto ld1 = [&](int voff, int soff) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    };
+    // byte offset (from wrec) of this wave's first record of item k
+    auto item_base = [&](int k) -> int {
+        const int m = items[4 * k + 2];
+        return __builtin_amdgcn_readfirstlane((m * (P.HB + NPAD_REC) + wave * NSL * HBS) * RECB);
+    };
+    // normalised layer-1 inputs of item k: lane l holds x[sample rb*16 + (l&15)][param 4*kp + (l>>4)]
+    auto load_x = [&](int k, float (&x)[R][KP]) {
+        const int m = items[4 * k + 2];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const int p = 4 * kp + (lane >> 4);
+            const double mn = (p < NP) ? pmin[m * NP + p] : 0.0, iv = (p < NP) ? pinv[m * NP + p] : 0.0;
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb) x[rb][kp] = (float)((xraw[rb][kp] - mn) * iv);
+        }
+    };
+
+    float xB[R][KP], xN[R][KP];
+    load_x(0, xB);
+    int base = item_base(0);
+    f32x4 ra2[PF], rbias[PF];
+    float ra1[PF][KP];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        ra2[u] = ld4(off_a2, base + u * RECB);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, base + u * RECB);
+        rbias[u] = ld4(off_b, base + u * RECB);
+    }
+    f32x4 d[R];
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) {
+        d[rb] = rbias[0];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+            d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[0][kp], xB[rb][kp], d[rb], 0, 0, 0);
+    }
+
+#pragma unroll 1
+    for (int k = 0; k < W; ++k) {
+        if (dbg && blockIdx.x == 0 && wave == 0 && lane == 0) dbg[2 * k] = clock64();
+        const int nbase = (k + 1 < W) ? item_base(k + 1) : base;     // last item: harmless re-read
+        if (k + 1 < W) load_x(k + 1, xN);
+        else {
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) xN[rb][kp] = xB[rb][kp];
+        }
+        float* pk = part + (k % NBUF) * (NSLICE * TS * PSTR);
+        int soff = base + PF * RECB;              // record fetched by the next refill
+#pragma unroll 1
+        for (int sl = 0; sl < NSL; ++sl) {
+            f32x4 acc[R][2];
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb) { acc[rb][0] = f32x4{0, 0, 0, 0}; acc[rb][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 1
+            for (int c = 0; c < CPS; ++c) {
+                const bool last_chunk = (sl == NSL - 1) && (c == CPS - 1);
+                if (last_chunk) soff = nbase;     // refills now fetch the first PF records of the next item
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int nu = (u + 1) % PF;
+                    f32x4 h[R];
+#pragma unroll
+                    for (int rb = 0; rb < R; ++rb) {
+                        h[rb][0] = relu1(d[rb][0]); h[rb][1] = relu1(d[rb][1]);
+                        h[rb][2] = relu1(d[rb][2]); h[rb][3] = relu1(d[rb][3]);
+                    }
+                    // layer 1 of the NEXT record; the record after the last one of an item is the next item's
+#pragma unroll
+                    for (int rb = 0; rb < R; ++rb) {
+                        d[rb] = rbias[nu];
+#pragma unroll
+                        for (int kp = 0; kp < KP; ++kp) {
+                            const float xv = (u == PF - 1 && last_chunk) ? xN[rb][kp] : xB[rb][kp];
+                            d[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[nu][kp], xv, d[rb], 0, 0, 0);
+                        }
+                    }
+                    const f32x4 a2 = ra2[u];
+                    ra2[u] = ld4(off_a2, soff);
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, soff);
+                    rbias[u] = ld4(off_b, soff);
+                    soff += RECB;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int rb = 0; rb < R; ++rb)
+                            acc[rb][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[r], h[rb][r], acc[rb][r & 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4 * R, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, R * KP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * R, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int slice = wave * NSL + sl;
+            if (sl == 0 && k >= NBUF) sync_wait(sync + 1, NVW * (k - NBUF + 2));   // item k - NBUF consumed
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb) {
+                const f32x4 s = acc[rb][0] + acc[rb][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pk[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = s[r];
+            }
+        }
+        sync_signal(sync, lane);          // item k published
+        base = nbase;
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) xB[rb][kp] = xN[rb][kp];
+        if (dbg && blockIdx.x == 0 && wave == 0 && lane == 0) dbg[2 * k + 1] = clock64();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Sum of a double over lane groups of G = 16, 32 or 64 lanes with DPP moves (VALU only).
 // The total lands in every lane of the group's LAST 16-lane row (lanes G-16 .. G-1).
 // Fixed addition order => deterministic.
@@ -240,11 +414,10 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 // em_logl: the hot path
 // =======================================================================================
 // workgroup of em_logl: 4 MFMA-role waves + NVW VALU-role waves
-constexpr int NVW = 8;
-constexpr int LOGL_THREADS = 64 * (4 + NVW);
+constexpr int logl_threads(int NMW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, total;
     int32_t nf_max;
 };
 
@@ -255,9 +428,10 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
     L.stl = off;  off = align16(off + NS * 8);
-    L.part = off; off = align16(off + 2 * NSLICE * TS * PSTR * 4);   // double-buffered
-    L.chi = off;  off = align16(off + TS * 8);
-    L.gp = off;   off = align16(off + TS * 8);
+    L.part = off; off = align16(off + NBUF * NSLICE * TS * PSTR * 4);   // ring of NBUF items
+    L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
+    L.gp = off;   off = align16(off + n_items * TS * 8);
+    L.sync = off; off = align16(off + 16);
     L.bad = off;  off = align16(off + TS * 4);
     L.cdl = off;  off = align16(off + NVW * 4 * 16 * 8);           // per VALU wave: 4 slots x 16 coefficients
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
@@ -269,8 +443,8 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     return L;
 }
 
-template <int R, int KP>
-__global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
+template <int R, int KP, int NMW>
+__global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
     long long* __restrict__ dbg) {
@@ -292,16 +466,19 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
     unsigned char* tabl = smem + L.tab;
     double* cdl = reinterpret_cast<double*>(smem + L.cdl);
     const ItemDesc* itab = reinterpret_cast<const ItemDesc*>(smem + L.itab);
+    int* sync = reinterpret_cast<int*>(smem + L.sync);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 4) sync[tid] = 0;
+    __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
     const int W = P.n_items;
     gci32p items = as_global(P.items);
 
-    if (wave < 4) {
+    if (wave < NMW) {
         // ============================ MFMA role ============================
         // layer-1 operands straight from theta (no dependency on the other role's prologue)
         double xraw[R][KP];
@@ -316,24 +493,7 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
                 xraw[rb][kp] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
             }
         }
-        const int HBS = P.HB / NSLICE;
-        for (int k = 0; k < W; ++k) {
-            const int m = items[4 * k + 2];
-            float xB[R][KP];
-#pragma unroll
-            for (int rb = 0; rb < R; ++rb)
-#pragma unroll
-                for (int kp = 0; kp < KP; ++kp) {
-                    const int p = 4 * kp + (lane >> 4);
-                    xB[rb][kp] = (p < NP) ? (float)((xraw[rb][kp] - P.pmin[m * NP + p]) / P.pspan[m * NP + p]) : 0.f;
-                }
-            gcf32p rec = as_global(P.wrec) + ((size_t)m * (P.HB + NPAD_REC) + (size_t)wave * 2 * HBS) * RECF;
-            if (dbg && blockIdx.x == 0 && tid == 0) dbg[2 * k] = clock64();
-            mlp_slices<R, KP, PF, 2>(rec, xB, HBS, lane, part + (k & 1) * (NSLICE * TS * PSTR), wave * 2);
-            if (dbg && blockIdx.x == 0 && tid == 0) dbg[2 * k + 1] = clock64();
-            __syncthreads();     // barrier k: coefficients of item k published, buffer of item k-1 free
-        }
-        __syncthreads();         // barrier W (the other role finishes item W-1 before it)
+        mfma_role<R, KP, PF, NMW>(P, xraw, wave, lane, part, sync, dbg);
         return;
     }
 
@@ -341,8 +501,8 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
     // Few instructions, long dependency chains: give them the issue slot whenever they are
     // ready; the MFMA waves (lower priority) soak up every other cycle of the SIMD.
     __builtin_amdgcn_s_setprio(3);
-    const int vt = tid - 256;
-    const int vwave = wave - 4;
+    const int vt = tid - 64 * NMW;
+    const int vwave = wave - NMW;
     if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
     // ---- prologue: per-sample scalars, accumulators, sample-time grid
     if (vt < TS) {
@@ -353,8 +513,9 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
         sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
         for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
         scal[vt * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
-        chi_tot[vt] = 0.0; gp_tot[vt] = 0.0; bad[vt] = 0;
+        bad[vt] = 0;
     }
+    for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
     for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
     {
         gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
@@ -378,7 +539,7 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
     tab_dma(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
-    __syncthreads();             // barrier 0
+    sync_signal(sync + 1, lane);     // phase "prologue" of this wave done
 
     const bool uniform = P.st_uniform != 0;
     const double st0 = P.st0, inv_dt = P.st_inv_dt;
@@ -389,7 +550,7 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
         constexpr int NCT = decltype(nct_tag)::value;
         const ItemDesc& it = itab[k];
         const int o = it.o, ks = it.ks, nsrc = it.nsrc;
-        const float* pbuf = part + (k & 1) * (NSLICE * TS * PSTR);
+        const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
         const bool identity = it.identity != 0, same_grid = it.same_grid != 0;
         const double ebvc = it.ebvc;
@@ -570,8 +731,8 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
             gp = group_sum(gp, G);
             if (active && gi == G - 16) {
                 // running sums over observed filters, in filter order (em_likelihood.py:337-352)
-                chi_tot[s] += chi;
-                gp_tot[s] += gp;
+                chi_tot[k * TS + s] = chi;
+                gp_tot[k * TS + s] = gp;
                 if (chi != chi) bad[s] = 1;
                 if (chi_parts != nullptr && tile0 + s < B) {
                     chi_parts[(long)o * B + tile0 + s] = (scal[s * 8 + S_BAD] != 0.0) ? dnan() : chi;
@@ -592,7 +753,7 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
     auto item_fast = [&](const int k) {
         const ItemDesc& it = itab[k];
         const int o = it.o;
-        const float* pbuf = part + (k & 1) * (NSLICE * TS * PSTR);
+        const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
         const int G = it.G, d0 = it.d0, nf = it.nf;
         const double e_const = it.e_const;
@@ -663,8 +824,8 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
             chi = group_sum(chi, G);
             if (it.has_ul) gp = group_sum(gp, G);
             if (active && gi == G - 16) {
-                chi_tot[s] += chi;
-                gp_tot[s] += gp;
+                chi_tot[k * TS + s] = chi;
+                gp_tot[k * TS + s] = gp;
                 if (chi != chi) bad[s] = 1;
                 if (chi_parts != nullptr && tile0 + s < B) {
                     chi_parts[(long)o * B + tile0 + s] = (sc[S_BAD] != 0.0) ? dnan() : chi;
@@ -675,20 +836,27 @@ __global__ __launch_bounds__(LOGL_THREADS, 3) void em_logl(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    for (int k = 1; k <= W; ++k) {
-        if (dbg && blockIdx.x == 0 && vt == 0) dbg[64 + 2 * k] = clock64();
-        if (itab[k - 1].fast) item_fast(k - 1);
-        else if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k - 1);   // the reference default
-        else item_phase(std::integral_constant<int, 0>{}, k - 1);
-        if (dbg && blockIdx.x == 0 && vt == 0) dbg[64 + 2 * k + 1] = clock64();
-        __syncthreads();         // barrier k
+    for (int k = 0; k < W; ++k) {
+        sync_wait(sync + 1, NVW * (k + 1));      // every likelihood wave finished its previous phase
+        sync_wait(sync, NMW * (k + 1));          // coefficients of item k published
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k] = clock64();
+        if (itab[k].fast) item_fast(k);
+        else if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k);   // the reference default
+        else item_phase(std::integral_constant<int, 0>{}, k);
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k + 1] = clock64();
+        sync_signal(sync + 1, lane);
     }
     // ---- sum over filters + floor (core/base.py:178-182)
-    if (vt < TS && tile0 + vt < B) {
-        double tot = chi_tot[vt] + gp_tot[vt];
-        const bool isbad = always_floor != 0 || bad[vt] != 0 || scal[vt * 8 + S_BAD] != 0.0;
-        if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
-        out[tile0 + vt] = tot;
+    if (vwave == 0) {
+        sync_wait(sync + 1, NVW * (W + 1));
+        if (vt < TS && tile0 + vt < B) {
+            double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
+            for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
+            double tot = c + g;
+            const bool isbad = always_floor != 0 || bad[vt] != 0 || scal[vt * 8 + S_BAD] != 0.0;
+            if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+            out[tile0 + vt] = tot;
+        }
     }
 }
 
