@@ -37,6 +37,8 @@ struct EmDev {
     // surrogate
     const float* wrec;        // [M][HB + NPAD_REC][rec_floats(KP)]   (zero records: branch-free prefetch)
     int32_t wrec_bytes;
+    int32_t prio_valu, prio_mfma;   // s_setprio of the two roles of em_logl (NMMA_EM_PRIO="v,m"; default 3,0)
+    int32_t all_fast;         // every work item takes em_logl's fast path (no LDS table staging needed)
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
     const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
@@ -65,6 +67,7 @@ struct EmDev {
     const double* dsig;       // [N]
     const double* dsigtot;    // [N]  sqrt(sig^2 + e^2) for NMMA_SYS_CONST filters
     const double* dlogsig;    // [N]  log of the above
+    const double* dinvsig;    // [N]  1 / dsigtot (0 for upper limits: infinite sigma)
     const double* lim;        // [O]
     const int32_t* nsrc;      // [O]
     const int32_t* src;       // [O][3]

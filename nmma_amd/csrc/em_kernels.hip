@@ -72,8 +72,8 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 // Hidden units are always split into NSLICE partial sums added in slice order, so the
 // fp32 result does not depend on the launch geometry (R, WPB) chosen for a batch size.
 constexpr int NSLICE = 8;
-// likelihood-role waves of an em_logl workgroup (next to its NMW MFMA-role waves)
-constexpr int NVW = 8;
+// most likelihood-role waves of an em_logl workgroup (template NVW; next to its NMW MFMA-role waves)
+constexpr int NVW_MAX = 8;
 // zero records appended to every model filter's weight stream (deepest prefetch ring + 1)
 constexpr int NPAD_REC = 9;
 // row stride (floats) of the LDS partial-sum tiles: 16 coefficients + 1 pad (bank spread)
@@ -196,8 +196,10 @@ __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP],
 // ---------------------------------------------------------------------------------------
 // Role hand-off of em_logl through three LDS counters instead of workgroup barriers, so the
 // two roles never wait for each other unless the data dependency is real:
-//   sync[0] += 1 by every MFMA wave after its partial sums of an item are in LDS;
-//   sync[1] += 1 by every likelihood wave after each of its phases (prologue, item 0, ...).
+//   sync[k]         += 1 by every MFMA wave once its partial sums of item k are in LDS;
+//   sync[W + 1 + j] += 1 by every likelihood wave after its phase j - 1 (j = 0: prologue, j = k + 1: item k).
+// One counter per item/phase (never reset): waves of a role may run ahead of each other, so a
+// running total could be reached by early signals of the next item.
 // LDS instructions of one wave execute in order, so "data writes, then counter add" by the
 // producer and "counter read, then data reads" by the consumer need no further fence.
 // ---------------------------------------------------------------------------------------
@@ -224,8 +226,8 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target) {
 // ---------------------------------------------------------------------------------------
 constexpr int NBUF = 3;
 
-template <int R, int KP, int PF, int NMW>
-__device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], const int wave, const int lane,
+template <int R, int KP, int PF, int NMW, int NVW>
+__device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
                                           float* __restrict__ part, int* sync, long long* __restrict__ dbg) {
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
@@ -253,20 +255,22 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         const int m = items[4 * k + 2];
         return __builtin_amdgcn_readfirstlane((m * (P.HB + NPAD_REC) + wave * NSL * HBS) * RECB);
     };
+    // Normalisation constants (pmin, 1/pspan) of every model filter go to LDS once: every MFMA wave
+    // writes the same values and reads them back after its own writes (in-order LDS), so switching
+    // items costs LDS latency instead of an L2 round trip in the middle of the record stream.
+    for (int j = lane; j < P.M * NP; j += 64) { xnl[2 * j] = pmin[j]; xnl[2 * j + 1] = pinv[j]; }
     // normalised layer-1 inputs of item k: lane l holds x[sample rb*16 + (l&15)][param 4*kp + (l>>4)]
     auto load_x = [&](int k, float (&x)[R][KP]) {
         const int m = items[4 * k + 2];
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             const int p = 4 * kp + (lane >> 4);
-            const double mn = (p < NP) ? pmin[m * NP + p] : 0.0, iv = (p < NP) ? pinv[m * NP + p] : 0.0;
+            const double mn = (p < NP) ? xnl[2 * (m * NP + p)] : 0.0, iv = (p < NP) ? xnl[2 * (m * NP + p) + 1] : 0.0;
 #pragma unroll
             for (int rb = 0; rb < R; ++rb) x[rb][kp] = (float)((xraw[rb][kp] - mn) * iv);
         }
     };
 
-    float xB[R][KP], xN[R][KP];
-    load_x(0, xB);
     int base = item_base(0);
     f32x4 ra2[PF], rbias[PF];
     float ra1[PF][KP];
@@ -277,6 +281,8 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, base + u * RECB);
         rbias[u] = ld4(off_b, base + u * RECB);
     }
+    float xB[R][KP], xN[R][KP];
+    load_x(0, xB);
     f32x4 d[R];
 #pragma unroll
     for (int rb = 0; rb < R; ++rb) {
@@ -314,8 +320,12 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     f32x4 h[R];
 #pragma unroll
                     for (int rb = 0; rb < R; ++rb) {
+#ifdef NMMA_DBG_NORELU
+                        h[rb] = d[rb];
+#else
                         h[rb][0] = relu1(d[rb][0]); h[rb][1] = relu1(d[rb][1]);
                         h[rb][2] = relu1(d[rb][2]); h[rb][3] = relu1(d[rb][3]);
+#endif
                     }
                     // layer 1 of the NEXT record; the record after the last one of an item is the next item's
 #pragma unroll
@@ -328,25 +338,31 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                         }
                     }
                     const f32x4 a2 = ra2[u];
+#ifndef NMMA_DBG_NOLOAD
                     ra2[u] = ld4(off_a2, soff);
 #pragma unroll
                     for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, soff);
                     rbias[u] = ld4(off_b, soff);
+#endif
                     soff += RECB;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int rb = 0; rb < R; ++rb)
                             acc[rb][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[r], h[rb][r], acc[rb][r & 1], 0, 0, 0);
+#ifndef NMMA_DBG_NORELU
                     __builtin_amdgcn_sched_group_barrier(0x002, 4 * R, 0);
+#endif
                     __builtin_amdgcn_sched_group_barrier(0x008, R * KP, 0);
+#ifndef NMMA_DBG_NOLOAD
                     __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
+#endif
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * R, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             const int slice = wave * NSL + sl;
-            if (sl == 0 && k >= NBUF) sync_wait(sync + 1, NVW * (k - NBUF + 2));   // item k - NBUF consumed
+            if (sl == 0 && k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), NVW);   // item k - NBUF consumed
 #pragma unroll
             for (int rb = 0; rb < R; ++rb) {
                 const f32x4 s = acc[rb][0] + acc[rb][1];
@@ -355,7 +371,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     pk[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = s[r];
             }
         }
-        sync_signal(sync, lane);          // item k published
+        sync_signal(sync + k, lane);      // item k published
         base = nbase;
 #pragma unroll
         for (int rb = 0; rb < R; ++rb)
@@ -414,14 +430,14 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 // em_logl: the hot path
 // =======================================================================================
 // workgroup of em_logl: 4 MFMA-role waves + NVW VALU-role waves
-constexpr int logl_threads(int NMW) { return 64 * (NMW + NVW); }
+constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, total;
     int32_t nf_max;
 };
 
-__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items) {
+__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items, int M, int NP) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -431,9 +447,10 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.part = off; off = align16(off + NBUF * NSLICE * TS * PSTR * 4);   // ring of NBUF items
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + 16);
+    L.sync = off; off = align16(off + (2 * n_items + 2) * 4);
+    L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + TS * 4);
-    L.cdl = off;  off = align16(off + NVW * 4 * 16 * 8);           // per VALU wave: 4 slots x 16 coefficients
+    L.cdl = off;  off = align16(off + NVW_MAX * 4 * 16 * 8);           // per VALU wave: 4 slots x 16 coefficients
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
@@ -443,8 +460,8 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     return L;
 }
 
-template <int R, int KP, int NMW>
-__global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
+template <int R, int KP, int NMW, int NVW>
+__global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
     long long* __restrict__ dbg) {
@@ -467,11 +484,12 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
     double* cdl = reinterpret_cast<double*>(smem + L.cdl);
     const ItemDesc* itab = reinterpret_cast<const ItemDesc*>(smem + L.itab);
     int* sync = reinterpret_cast<int*>(smem + L.sync);
+    double* xnl = reinterpret_cast<double*>(smem + L.xn);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 4) sync[tid] = 0;
+    for (int j = tid; j < 2 * P.n_items + 2; j += logl_threads(NMW, NVW)) sync[j] = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
@@ -493,14 +511,25 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
                 xraw[rb][kp] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
             }
         }
-        mfma_role<R, KP, PF, NMW>(P, xraw, wave, lane, part, sync, dbg);
+        switch (P.prio_mfma) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            default: break;
+        }
+        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, sync, dbg);
         return;
     }
 
     // ================================ VALU role ================================
     // Few instructions, long dependency chains: give them the issue slot whenever they are
     // ready; the MFMA waves (lower priority) soak up every other cycle of the SIMD.
-    __builtin_amdgcn_s_setprio(3);
+    switch (P.prio_valu) {
+        case 0: break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const int vt = tid - 64 * NMW;
     const int vwave = wave - NMW;
     if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
@@ -536,15 +565,16 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
         for (int c = vwave; c * 1024 < tab_bytes; c += NVW)
             __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, dst + c * 1024, 16, 0, 0);
     };
-    tab_dma(0);
+    const bool all_fast = P.all_fast != 0;
+    if (!all_fast) tab_dma(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
-    sync_signal(sync + 1, lane);     // phase "prologue" of this wave done
+    sync_signal(sync + W + 1, lane);     // phase "prologue" of this wave done
 
     const bool uniform = P.st_uniform != 0;
     const double st0 = P.st0, inv_dt = P.st_inv_dt;
     gcf64p g_dt = as_global(P.dt), g_dm = as_global(P.dm), g_dsig = as_global(P.dsig);
-    gcf64p g_sigtot = as_global(P.dsigtot), g_logsig = as_global(P.dlogsig);
+    gcf64p g_sigtot = as_global(P.dsigtot), g_logsig = as_global(P.dlogsig), g_invsig = as_global(P.dinvsig);
 
     auto item_phase = [&](auto nct_tag, const int k) {
         constexpr int NCT = decltype(nct_tag)::value;
@@ -755,22 +785,65 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
         const int o = it.o;
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
-        const int G = it.G, d0 = it.d0, nf = it.nf;
+        const int G = it.G, d0 = it.d0, nf = it.nf;      // G = 16 lanes per sample unless nf > 32
         const double e_const = it.e_const;
         const int gpb = NV / G;
         const int g = vt / G, gi = vt - g * G;
         const int npass = (TS + gpb - 1) / gpb;
-        const unsigned char* tb = tabl + (k & 1) * tab_bytes;
-        const double* rows_m = reinterpret_cast<const double*>(tb);   // [NT][12]: VA row | span | mins
-        const float* b2l = reinterpret_cast<const float*>(tb + P.tab_off_b2);
-        double c_t = 0, c_m = 0, c_sig = 0, c_lsig = 0;
-        if (gi < nf) {
-            const int di = d0 + gi;
-            c_t = g_dt[di]; c_m = g_dm[di]; c_sig = g_sigtot[di]; c_lsig = g_logsig[di];
+        // basis rows straight from L2 (20 KiB per filter, shared by every workgroup): no LDS staging
+        const unsigned char* tb = P.tab + (size_t)it.m * tab_bytes;
+        gcf64p rows_m = as_global(reinterpret_cast<const double*>(tb));   // [NT][12]: VA row | span | mins
+        gcf32p b2l = as_global(reinterpret_cast<const float*>(tb + P.tab_off_b2));
+        // this lane's data (time, magnitude, 1/sigma_tot, log sigma_tot); 1/sigma_tot == 0 marks an upper limit
+        constexpr int NDL = 2;
+        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL];
+#pragma unroll
+        for (int u = 0; u < NDL; ++u) {
+            const int dd = gi + u * G;
+            c_t[u] = 0; c_m[u] = 0; c_is[u] = 0; c_ls[u] = 0;
+            if (dd < nf) {
+                const int di = d0 + dd;
+                c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di];
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_t), "+v"(c_m), "+v"(c_sig), "+v"(c_lsig)::"memory");
-        if (k + 1 < W) tab_dma(k + 1);
+        if (!all_fast) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (k + 1 < W) tab_dma(k + 1);
+        }
         const double st0 = P.st0, inv_dt = P.st_inv_dt;
+
+        // one datum: bracket on the sample's observer-frame grid, two basis rows, lerp, likelihood term
+        auto datum = [&](const double t, const double mobs, const double isig, const double lsig, const double (&cc)[10],
+                         const double zp1, const double tsh, const double izp1, const double izdt, const double dmrc,
+                         const double t_lo, const double t_hi, double& chi, double& gp) {
+            const bool inside = (jhi > jlo) && t >= t_lo && t <= t_hi;
+            int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+            lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
+            if (lo < 0) lo = 0;
+            double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
+            while (inside && ((x0 > t && lo > jlo) || (x1 <= t && lo < jhi - 1))) {   // exact re-check
+                lo += (x0 > t) ? -1 : 1;
+                x0 = stl[lo] * zp1 + tsh; x1 = stl[lo + 1] * zp1 + tsh;
+            }
+            gcf64p r0 = rows_m + lo * 12;
+            gcf64p r1 = r0 + 12;
+            double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
+#pragma unroll
+            for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
+            const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
+            const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
+            double est = ((y1 - y0) * izdt) * (t - x0) + y0;
+            if (x1 == t) est = y1;
+            if (!inside) est = (t != t) ? t : dinf();
+            const double x = (mobs - est) * isig;
+            if (isig != 0.0) {
+                double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
+                if (!(est < dinf())) v = dnan();
+                chi += v;
+            } else {
+                gp += upper_limit_term(mobs, est, e_const);
+            }
+        };
 
         for (int pass = 0; pass < npass; ++pass) {
             if (pass * gpb + (vwave * 64) / G >= TS) continue;     // wave has no sample in this pass
@@ -791,35 +864,19 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
 #pragma unroll
             for (int j = 0; j < 10; ++j) cc[j] = crow[j];
             const double* sc = scal + s * 8;
-            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], dmod = sc[S_DMOD], rc = sc[S_RC], izp1 = sc[S_IZP1];
+            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
+            const double dmrc = sc[S_DMOD] + sc[S_RC];
+            const double izdt = izp1 * inv_dt;
             const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
 
             double chi = 0.0, gp = 0.0;
-            for (int dd = gi; dd < nf; dd += G) {
-                double t = c_t, mobs = c_m, sig = c_sig, lsig = c_lsig;
-                if (dd != gi) { const int di = d0 + dd; t = g_dt[di]; mobs = g_dm[di]; sig = g_sigtot[di]; lsig = g_logsig[di]; }
-                const bool inside = (jhi > jlo) && t >= t_lo && t <= t_hi;
-                int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
-                lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
-                if (lo < 0) lo = 0;
-                double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
-                while (inside && ((x0 > t && lo > jlo) || (x1 <= t && lo < jhi - 1))) {   // exact re-check
-                    lo += (x0 > t) ? -1 : 1;
-                    x0 = stl[lo] * zp1 + tsh; x1 = stl[lo + 1] * zp1 + tsh;
-                }
-                const double* r0 = rows_m + lo * 12;
-                const double* r1 = r0 + 12;
-                double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
 #pragma unroll
-                for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
-                const double y0 = ((a0 * r0[10] + r0[11]) + dmod) + rc;
-                const double y1 = ((a1 * r1[10] + r1[11]) + dmod) + rc;
-                double est = lerp_np(t, x0, x1, y0, y1);
-                if (x0 == t) est = y0;
-                if (x1 == t) est = y1;
-                if (!inside) est = (t != t) ? t : dinf();
-                if (sig - sig == 0.0) chi += detection_term(mobs, est, sig, lsig, dinf());
-                else gp += upper_limit_term(mobs, est, e_const);
+            for (int u = 0; u < NDL; ++u)
+                if (gi + u * G < nf)
+                    datum(c_t[u], c_m[u], c_is[u], c_ls[u], cc, zp1, tsh, izp1, izdt, dmrc, t_lo, t_hi, chi, gp);
+            for (int dd = gi + NDL * G; dd < nf; dd += G) {
+                const int di = d0 + dd;
+                datum(g_dt[di], g_dm[di], g_invsig[di], g_logsig[di], cc, zp1, tsh, izp1, izdt, dmrc, t_lo, t_hi, chi, gp);
             }
             chi = group_sum(chi, G);
             if (it.has_ul) gp = group_sum(gp, G);
@@ -837,18 +894,23 @@ __global__ __launch_bounds__(logl_threads(NMW), 3) void em_logl(
     };
 
     for (int k = 0; k < W; ++k) {
-        sync_wait(sync + 1, NVW * (k + 1));      // every likelihood wave finished its previous phase
-        sync_wait(sync, NMW * (k + 1));          // coefficients of item k published
+        // every likelihood wave finished its previous phase (prologue data; LDS table buffer free).
+        // Without staged tables the waves only share read-only prologue data and run independently.
+        if (k == 0 || !all_fast) sync_wait(sync + W + 1 + k, NVW);
+        sync_wait(sync + k, NMW);                // coefficients of item k published
         if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k] = clock64();
+#ifdef NMMA_DBG_NOVALU
+        if (k < 0)
+#endif
         if (itab[k].fast) item_fast(k);
         else if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k);   // the reference default
         else item_phase(std::integral_constant<int, 0>{}, k);
         if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k + 1] = clock64();
-        sync_signal(sync + 1, lane);
+        sync_signal(sync + W + 2 + k, lane);
     }
     // ---- sum over filters + floor (core/base.py:178-182)
     if (vwave == 0) {
-        sync_wait(sync + 1, NVW * (W + 1));
+        sync_wait(sync + 2 * W + 1, NVW);
         if (vt < TS && tile0 + vt < B) {
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
