@@ -362,7 +362,8 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                 }
             }
             const int slice = wave * NSL + sl;
-            if (sl == 0 && k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), NVW);   // item k - NBUF consumed
+            if (sl == 0 && k >= NBUF)     // item k - NBUF consumed (one signal per wave, or per task in fast mode)
+                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW);
 #pragma unroll
             for (int rb = 0; rb < R; ++rb) {
                 const f32x4 s = acc[rb][0] + acc[rb][1];
@@ -776,141 +777,150 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     };
 
     // ---------------------------------------------------------------------------------
-    // Fast path of item_phase for the common configuration (flag computed at create):
-    // NC == 10, one source per band, constant systematics, no detection limit, sample_times
-    // equal to an equally spaced SVD grid, no extinction.  Same arithmetic, straight-line.
+    // Fast path (every item qualifies; flag computed at create): NC == 10, one source per band,
+    // constant systematics, no detection limit, sample_times equal to an equally spaced SVD grid,
+    // no extinction.  The likelihood waves are independent workers: a task is one wave-load of
+    // (item k, 64/G consecutive samples), G = 16/32/64 lanes per sample with two data per lane;
+    // tasks are dealt round-robin to the waves.  A task has two stages:
+    //   P (needs only the prologue): bracket every datum on the sample's observer-frame grid and
+    //     fetch its two basis rows [VA | span | mins] from L2 into registers;
+    //   Q (needs the coefficients of item k): reduce the 8 slice partial sums, 2 x 10 FMAs per datum,
+    //     lerp, likelihood term, DPP group sum.
+    // Only Q is on the critical path behind the MFMA role, and it contains no global-memory latency.
     // ---------------------------------------------------------------------------------
-    auto item_fast = [&](const int k) {
+    auto fast_task = [&](const int k, const int c) {
         const ItemDesc& it = itab[k];
         const int o = it.o;
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
-        const int G = it.G, d0 = it.d0, nf = it.nf;      // G = 16 lanes per sample unless nf > 32
+        const int G = it.G, d0 = it.d0, nf = it.nf;
         const double e_const = it.e_const;
-        const int gpb = NV / G;
-        const int g = vt / G, gi = vt - g * G;
-        const int npass = (TS + gpb - 1) / gpb;
-        // basis rows straight from L2 (20 KiB per filter, shared by every workgroup): no LDS staging
+        const int g = lane / G, gi = lane - g * G;
+        const int s = c * (64 / G) + g;                     // < TS: TS * G is a multiple of 64
         const unsigned char* tb = P.tab + (size_t)it.m * tab_bytes;
         gcf64p rows_m = as_global(reinterpret_cast<const double*>(tb));   // [NT][12]: VA row | span | mins
         gcf32p b2l = as_global(reinterpret_cast<const float*>(tb + P.tab_off_b2));
-        // this lane's data (time, magnitude, 1/sigma_tot, log sigma_tot); 1/sigma_tot == 0 marks an upper limit
+        const double st0 = P.st0, inv_dt = P.st_inv_dt;
+        const double* sc = scal + s * 8;
+        const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
+        const double dmrc = sc[S_DMOD] + sc[S_RC];
+        const double izdt = izp1 * inv_dt;
+        const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
+        const float b2mine = (gi < 16) ? b2l[gi] : 0.f;
+
+        // ---- stage P
         constexpr int NDL = 2;
-        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL];
+        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL], x1[NDL];
+        bool inside[NDL];
+        double r0[NDL][12], r1[NDL][12];
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
             const int dd = gi + u * G;
-            c_t[u] = 0; c_m[u] = 0; c_is[u] = 0; c_ls[u] = 0;
-            if (dd < nf) {
-                const int di = d0 + dd;
-                c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di];
-            }
+            const int di = d0 + (dd < nf ? dd : 0);
+            c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di];
         }
-        if (!all_fast) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (k + 1 < W) tab_dma(k + 1);
-        }
-        const double st0 = P.st0, inv_dt = P.st_inv_dt;
-
-        // one datum: bracket on the sample's observer-frame grid, two basis rows, lerp, likelihood term
-        auto datum = [&](const double t, const double mobs, const double isig, const double lsig, const double (&cc)[10],
-                         const double zp1, const double tsh, const double izp1, const double izdt, const double dmrc,
-                         const double t_lo, const double t_hi, double& chi, double& gp) {
-            const bool inside = (jhi > jlo) && t >= t_lo && t <= t_hi;
+#pragma unroll
+        for (int u = 0; u < NDL; ++u) {
+            if (u * G >= nf) { inside[u] = false; x0[u] = 0; x1[u] = 0; continue; }   // uniform: slot unused by this item
+            const double t = c_t[u];
+            inside[u] = (jhi > jlo) && t >= t_lo && t <= t_hi;
             int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
             lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
             if (lo < 0) lo = 0;
-            double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
-            while (inside && ((x0 > t && lo > jlo) || (x1 <= t && lo < jhi - 1))) {   // exact re-check
-                lo += (x0 > t) ? -1 : 1;
-                x0 = stl[lo] * zp1 + tsh; x1 = stl[lo + 1] * zp1 + tsh;
+            double a = stl[lo] * zp1 + tsh, b = stl[lo + 1] * zp1 + tsh;
+            while (inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1))) {   // exact re-check
+                lo += (a > t) ? -1 : 1;
+                a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
             }
-            gcf64p r0 = rows_m + lo * 12;
-            gcf64p r1 = r0 + 12;
-            double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
+            x0[u] = a; x1[u] = b;
+            gcf64p p0 = rows_m + lo * 12;
 #pragma unroll
-            for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
-            const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
-            const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
-            double est = ((y1 - y0) * izdt) * (t - x0) + y0;
-            if (x1 == t) est = y1;
-            if (!inside) est = (t != t) ? t : dinf();
-            const double x = (mobs - est) * isig;
-            if (isig != 0.0) {
-                double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
-                if (!(est < dinf())) v = dnan();
-                chi += v;
-            } else {
-                gp += upper_limit_term(mobs, est, e_const);
-            }
-        };
+            for (int j = 0; j < 12; ++j) { r0[u][j] = p0[j]; r1[u][j] = p0[12 + j]; }
+        }
 
-        for (int pass = 0; pass < npass; ++pass) {
-            if (pass * gpb + (vwave * 64) / G >= TS) continue;     // wave has no sample in this pass
-            const int sl = pass * gpb + g;
-            const bool active = sl < TS;
-            const int s = active ? sl : 0;
-            if (gi < 16) {
-                const int rb = s >> 4, sidx = s & 15;
-                const float* pp = pbuf + (rb * 16 + sidx) * PSTR + gi;
-                float cmine = 0.f;
+        // ---- stage Q
+        sync_wait(sync + k, NMW);                // coefficients of item k published
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        if (gi < 16) {
+            const int rb = s >> 4, sidx = s & 15;
+            const float* pp = pbuf + (rb * 16 + sidx) * PSTR + gi;
+            float cmine = 0.f;
 #pragma unroll
-                for (int w = 0; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
-                cmine += b2l[gi];
-                cdl[(vwave * 4 + (lane >> 4)) * 16 + gi] = (double)cmine;
-            }
-            const double* crow = cdl + (vwave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;
-            double cc[10];
+            for (int w = 0; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
+            cmine += b2mine;
+            cdl[(vwave * 4 + (lane >> 4)) * 16 + gi] = (double)cmine;
+        }
+        const double* crow = cdl + (vwave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;
+        double cc[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) cc[j] = crow[j];
-            const double* sc = scal + s * 8;
-            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
-            const double dmrc = sc[S_DMOD] + sc[S_RC];
-            const double izdt = izp1 * inv_dt;
-            const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
-
-            double chi = 0.0, gp = 0.0;
+        for (int j = 0; j < 10; ++j) cc[j] = crow[j];
+        double chi = 0.0, gp = 0.0;
 #pragma unroll
-            for (int u = 0; u < NDL; ++u)
-                if (gi + u * G < nf)
-                    datum(c_t[u], c_m[u], c_is[u], c_ls[u], cc, zp1, tsh, izp1, izdt, dmrc, t_lo, t_hi, chi, gp);
-            for (int dd = gi + NDL * G; dd < nf; dd += G) {
-                const int di = d0 + dd;
-                datum(g_dt[di], g_dm[di], g_invsig[di], g_logsig[di], cc, zp1, tsh, izp1, izdt, dmrc, t_lo, t_hi, chi, gp);
-            }
-            chi = group_sum(chi, G);
-            if (it.has_ul) gp = group_sum(gp, G);
-            if (active && gi == G - 16) {
-                chi_tot[k * TS + s] = chi;
-                gp_tot[k * TS + s] = gp;
-                if (chi != chi) bad[s] = 1;
-                if (chi_parts != nullptr && tile0 + s < B) {
-                    chi_parts[(long)o * B + tile0 + s] = (sc[S_BAD] != 0.0) ? dnan() : chi;
-                    gp_parts[(long)o * B + tile0 + s] = gp;
+        for (int u = 0; u < NDL; ++u) {
+            if (u * G >= nf) continue;
+            double a0 = r0[u][0] * cc[0], a1 = r1[u][0] * cc[0];
+#pragma unroll
+            for (int j = 1; j < 10; ++j) { a0 = fma(r0[u][j], cc[j], a0); a1 = fma(r1[u][j], cc[j], a1); }
+            const double y0 = (a0 * r0[u][10] + r0[u][11]) + dmrc;
+            const double y1 = (a1 * r1[u][10] + r1[u][11]) + dmrc;
+            const double t = c_t[u];
+            double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
+            if (x1[u] == t) est = y1;
+            if (!inside[u]) est = (t != t) ? t : dinf();
+            if (gi + u * G < nf) {
+                if (c_is[u] != 0.0) {
+                    const double x = (c_m[u] - est) * c_is[u];
+                    double v = (-(x * x) / 2.0 - kNormPdfLogC) - c_ls[u];
+                    if (!(est < dinf())) v = dnan();
+                    chi += v;
+                } else {
+                    gp += upper_limit_term(c_m[u], est, e_const);
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        chi = group_sum(chi, G);
+        if (it.has_ul) gp = group_sum(gp, G);
+        if (gi == G - 16) {
+            chi_tot[k * TS + s] = chi;
+            gp_tot[k * TS + s] = gp;
+            if (chi != chi) bad[s] = 1;
+            if (chi_parts != nullptr && tile0 + s < B) {
+                chi_parts[(long)o * B + tile0 + s] = (sc[S_BAD] != 0.0) ? dnan() : chi;
+                gp_parts[(long)o * B + tile0 + s] = gp;
+            }
+        }
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
+        sync_signal(sync + W + 2 + k, lane);     // one signal per task
     };
 
-    for (int k = 0; k < W; ++k) {
-        // every likelihood wave finished its previous phase (prologue data; LDS table buffer free).
-        // Without staged tables the waves only share read-only prologue data and run independently.
-        if (k == 0 || !all_fast) sync_wait(sync + W + 1 + k, NVW);
-        sync_wait(sync + k, NMW);                // coefficients of item k published
-        if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k] = clock64();
-#ifdef NMMA_DBG_NOVALU
-        if (k < 0)
+    if (all_fast) {
+        sync_wait(sync + W + 1, NVW);            // prologue data of every likelihood wave in LDS
+        int t0 = 0;                              // index of the item's first task
+        for (int k = 0; k < W; ++k) {
+            const int ntask = TS * itab[k].G / 64;
+#ifndef NMMA_DBG_NOVALU
+            for (int c = 0; c < ntask; ++c)
+                if ((t0 + c) % NVW == vwave) fast_task(k, c);
+#else
+            for (int c = 0; c < ntask; ++c) if ((t0 + c) % NVW == vwave) { sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane); }
 #endif
-        if (itab[k].fast) item_fast(k);
-        else if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k);   // the reference default
-        else item_phase(std::integral_constant<int, 0>{}, k);
-        if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k + 1] = clock64();
-        sync_signal(sync + W + 2 + k, lane);
+            t0 += ntask;
+        }
+    } else {
+        for (int k = 0; k < W; ++k) {
+            // every likelihood wave finished its previous phase (prologue data; LDS table buffer free)
+            sync_wait(sync + W + 1 + k, NVW);
+            sync_wait(sync + k, NMW);            // coefficients of item k published
+            if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k] = clock64();
+            if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k);   // the reference default
+            else item_phase(std::integral_constant<int, 0>{}, k);
+            if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k + 1] = clock64();
+            sync_signal(sync + W + 2 + k, lane);
+        }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
     if (vwave == 0) {
-        sync_wait(sync + 2 * W + 1, NVW);
+        for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? TS * itab[k].G / 64 : NVW);
         if (vt < TS && tile0 + vt < B) {
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }

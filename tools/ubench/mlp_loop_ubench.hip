@@ -29,6 +29,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ wrec, float* 
     soff += PF * RECB;
     f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[0], xB, rbias[0], 0, 0, 0);
     f32x4 dprev = d;
+    f32x4 dcur = d;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     f32x4 h = {relu1(d[0]), relu1(d[1]), relu1(d[2]), relu1(d[3])};
     const long long t0 = clock64();
@@ -39,6 +40,39 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ wrec, float* 
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int nu = (u + 1) % PF;
+            if (V == 4 || V == 5) {
+                // h = relu'd hidden values of record u (h[0] ready; h[1..3] computed below from dcur)
+                const f32x4 a2 = ra2[u];
+                h[1] = relu1(dcur[1]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0], h[0], acc0, 0, 0, 0);
+                h[2] = relu1(dcur[2]);
+                const f32x4 dn = __builtin_amdgcn_mfma_f32_16x16x4f32(ra1[nu], xB, rbias[nu], 0, 0, 0);
+                h[3] = relu1(dcur[3]);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[1], h[1], acc1, 0, 0, 0);
+                ra2[u] = ld4(off_a2, soff);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[2], h[2], acc0, 0, 0, 0);
+                ra1[u] = ld1(off_a1, soff);
+                rbias[u] = ld4(off_b, soff);
+                soff += RECB;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[3], h[3], acc1, 0, 0, 0);
+                dcur = dn;
+                h[0] = relu1(dn[0]);
+                if (V == 4) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // v_max h1
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // L2(0)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // v_max h2
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // L1 next
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // v_max h3
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // L2(1)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // load
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // L2(2)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // loads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // L2(3)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // v_max h0 (next)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if (V == 3) {
                 // h (relu of record u) was produced during the previous step; compute d(next) then, interleaved with
                 // this record's L2 MFMAs, the relu of d(next)
@@ -81,7 +115,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ wrec, float* 
         }
     }
     const long long t1 = clock64();
-    const f32x4 s = acc0 + acc1 + d + h + dprev;
+    const f32x4 s = acc0 + acc1 + d + h + dprev + dcur;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -112,10 +146,8 @@ int main() {
     run<0>("baseline (relu|L1|loads|L2)", d_w, out, cyc, wb);
     run<1>("no loads", d_w, out, cyc, wb);
     run<2>("no relu", d_w, out, cyc, wb);
-    run<0, 1>("baseline aux=1 (sc0)", d_w, out, cyc, wb);
-    run<0, 2>("baseline aux=2 (nt)", d_w, out, cyc, wb);
-    run<0, 3>("baseline aux=3", d_w, out, cyc, wb);
-    run<0, 0, 1>("compact W2 rows (OOB lanes)", d_w, out, cyc, wb);
+    run<4>("hand-interleaved + sched groups", d_w, out, cyc, wb);
+    run<5>("hand-interleaved, compiler order", d_w, out, cyc, wb);
     run<0>("baseline, 1 workgroup", d_w, out, cyc, wb, 1);
     return 0;
 }
