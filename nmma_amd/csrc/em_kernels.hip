@@ -224,11 +224,11 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target) {
 // last record of an item.  Partial sums of item k go to buffer k % NBUF of `part`; the role
 // only waits for the likelihood role when that buffer still holds item k - NBUF.
 // ---------------------------------------------------------------------------------------
-constexpr int NBUF = 3;
+constexpr int NBUF_MAX = 8;     // the ring depth NBUF is a launch parameter (LdsW::nbuf): min(n_items, what fits in LDS)
 
 template <int R, int KP, int PF, int NMW, int NVW>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
-                                          float* __restrict__ part, int* sync, long long* __restrict__ dbg) {
+                                          float* __restrict__ part, const int NBUF, int* sync, long long* __restrict__ dbg) {
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
     constexpr int NSL = NSLICE / NMW;
@@ -436,16 +436,20 @@ constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 struct LdsW {
     int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, total;
     int32_t nf_max;
+    int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
 
-__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items, int M, int NP) {
+__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items, int M, int NP, int all_fast) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
     L.stl = off;  off = align16(off + NS * 8);
-    L.part = off; off = align16(off + NBUF * NSLICE * TS * PSTR * 4);   // ring of NBUF items
+    // ring of partial-sum buffers: every item when the static tables need no LDS (fast mode), else 3
+    L.nbuf = all_fast ? (n_items < NBUF_MAX ? n_items : NBUF_MAX) : (n_items < 3 ? n_items : 3);
+    if (L.nbuf < 1) L.nbuf = 1;
+    L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
     L.sync = off; off = align16(off + (2 * n_items + 2) * 4);
@@ -456,7 +460,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
     off = (off + 1023) / 1024 * 1024;
-    L.tab = off;  off = align16(off + 2 * tab_bytes);               // double-buffered static tables
+    L.tab = off;  off = align16(off + (all_fast ? 0 : 2 * tab_bytes));   // double-buffered static tables (generic path)
     L.total = off;
     return L;
 }
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NBUF = L.nbuf;
     for (int j = tid; j < 2 * P.n_items + 2; j += logl_threads(NMW, NVW)) sync[j] = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             case 3: __builtin_amdgcn_s_setprio(3); break;
             default: break;
         }
-        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, sync, dbg);
+        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg);
         return;
     }
 
