@@ -205,6 +205,10 @@ int64_t nmma_em_flops_per_eval(const nmma_em_handle* h);   /* SURVEY.md section 
 int32_t nmma_em_last_launch_geometry(const nmma_em_handle* h, int32_t* grid_x, int32_t* grid_y,
                                      int32_t* block, int32_t* tile_samples, int32_t* lds_bytes);
 
+/* Synchronise the handle's device and report asynchronous failures of earlier launches (the hand-off
+ * watchdog of the log-likelihood kernel).  No reference counterpart: the reference is synchronous. */
+int32_t nmma_em_check(nmma_em_handle* h);
+
 /* Diagnostics: run nmma_em_loglike once and return 128 shader-clock stamps taken inside
  * workgroup 0 (entries 2k, 2k+1: MFMA role around the MLP of work item k; 64+2k, 64+2k+1:
  * VALU role around the downstream phase of item k-1; 64, 65: prologue).  Synchronous. */

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_em_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
+    "nmma_em_check": (C.c_int32, [C.c_void_p]),
     "nmma_em_debug_timeline": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                            C.POINTER(C.c_int64)]),
     "nmma_em_n_sample_times": (C.c_int32, [C.c_void_p]),

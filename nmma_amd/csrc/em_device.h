@@ -38,6 +38,8 @@ struct EmDev {
     const float* wrec;        // [M][HB + NPAD_REC][rec_floats(KP)]   (zero records: branch-free prefetch)
     int32_t wrec_bytes;
     int32_t prio_valu, prio_mfma;   // s_setprio of the two roles of em_logl (NMMA_EM_PRIO="v,m"; default 3,0)
+    int* watchdog;            // [4] device words: {tripped, code, workgroup*64+wave, value*65536+target} (em_logl hand-off waits)
+    int32_t helpers;          // MFMA-role waves join the likelihood workers after their stream (NMMA_EM_HELPERS, default 1)
     int32_t all_fast;         // every work item takes em_logl's fast path (no LDS table staging needed)
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)

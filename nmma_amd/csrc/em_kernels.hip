@@ -208,9 +208,21 @@ __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lds_ip)cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void sync_wait(int* cnt, const int target) {
-    while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+// A wait that does not complete within ~2^20 polls (tens of milliseconds; a healthy launch needs
+// microseconds) records where it was stuck in the handle's watchdog words and gives up, so that a
+// protocol bug surfaces as an error code from the C ABI instead of a hung GPU.
+__device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog = nullptr, const int code = 0) {
+    int spins = 0;
+    while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
         __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) {
+            if (watchdog != nullptr && (threadIdx.x & 63) == 0) {
+                watchdog[0] = 1; watchdog[1] = code; watchdog[2] = (int)blockIdx.x * 64 + (int)(threadIdx.x >> 6);
+                watchdog[3] = __hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 65536 + target;
+            }
+            break;
+        }
+    }
     asm volatile("" ::: "memory");
 }
 
@@ -224,7 +236,9 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target) {
 // last record of an item.  Partial sums of item k go to buffer k % NBUF of `part`; the role
 // only waits for the likelihood role when that buffer still holds item k - NBUF.
 // ---------------------------------------------------------------------------------------
-constexpr int NBUF_MAX = 8;     // the ring depth NBUF is a launch parameter (LdsW::nbuf): min(n_items, what fits in LDS)
+constexpr int NBUF_MAX = 8;
+// prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
+constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;     // the ring depth NBUF is a launch parameter (LdsW::nbuf): min(n_items, what fits in LDS)
 
 template <int R, int KP, int PF, int NMW, int NVW>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
@@ -363,7 +377,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
             }
             const int slice = wave * NSL + sl;
             if (sl == 0 && k >= NBUF)     // item k - NBUF consumed (one signal per wave, or per task in fast mode)
-                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW);
+                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
 #pragma unroll
             for (int rb = 0; rb < R; ++rb) {
                 const f32x4 s = acc[rb][0] + acc[rb][1];
@@ -408,14 +422,16 @@ __device__ __forceinline__ double group_sum(double v, const int G) {
 // Per-sample scalars of em_parameter_setup (model.py:288-303) + conversions, for the
 // sample whose theta row is `row`; written to scal[8] / praw[8] of that sample.
 __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row, double* praw, double* scal,
-                                               double& chk) {
+                                               double& chk, const double* dist_grid = nullptr,
+                                               const double* z_grid = nullptr) {
+    if (dist_grid == nullptr) { dist_grid = P.dist_grid; z_grid = P.z_grid; }
     for (int p = 0; p < NMMA_MAX_PARAMS; ++p) praw[p] = (p < P.NP) ? apply_slot(P.model_param[p], row) : 0.0;
     const double d_l = apply_slot(P.lumdist, row);
     double z = 0.0;
     if (P.redshift_mode == NMMA_Z_SLOT) {
         z = apply_slot(P.redshift, row);
     } else if (P.redshift_mode == NMMA_Z_GRID) {
-        z = interp_np(d_l, P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
+        z = interp_np(d_l, dist_grid, z_grid, P.n_cosmo, z_grid[0], z_grid[P.n_cosmo - 1]);
     }
     scal[S_ZP1] = 1 + z;
     scal[S_IZP1] = 1.0 / (1 + z);   // only seeds the bracket guess (exactly re-checked)
@@ -434,7 +450,7 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, total;
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
@@ -452,10 +468,11 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + (2 * n_items + 2) * 4);
+    L.sync = off; off = align16(off + (2 * n_items + 4) * 4);
+    L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + TS * 4);
-    L.cdl = off;  off = align16(off + NVW_MAX * 4 * 16 * 8);           // per VALU wave: 4 slots x 16 coefficients
+    L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);             // per wave (any role): 4 slots x 16 coefficients           // per VALU wave: 4 slots x 16 coefficients
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
@@ -495,7 +512,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
-    for (int j = tid; j < 2 * P.n_items + 2; j += logl_threads(NMW, NVW)) sync[j] = 0;
+    for (int j = tid; j < 2 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
@@ -524,7 +541,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             default: break;
         }
         mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg);
-        return;
+        if (!P.all_fast || !P.helpers) return;
+        // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
     }
 
     // ================================ VALU role ================================
@@ -536,31 +554,59 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
     }
-    const int vt = tid - 64 * NMW;
+    const bool helper = wave < NMW;              // an MFMA-role wave that finished its stream
+    const int vt = tid - 64 * NMW;               // negative for helpers (they skip the prologue)
     const int vwave = wave - NMW;
-    if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
-    // ---- prologue: per-sample scalars, accumulators, sample-time grid
-    if (vt < TS) {
-        long b = tile0 + vt;
-        if (b >= B) b = B - 1;
-        const double* row = theta + b * ld;
-        double chk;
-        sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
-        for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
-        scal[vt * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
-        bad[vt] = 0;
-    }
-    for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
-    for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
-    {
-        gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
-        int* dst = reinterpret_cast<int*>(smem + L.itab);
-        for (int j = vt; j < W * ITEM_WORDS; j += NV) dst[j] = src[j];
-    }
+    if (!helper) {
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
+        // ---- prologue: per-sample scalars, accumulators, sample-time grid.
+        // The tile's theta rows and the cosmology grid are first staged in LDS by all likelihood waves
+        // (ONE memory round trip), so the serial slot/interpolation chain of sample_scalars runs on
+        // LDS latency instead of ~40 dependent L2/HBM round trips.
+        const bool staged = (ld <= STAGE_COLS) && (P.redshift_mode != NMMA_Z_GRID || P.n_cosmo <= STAGE_COSMO);
+        double* thl = reinterpret_cast<double*>(smem + L.stage);
+        double* dgl = thl + TS * STAGE_COLS;
+        double* zgl = dgl + STAGE_COSMO;
+        if (staged) {
+            const int ncol = (int)ld;
+            for (int idx = vt; idx < TS * ncol; idx += NV) {
+                const int sidx = idx / ncol, cidx = idx - sidx * ncol;
+                long b = tile0 + sidx;
+                if (b >= B) b = B - 1;
+                thl[sidx * ncol + cidx] = theta[b * ld + cidx];
+            }
+            if (P.redshift_mode == NMMA_Z_GRID)
+                for (int j = vt; j < P.n_cosmo; j += NV) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
+            sync_signal(sync + 2 * W + 2, lane);
+        }
+        if (vt < TS) {
+            long b = tile0 + vt;
+            if (b >= B) b = B - 1;
+            const double* row = theta + b * ld;
+            double chk;
+            if (staged) {
+                sync_wait(sync + 2 * W + 2, NVW, P.watchdog, 200);
+                row = thl + vt * (int)ld;
+                sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk, dgl, zgl);
+            } else {
+                sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
+            }
+            for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+            scal[vt * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+            bad[vt] = 0;
+        }
+        for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
+        for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
+        {
+            gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
+            int* dst = reinterpret_cast<int*>(smem + L.itab);
+            for (int j = vt; j < W * ITEM_WORDS; j += NV) dst[j] = src[j];
+        }
 
-    // Static tables of a model filter (basis rows, span, mins, stage-1 lerp tables) are
-    // copied global -> LDS by LDS-DMA one item ahead, into the other half of a double buffer:
-    // no registers, and the L2 latency hides behind the phase of the previous item.
+        // Static tables of a model filter (basis rows, span, mins, stage-1 lerp tables) are
+        // copied global -> LDS by LDS-DMA one item ahead, into the other half of a double buffer:
+        // no registers, and the L2 latency hides behind the phase of the previous item.
+    }
     const int tab_bytes = P.tab_bytes;                 // multiple of 1 KiB (one wave-instruction)
     typedef __attribute__((address_space(3))) unsigned char* lds_p;
     typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
@@ -572,10 +618,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, dst + c * 1024, 16, 0, 0);
     };
     const bool all_fast = P.all_fast != 0;
-    if (!all_fast) tab_dma(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
-    sync_signal(sync + W + 1, lane);     // phase "prologue" of this wave done
+    if (!helper) {
+        if (!all_fast) tab_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
+        sync_signal(sync + W + 1, lane);     // phase "prologue" of this wave done
+    }
 
     const bool uniform = P.st_uniform != 0;
     const double st0 = P.st0, inv_dt = P.st_inv_dt;
@@ -833,7 +881,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
             if (lo < 0) lo = 0;
             double a = stl[lo] * zp1 + tsh, b = stl[lo + 1] * zp1 + tsh;
-            while (inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1))) {   // exact re-check
+            for (int it2 = 0; it2 < 4 && inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1)); ++it2) {   // exact re-check (the guess is off by at most one)
                 lo += (a > t) ? -1 : 1;
                 a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
             }
@@ -844,7 +892,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         }
 
         // ---- stage Q
-        sync_wait(sync + k, NMW);                // coefficients of item k published
+        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
         if (gi < 16) {
             const int rb = s >> 4, sidx = s & 15;
@@ -853,9 +901,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
 #pragma unroll
             for (int w = 0; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
             cmine += b2mine;
-            cdl[(vwave * 4 + (lane >> 4)) * 16 + gi] = (double)cmine;
+            cdl[(wave * 4 + (lane >> 4)) * 16 + gi] = (double)cmine;
         }
-        const double* crow = cdl + (vwave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;
+        const double* crow = cdl + (wave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;
         double cc[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) cc[j] = crow[j];
@@ -899,23 +947,46 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     };
 
     if (all_fast) {
-        sync_wait(sync + W + 1, NVW);            // prologue data of every likelihood wave in LDS
-        int t0 = 0;                              // index of the item's first task
-        for (int k = 0; k < W; ++k) {
-            const int ntask = TS * itab[k].G / 64;
-#ifndef NMMA_DBG_NOVALU
-            for (int c = 0; c < ntask; ++c)
-                if ((t0 + c) % NVW == vwave) fast_task(k, c);
+        sync_wait(sync + W + 1, NVW, P.watchdog, 400);   // prologue data of every likelihood wave in LDS
+        // Tasks (item-major) are claimed from one LDS counter: likelihood waves from the start, MFMA-role
+        // waves once their record stream is finished.  Any wave may compute any task (results go to
+        // per-(item, sample) slots), so the claim order does not affect the values.
+        // (task counts are made explicitly wave-uniform: the claim loop must not be compiled as a divergent loop)
+        int ntot = 0;
+        for (int k = 0; k < W; ++k) ntot += __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64);
+        int tstat = vwave; (void)tstat;
+        int claims = 0;
+        for (;;) {
+#ifdef NMMA_DBG_STATIC
+            int t = tstat; tstat += NVW;
 #else
-            for (int c = 0; c < ntask; ++c) if ((t0 + c) % NVW == vwave) { sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane); }
+            // every lane issues the LDS add (lane 0 adds 1, the others 0): no divergent control flow around the claim
+            int tv;
+            {
+                const unsigned addr = (unsigned)(uintptr_t)(lds_ip)(sync + 2 * W + 3);
+                const int inc = (lane == 0) ? 1 : 0;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tv) : "v"(addr), "v"(inc) : "memory");
+            }
+            int t = __builtin_amdgcn_readfirstlane(tv);
 #endif
-            t0 += ntask;
+            if (t >= ntot) break;
+            if (++claims > ntot + 64) {          // cannot happen; fail loudly instead of spinning
+                if (lane == 0) { P.watchdog[0] = 1; P.watchdog[1] = 900; P.watchdog[2] = (int)blockIdx.x * 64 + wave; P.watchdog[3] = t; }
+                break;
+            }
+            int k = 0;
+            for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64); if (t < n) break; t -= n; }
+#ifndef NMMA_DBG_NOVALU
+            fast_task(k, t);
+#else
+            sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
+#endif
         }
     } else {
         for (int k = 0; k < W; ++k) {
             // every likelihood wave finished its previous phase (prologue data; LDS table buffer free)
-            sync_wait(sync + W + 1 + k, NVW);
-            sync_wait(sync + k, NMW);            // coefficients of item k published
+            sync_wait(sync + W + 1 + k, NVW, P.watchdog, 500 + k);
+            sync_wait(sync + k, NMW, P.watchdog, 600 + k);   // coefficients of item k published
             if (dbg && blockIdx.x == 0 && vt == 0) dbg[66 + 2 * k] = clock64();
             if (NC == 10) item_phase(std::integral_constant<int, 10>{}, k);   // the reference default
             else item_phase(std::integral_constant<int, 0>{}, k);
@@ -924,8 +995,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
-    if (vwave == 0) {
-        for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? TS * itab[k].G / 64 : NVW);
+    if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
+        for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? TS * itab[k].G / 64 : NVW, P.watchdog, 700 + k);
         if (vt < TS && tile0 + vt < B) {
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }

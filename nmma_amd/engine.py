@@ -407,6 +407,10 @@ class EMEngine:
                 "nmma_em_profile_end")
         return dict(fused_ms_total=f.value, combine_ms_total=c.value, n_launches=n.value)
 
+    def check(self):
+        """Synchronise and raise if an earlier asynchronous launch failed (kernel watchdog)."""
+        L.check(self._lib.nmma_em_check(self._handle), "nmma_em_check")
+
     def close(self):
         if getattr(self, "_handle", None):
             self._lib.nmma_em_destroy(self._handle)
