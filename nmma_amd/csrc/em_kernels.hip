@@ -212,10 +212,12 @@ __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
 // microseconds) records where it was stuck in the handle's watchdog words and gives up, so that a
 // protocol bug surfaces as an error code from the C ABI instead of a hung GPU.
 __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog = nullptr, const int code = 0) {
+    // Every VALU instruction of a polling wave takes an issue slot from the MFMA waves of its SIMD (a poll is
+    // v_mov + ds_read + v_cmp): sleep ~400 cycles between polls so that waiting costs next to nothing.
     int spins = 0;
     while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) {
+        __builtin_amdgcn_s_sleep(6);
+        if (++spins > (1 << 18)) {
             if (watchdog != nullptr && (threadIdx.x & 63) == 0) {
                 watchdog[0] = 1; watchdog[1] = code; watchdog[2] = (int)blockIdx.x * 64 + (int)(threadIdx.x >> 6);
                 watchdog[3] = __hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 65536 + target;
@@ -242,7 +244,8 @@ constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;     // the ring depth NBUF is 
 
 template <int R, int KP, int PF, int NMW, int NVW>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
-                                          float* __restrict__ part, const int NBUF, int* sync, long long* __restrict__ dbg) {
+                                          float* __restrict__ part, unsigned char* tabl, const int NBUF, int* sync,
+                                          long long* __restrict__ dbg) {
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
     constexpr int NSL = NSLICE / NMW;
@@ -318,6 +321,15 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                 for (int kp = 0; kp < KP; ++kp) xN[rb][kp] = xB[rb][kp];
         }
         float* pk = part + (k % NBUF) * (NSLICE * TS * PSTR);
+        // ring slot k % NBUF is reused: item k - NBUF must be consumed before the first write into it
+        // (partial sums or staged rows, whichever comes first); one signal per wave, or per task in fast mode
+        bool slot_free = k < NBUF;
+        auto wait_slot = [&]() {
+            if (!slot_free) {
+                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
+                slot_free = true;
+            }
+        };
         int soff = base + PF * RECB;              // record fetched by the next refill
 #pragma unroll 1
         for (int sl = 0; sl < NSL; ++sl) {
@@ -327,7 +339,21 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
 #pragma unroll 1
             for (int c = 0; c < CPS; ++c) {
                 const bool last_chunk = (sl == NSL - 1) && (c == CPS - 1);
-                if (last_chunk) soff = nbase;     // refills now fetch the first PF records of the next item
+                if (last_chunk) {
+                    soff = nbase;                 // refills now fetch the first PF records of the next item
+                    if (P.all_fast) {
+                        // ring slot k % NBUF: wait until item k - NBUF is consumed, then stage this item's basis
+                        // rows (LDS-DMA, no registers); they land during the last PF records of the item
+                        wait_slot();
+                        typedef __attribute__((address_space(3))) unsigned char* lds_bp;
+                        typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+                        const int m = items[4 * k + 2];
+                        gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)m * P.tab_bytes);
+                        lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
+                        for (int q = wave; q * 1024 < P.tab_fast_bytes; q += NMW)
+                            __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int nu = (u + 1) % PF;
@@ -376,8 +402,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                 }
             }
             const int slice = wave * NSL + sl;
-            if (sl == 0 && k >= NBUF)     // item k - NBUF consumed (one signal per wave, or per task in fast mode)
-                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
+            wait_slot();
 #pragma unroll
             for (int rb = 0; rb < R; ++rb) {
                 const f32x4 s = acc[rb][0] + acc[rb][1];
@@ -386,6 +411,8 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     pk[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = s[r];
             }
         }
+        // every load older than the PF records in flight has landed -- including this item's staged rows
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * (2 + KP)) : "memory");
         sync_signal(sync + k, lane);      // item k published
         base = nbase;
 #pragma unroll
@@ -455,16 +482,23 @@ struct LdsW {
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
 
-__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int n_items, int M, int NP, int all_fast) {
+__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
+                                     int all_fast) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
     L.stl = off;  off = align16(off + NS * 8);
-    // ring of partial-sum buffers: every item when the static tables need no LDS (fast mode), else 3
-    L.nbuf = all_fast ? (n_items < NBUF_MAX ? n_items : NBUF_MAX) : (n_items < 3 ? n_items : 3);
-    if (L.nbuf < 1) L.nbuf = 1;
+    // ring depth (items the MFMA role may run ahead): fast mode rings {partial sums, staged basis rows}
+    // per item and takes as many slots as fit the 160 KiB of LDS (at most 4); the generic path keeps
+    // 3 partial-sum buffers next to its double-buffered tables
+    L.nbuf = n_items < 3 ? (n_items < 1 ? 1 : n_items) : 3;
+    if (all_fast && n_items > 3) {
+        const int fixed = 44 * 1024;      // everything except the ring (generous)
+        const int slot = NSLICE * TS * PSTR * 4 + tab_fast_bytes;
+        if (fixed + 4 * slot <= 160 * 1024) L.nbuf = 4;
+    }
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
@@ -477,7 +511,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
     off = (off + 1023) / 1024 * 1024;
-    L.tab = off;  off = align16(off + (all_fast ? 0 : 2 * tab_bytes));   // double-buffered static tables (generic path)
+    L.tab = off;  off = align16(off + (all_fast ? L.nbuf * tab_fast_bytes : 2 * tab_bytes));   // fast: ring of [rows | b2]; generic: double buffer
     L.total = off;
     return L;
 }
@@ -540,7 +574,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             case 3: __builtin_amdgcn_s_setprio(3); break;
             default: break;
         }
-        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg);
+        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, tabl, L.nbuf, sync, dbg);
         if (!P.all_fast || !P.helpers) return;
         // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
     }
@@ -850,22 +884,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         const double e_const = it.e_const;
         const int g = lane / G, gi = lane - g * G;
         const int s = c * (64 / G) + g;                     // < TS: TS * G is a multiple of 64
-        const unsigned char* tb = P.tab + (size_t)it.m * tab_bytes;
-        gcf64p rows_m = as_global(reinterpret_cast<const double*>(tb));   // [NT][12]: VA row | span | mins
-        gcf32p b2l = as_global(reinterpret_cast<const float*>(tb + P.tab_off_b2));
         const double st0 = P.st0, inv_dt = P.st_inv_dt;
         const double* sc = scal + s * 8;
         const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
         const double dmrc = sc[S_DMOD] + sc[S_RC];
         const double izdt = izp1 * inv_dt;
         const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
-        const float b2mine = (gi < 16) ? b2l[gi] : 0.f;
 
-        // ---- stage P
+        // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid
         constexpr int NDL = 2;
-        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL], x1[NDL];
-        bool inside[NDL];
-        double r0[NDL][12], r1[NDL][12];
+        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL];
+        bool inside[NDL], hit1[NDL];
+        int lo_[NDL];
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
             const int dd = gi + u * G;
@@ -874,7 +904,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         }
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
-            if (u * G >= nf) { inside[u] = false; x0[u] = 0; x1[u] = 0; continue; }   // uniform: slot unused by this item
+            if (u * G >= nf) { inside[u] = false; hit1[u] = false; x0[u] = 0; lo_[u] = 0; continue; }   // uniform: slot unused by this item
             const double t = c_t[u];
             inside[u] = (jhi > jlo) && t >= t_lo && t <= t_hi;
             int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
@@ -885,22 +915,22 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
                 lo += (a > t) ? -1 : 1;
                 a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
             }
-            x0[u] = a; x1[u] = b;
-            gcf64p p0 = rows_m + lo * 12;
-#pragma unroll
-            for (int j = 0; j < 12; ++j) { r0[u][j] = p0[j]; r1[u][j] = p0[12 + j]; }
+            x0[u] = a; hit1[u] = (b == t); lo_[u] = lo;
         }
 
         // ---- stage Q
-        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
+        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients + staged rows of item k published
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
+        const double* rows_l = reinterpret_cast<const double*>(tbl);          // [NT][12]: VA row | span | mins
+        const float* b2l = reinterpret_cast<const float*>(tbl + P.tab_off_b2);
         if (gi < 16) {
             const int rb = s >> 4, sidx = s & 15;
             const float* pp = pbuf + (rb * 16 + sidx) * PSTR + gi;
             float cmine = 0.f;
 #pragma unroll
             for (int w = 0; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
-            cmine += b2mine;
+            cmine += b2l[gi];
             cdl[(wave * 4 + (lane >> 4)) * 16 + gi] = (double)cmine;
         }
         const double* crow = cdl + (wave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;
@@ -911,14 +941,16 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
             if (u * G >= nf) continue;
-            double a0 = r0[u][0] * cc[0], a1 = r1[u][0] * cc[0];
+            const double* r0 = rows_l + lo_[u] * 12;
+            const double* r1 = r0 + 12;
+            double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
 #pragma unroll
-            for (int j = 1; j < 10; ++j) { a0 = fma(r0[u][j], cc[j], a0); a1 = fma(r1[u][j], cc[j], a1); }
-            const double y0 = (a0 * r0[u][10] + r0[u][11]) + dmrc;
-            const double y1 = (a1 * r1[u][10] + r1[u][11]) + dmrc;
+            for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
+            const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
+            const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
             const double t = c_t[u];
             double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
-            if (x1[u] == t) est = y1;
+            if (hit1[u]) est = y1;
             if (!inside[u]) est = (t != t) ? t : dinf();
             if (gi + u * G < nf) {
                 if (c_is[u] != 0.0) {
