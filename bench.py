@@ -12,8 +12,9 @@ shards' logL are exchanged with ONE RCCL all-gather per step (weak scaling).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` prices the fused per-filter kernel against the
-dense fp32 MFMA peak with the ALGORITHMIC flop count of SURVEY.md section 8d
+Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
+MLP on the f32 MFMA pipe, SVD reconstruction, interpolation and likelihood terms in one launch)
+against the dense fp32 MFMA peak with the ALGORITHMIC flop count of SURVEY.md section 8d
 (sum over filters of 2*NP*NH + 2*NH*NC + 2*NC*NT = 369 384 flop/eval); its duration is
 measured with HIP events on the launch stream inside the timed region.  `cpu_baseline`
 times the CPU oracle (a port of the reference's per-sample Python calling pattern,
@@ -97,7 +98,11 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    os.environ["NMMA_PROFILE_STRIDE"] = "4"     # HIP events around every 4th launch of the timed region
+    # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
+    # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
+    # by the dispatch latency behind the start event); with a collective between launches, single launches.
+    os.environ["NMMA_PROFILE_GROUP"] = "8" if world == 1 else "1"
+    os.environ["NMMA_PROFILE_STRIDE"] = "2" if world == 1 else "4"
     eng.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
