@@ -238,11 +238,11 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 // last record of an item.  Partial sums of item k go to buffer k % NBUF of `part`; the role
 // only waits for the likelihood role when that buffer still holds item k - NBUF.
 // ---------------------------------------------------------------------------------------
-constexpr int NBUF_MAX = 8;
+// (the ring depth NBUF is a launch parameter, LdsW::nbuf: what fits in LDS, at most 4)
 // prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
-constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;     // the ring depth NBUF is a launch parameter (LdsW::nbuf): min(n_items, what fits in LDS)
+constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 
-template <int R, int KP, int PF, int NMW, int NVW>
+template <int R, int KP, int PF, int NMW, int NVW, bool FAST>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
                                           float* __restrict__ part, unsigned char* tabl, const int NBUF, int* sync,
                                           long long* __restrict__ dbg) {
@@ -326,7 +326,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         bool slot_free = k < NBUF;
         auto wait_slot = [&]() {
             if (!slot_free) {
-                sync_wait(sync + W + 1 + (k - NBUF + 1), P.all_fast ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
+                sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
                 slot_free = true;
             }
         };
@@ -341,7 +341,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                 const bool last_chunk = (sl == NSL - 1) && (c == CPS - 1);
                 if (last_chunk) {
                     soff = nbase;                 // refills now fetch the first PF records of the next item
-                    if (P.all_fast) {
+                    if constexpr (FAST) {
                         // ring slot k % NBUF: wait until item k - NBUF is consumed, then stage this item's basis
                         // rows (LDS-DMA, no registers); they land during the last PF records of the item
                         wait_slot();
@@ -516,8 +516,10 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     return L;
 }
 
-template <int R, int KP, int NMW, int NVW>
-__global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
+// FAST: every work item qualifies for the fast path (EmDev::all_fast) -- the generic item phase and its
+// LDS table staging are not compiled in, which keeps the register budget small enough for 16-wave workgroups.
+template <int R, int KP, int NMW, int NVW, bool FAST>
+__global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
     long long* __restrict__ dbg) {
@@ -574,8 +576,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             case 3: __builtin_amdgcn_s_setprio(3); break;
             default: break;
         }
-        mfma_role<R, KP, PF, NMW, NVW>(P, xraw, xnl, wave, lane, part, tabl, L.nbuf, sync, dbg);
-        if (!P.all_fast || !P.helpers) return;
+        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, tabl, L.nbuf, sync, dbg);
+        if (!FAST || !P.helpers) return;
         // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
     }
 
@@ -651,9 +653,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         for (int c = vwave; c * 1024 < tab_bytes; c += NVW)
             __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, dst + c * 1024, 16, 0, 0);
     };
-    const bool all_fast = P.all_fast != 0;
+    constexpr bool all_fast = FAST;
     if (!helper) {
-        if (!all_fast) tab_dma(0);
+        if constexpr (!FAST) tab_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (dbg && blockIdx.x == 0 && vt == 0) dbg[65] = clock64();
         sync_signal(sync + W + 1, lane);     // phase "prologue" of this wave done
@@ -876,6 +878,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
     // Only Q is on the critical path behind the MFMA role, and it contains no global-memory latency.
     // ---------------------------------------------------------------------------------
     auto fast_task = [&](const int k, const int c) {
+        const bool dbt = dbg && blockIdx.x == 0 && lane == 0 && c == 0 && k == W - 1;
+        if (dbt) dbg[96] = clock64();
         const ItemDesc& it = itab[k];
         const int o = it.o;
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
@@ -918,9 +922,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             x0[u] = a; hit1[u] = (b == t); lo_[u] = lo;
         }
 
+        if (dbt) { asm volatile("" : "+v"(x0[0]), "+v"(lo_[0])); dbg[97] = clock64(); }
         // ---- stage Q
         sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients + staged rows of item k published
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        if (dbt) dbg[98] = clock64();
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
         const double* rows_l = reinterpret_cast<const double*>(tbl);          // [NT][12]: VA row | span | mins
         const float* b2l = reinterpret_cast<const float*>(tbl + P.tab_off_b2);
@@ -937,6 +943,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
         double cc[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) cc[j] = crow[j];
+        if (dbt) { asm volatile("" : "+v"(cc[0]), "+v"(cc[9])); dbg[99] = clock64(); }
         double chi = 0.0, gp = 0.0;
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
@@ -963,11 +970,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
                 }
             }
         }
+        if (dbt) { asm volatile("" : "+v"(chi)); dbg[100] = clock64(); }
         chi = group_sum(chi, G);
         if (it.has_ul) gp = group_sum(gp, G);
+        if (dbt) { asm volatile("" : "+v"(chi)); dbg[101] = clock64(); }
         if (gi == G - 16) {
-            chi_tot[k * TS + s] = chi;
-            gp_tot[k * TS + s] = gp;
+            chi_tot[o * TS + s] = chi;       // slot of the observed filter (= item order of the reference sum)
+            gp_tot[o * TS + s] = gp;
             if (chi != chi) bad[s] = 1;
             if (chi_parts != nullptr && tile0 + s < B) {
                 chi_parts[(long)o * B + tile0 + s] = (sc[S_BAD] != 0.0) ? dnan() : chi;
@@ -975,10 +984,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             }
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
+        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += TS * itab[q].G / 64; if (tt < 24) dbg[104 + tt] = clock64(); }
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
     };
 
-    if (all_fast) {
+    if constexpr (FAST) {
         sync_wait(sync + W + 1, NVW, P.watchdog, 400);   // prologue data of every likelihood wave in LDS
         // Tasks (item-major) are claimed from one LDS counter: likelihood waves from the start, MFMA-role
         // waves once their record stream is finished.  Any wave may compute any task (results go to
@@ -1001,6 +1011,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), 3) void em_logl(
             }
             int t = __builtin_amdgcn_readfirstlane(tv);
 #endif
+            if (dbg && blockIdx.x == 0 && lane == 0 && t < 24) { dbg[16 + t] = clock64(); dbg[40 + t] = wave; }
             if (t >= ntot) break;
             if (++claims > ntot + 64) {          // cannot happen; fail loudly instead of spinning
                 if (lane == 0) { P.watchdog[0] = 1; P.watchdog[1] = 900; P.watchdog[2] = (int)blockIdx.x * 64 + wave; P.watchdog[3] = t; }

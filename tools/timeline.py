@@ -14,7 +14,7 @@ th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
 for _ in range(3):
     eng.loglike(th)
 st = eng.debug_timeline(th)
-t0 = min(x for x in st if x > 0)
+t0 = min(x for x in st if x > 1000)
 W = 6
 print("MFMA role: item  start  end  dur")
 for k in range(W):
@@ -24,4 +24,10 @@ for k in range(1, W + 1):
     print(f"   B({k-1}) {st[64+2*k]-t0:8d} {st[64+2*k+1]-t0:8d}  {st[64+2*k+1]-st[64+2*k]:7d}")
 eng.close()
 
+print("last item, task c=0: P", st[97]-st[96], "| wait", st[98]-st[97], "| coef", st[99]-st[98], "| rows+FMA+term", st[100]-st[99], "| group_sum", st[101]-st[100])
 print("inside B(W-1): datum loads", st[97]-st[96], "| coef", st[98]-st[97], "| est", st[99]-st[98], "| terms", st[100]-st[99], "| reduce+write", st[101]-st[100], "| tail", st[102]-st[101], "| total", st[102]-st[96])
+
+print("tasks: index wave claim -> done (cycles rel. to t0)")
+for i in range(24):
+    if st[16 + i] > 0:
+        print(f"   task {i:2d} (item {i//4}) wave {st[40+i]:2d}  claim {st[16+i]-t0:7d}  done {st[104+i]-t0:7d}  dur {st[104+i]-st[16+i]:6d}")
