@@ -178,3 +178,38 @@ def weights_digest(svd):
             a = np.asarray(svd[f][k], dtype=np.float64)
             acc += float(np.sum(a * np.cos(np.arange(a.size).reshape(a.shape) % 97)))
     return acc
+
+
+# ---------------------------------------------------------------------------------------
+# Shape cases without golden vectors: they exercise geometry branches of the HIP path
+# (lanes per sample, ring wrap-around, KP = 2) and are checked against the oracle only.
+# ---------------------------------------------------------------------------------------
+def case_fast_many_filters():
+    """10 filters, 1 ... 128 epochs each: every lanes-per-sample variant of the fast path
+    (<= 32, <= 64, <= 128 points) and more work items than ring slots."""
+    filters = [f"f{i}" for i in range(10)]
+    counts = dict(zip(filters, [13, 40, 70, 100, 16, 33, 64, 128, 1, 20]))
+    return _base(seed=9234, filters=filters, counts=counts, batch=48, upper_limit_filter="f3")
+
+
+def case_fast_np6():
+    """Six model parameters (two layer-1 MFMA k-steps) on the fast path."""
+    filters = ["u", "g", "r"]
+    names = ["luminosity_distance", "inclination_EM", "timeshift", "log10_mej_dyn", "vej_dyn",
+             "Yedyn", "log10_mej_wind", "vej_wind"]
+    return _base(seed=9334, model="Bu2022Ye", filters=filters, counts=30, batch=40, names=names,
+                 upper_limit_filter="g")
+
+
+def case_generic_too_many_points():
+    """One filter with more than 128 epochs next to small ones: the whole launch takes the generic path."""
+    filters = ["a", "b", "c"]
+    counts = dict(a=12, b=150, c=20)
+    return _base(seed=9434, filters=filters, counts=counts, batch=24, upper_limit_filter="b")
+
+
+SHAPE_CASES = {
+    "fast_many_filters": case_fast_many_filters,
+    "fast_np6": case_fast_np6,
+    "generic_too_many_points": case_generic_too_many_points,
+}

@@ -151,3 +151,37 @@ def test_full_size_properties(torch_cuda):
     want = orc.log_likelihood_batch(olik, case["names"], theta[rows])
     assert rel_err(a[rows], want).max() <= LOGL_RTOL
     eng.close()
+
+
+@pytest.mark.parametrize("name", list(cases.SHAPE_CASES))
+@pytest.mark.parametrize("tile", ["auto", "32"])
+def test_shape_cases_match_oracle(name, tile, torch_cuda, monkeypatch):
+    """Geometry branches of em_logl (lanes per sample, ring wrap-around, KP = 2, generic fallback,
+    16- and 32-sample tiles) against the CPU oracle on the same seeded inputs."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    case = cases.SHAPE_CASES[name]()
+    if tile == "32":
+        monkeypatch.setenv("NMMA_EM_TILE", "2")       # read at create: 32-sample tiles for any batch
+    eng = engine_from_case(case)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    olik = oracle_from_case(case, use_scipy=False)
+    want = orc.log_likelihood_batch(olik, case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor)
+    err = rel_err(got[~floor], want[~floor])
+    print(f"{name}/{tile}: max rel err {err.max() if err.size else 0:.3e} over {err.size} finite rows")
+    assert err.size > 0 and err.max() <= LOGL_RTOL
+    eng.close()
+
+
+def test_check_reports_clean_handle(torch_cuda):
+    """nmma_em_check synchronises and finds no watchdog trip after ordinary launches."""
+    torch = torch_cuda
+    case = cases.case_small_hidden()
+    eng = engine_from_case(case)
+    eng.loglike(torch.as_tensor(case["theta"], device="cuda:0"))
+    eng.check()
+    eng.close()
