@@ -1,22 +1,24 @@
 // em_kernels.hip -- gfx950 kernels of the batched EM light-curve log-likelihood.
 //
-// em_logl<R, KP>  (the hot path: nmma_em_loglike)
-//   One 8-wave workgroup owns a tile of TS = 16*R parameter vectors and walks the work
-//   items (observed filter, source model filter) of the likelihood.  The waves are
-//   specialised, one of each kind per SIMD:
-//     waves 0-3  "MFMA waves": the surrogate MLP of item k+1
+// em_logl<R, KP, NMW, NVW, FAST>  (the hot path: nmma_em_loglike)
+//   One workgroup owns a tile of TS = 16*R parameter vectors and walks the work items
+//   (observed filter, source model filter) of the likelihood.  The waves are specialised:
+//     NMW "MFMA waves": the surrogate MLP, one continuous stream of weight records over all items
 //                x = (theta - pmin)/(pmax - pmin)          lightcurve_generation.py:193-194
 //                c = Dense(relu)(x) -> Dense  (fp32)       lightcurve_generation.py:198
-//     waves 4-7  "VALU waves": everything downstream of the coefficients of item k (fp64)
+//     NVW "likelihood waves": everything downstream of the coefficients (fp64)
 //                mag = (VA[:, :NC] @ c)*(maxs-mins)+mins   lightcurve_generation.py:214-216
 //                stage-1 lerp onto sample_times, +inf out  lightcurve_generation.py:177
 //                t_obs = t*(1+z)+timeshift, app = mag+ext+distmod-2.5log10(1+z)  model.py:374-404
 //                stage-2 lerp onto the data epochs         em_likelihood.py:313-335
 //                truncated-Gaussian / logsf terms, sum     em_likelihood.py:224-256, :337-352
-//   so the f32 MFMA pipe and the f64 VALU pipe of every SIMD work concurrently; the two
-//   roles meet at one workgroup barrier per item (coefficients handed over in LDS,
-//   double-buffered).  The final sum over filters and the floor (core/base.py:82, :180)
-//   happen in the same launch.
+//   so the f32 MFMA pipe and the f64 VALU pipe of every SIMD work concurrently.  The roles hand
+//   items over through LDS counters (no workgroup barrier after the first one): partial sums and,
+//   in FAST mode, the item's basis rows travel through a ring of LDS slots; the likelihood waves
+//   claim (item, sample group) tasks from a shared counter and the MFMA waves join them when their
+//   stream is done.  The final sum over filters and the floor (core/base.py:82, :180) happen in the
+//   same launch.  FAST = every item qualifies for the straight-line task (see EmDev::all_fast);
+//   otherwise the generic item phase with every reference branch runs in lock-step over the items.
 //
 //   MLP on the matrix cores: both Dense layers chained without a transpose -- layer 1
 //   produces H^T[hidden 16 x sample 16] whose accumulator registers ARE the B operands of
