@@ -199,13 +199,19 @@ __device__ __forceinline__ void mlp_slices(gcf32p rec, const float (&xB)[R][KP],
 // Role hand-off of em_logl through three LDS counters instead of workgroup barriers, so the
 // two roles never wait for each other unless the data dependency is real:
 //   sync[k]         += 1 by every MFMA wave once its partial sums of item k are in LDS;
-//   sync[W + 1 + j] += 1 by every likelihood wave after its phase j - 1 (j = 0: prologue, j = k + 1: item k).
+//   sync[W + 1 + j] += 1 by every likelihood wave after its phase j - 1 (j = 0: prologue, j = k + 1: item k;
+//                   fast mode: once per finished task of item k);
+//   sync[2W + 2], sync[2W + 3]: prologue staging done / next task to claim;  sync[2W + 4 + k]: rows of item k staged.
 // One counter per item/phase (never reset): waves of a role may run ahead of each other, so a
 // running total could be reached by early signals of the next item.
 // LDS instructions of one wave execute in order, so "data writes, then counter add" by the
 // producer and "counter read, then data reads" by the consumer need no further fence.
 // ---------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) int* lds_ip;
+// Debug stamps and watchdog words are written through GLOBAL-address-space pointers: a flat store anywhere in
+// the record loop nest makes the compiler guard every ring access with s_waitcnt vmcnt(0).
+typedef __attribute__((address_space(1))) int* g_ip;
+typedef __attribute__((address_space(1))) long long* g_llp;
 __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lds_ip)cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -213,14 +219,15 @@ __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
 // A wait that does not complete within ~2^20 polls (tens of milliseconds; a healthy launch needs
 // microseconds) records where it was stuck in the handle's watchdog words and gives up, so that a
 // protocol bug surfaces as an error code from the C ABI instead of a hung GPU.
-__device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog = nullptr, const int code = 0) {
+__device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog_generic = nullptr, const int code = 0) {
+    g_ip watchdog = (g_ip)(uintptr_t)watchdog_generic;
     // Every VALU instruction of a polling wave takes an issue slot from the MFMA waves of its SIMD (a poll is
     // v_mov + ds_read + v_cmp): sleep ~400 cycles between polls so that waiting costs next to nothing.
     int spins = 0;
     while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
         __builtin_amdgcn_s_sleep(6);
         if (++spins > (1 << 18)) {
-            if (watchdog != nullptr && (threadIdx.x & 63) == 0) {
+            if (watchdog_generic != nullptr && (threadIdx.x & 63) == 0) {
                 watchdog[0] = 1; watchdog[1] = code; watchdog[2] = (int)blockIdx.x * 64 + (int)(threadIdx.x >> 6);
                 watchdog[3] = __hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 65536 + target;
             }
@@ -238,7 +245,9 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 // L2 latency is paid once per launch instead of once per item.  Layer-1 pre-activations
 // run one record ahead and therefore switch to the next item's normalised inputs on the
 // last record of an item.  Partial sums of item k go to buffer k % NBUF of `part`; the role
-// only waits for the likelihood role when that buffer still holds item k - NBUF.
+// only waits for the likelihood role when that buffer still holds item k - NBUF.  The role issues
+// nothing but buffer loads into VGPRs: an LDS-DMA (or any flat load) inside this loop makes the compiler
+// guard every ring access with s_waitcnt vmcnt(0), i.e. one exposed L2 round trip per 8 records.
 // ---------------------------------------------------------------------------------------
 // (the ring depth NBUF is a launch parameter, LdsW::nbuf: what fits in LDS, at most 4)
 // prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
@@ -246,8 +255,9 @@ constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 
 template <int R, int KP, int PF, int NMW, int NVW, bool FAST>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
-                                          float* __restrict__ part, unsigned char* tabl, const int NBUF, int* sync,
-                                          long long* __restrict__ dbg) {
+                                          float* __restrict__ part, const int NBUF, int* sync,
+                                          long long* __restrict__ dbg_generic) {
+    g_llp dbg = (g_llp)(uintptr_t)dbg_generic;
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
     constexpr int NSL = NSLICE / NMW;
@@ -257,6 +267,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     const int CPS = HBS / PF;                      // chunks per slice
     const int CPI = NSL * CPS;                     // chunks per item (this wave)
     gci32p items = as_global(P.items);
+    gci32p idesc = as_global(reinterpret_cast<const int*>(P.item_desc));   // word 4 of a descriptor = G
     gcf64p pmin = as_global(P.pmin), pinv = as_global(P.pinv);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(uintptr_t)P.wrec, 0, P.wrec_bytes, 0x00020000);
@@ -293,8 +304,15 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     int base = item_base(0);
     f32x4 ra2[PF], rbias[PF];
     float ra1[PF][KP];
+    // The ring holds records g .. g+PF-2 when record g is consumed; the step that consumes slot g % PF
+    // refills the slot consumed ONE STEP EARLIER with record g+PF-1.  Every reader of that slot has been
+    // issued before the load, so the load writes the slot's own registers (loading into the slot being
+    // consumed makes hipcc double-buffer the whole ring: 16 v_mov_b64 and an s_waitcnt vmcnt(0) per chunk).
+    ra2[PF - 1] = f32x4{0, 0, 0, 0}; rbias[PF - 1] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int kp = 0; kp < KP; ++kp) ra1[PF - 1][kp] = 0.f;
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
         ra2[u] = ld4(off_a2, base + u * RECB);
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, base + u * RECB);
@@ -328,11 +346,11 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         bool slot_free = k < NBUF;
         auto wait_slot = [&]() {
             if (!slot_free) {
-                sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? TS * P.item_desc[k - NBUF].G / 64 : NVW, P.watchdog, 100 + k);
+                sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? TS * idesc[(k - NBUF) * ITEM_WORDS + 4] / 64 : NVW, P.watchdog, 100 + k);
                 slot_free = true;
             }
         };
-        int soff = base + PF * RECB;              // record fetched by the next refill
+        int soff = base + (PF - 1) * RECB;        // record fetched by the next refill (PF-1 of this item are in the ring)
 #pragma unroll 1
         for (int sl = 0; sl < NSL; ++sl) {
             f32x4 acc[R][2];
@@ -341,21 +359,6 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
 #pragma unroll 1
             for (int c = 0; c < CPS; ++c) {
                 const bool last_chunk = (sl == NSL - 1) && (c == CPS - 1);
-                if (last_chunk) {
-                    soff = nbase;                 // refills now fetch the first PF records of the next item
-                    if constexpr (FAST) {
-                        // ring slot k % NBUF: wait until item k - NBUF is consumed, then stage this item's basis
-                        // rows (LDS-DMA, no registers); they land during the last PF records of the item
-                        wait_slot();
-                        typedef __attribute__((address_space(3))) unsigned char* lds_bp;
-                        typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
-                        const int m = items[4 * k + 2];
-                        gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)m * P.tab_bytes);
-                        lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
-                        for (int q = wave; q * 1024 < P.tab_fast_bytes; q += NMW)
-                            __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
-                    }
-                }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int nu = (u + 1) % PF;
@@ -380,11 +383,15 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                         }
                     }
                     const f32x4 a2 = ra2[u];
+                    // refill the slot consumed one step earlier; in the last chunk of an item step 0 still
+                    // fetches the item's last record, steps 1.. fetch the first PF-1 records of the next item
+                    const int pu = (u + PF - 1) % PF;
+                    if (u == 1 && last_chunk) soff = nbase;
 #ifndef NMMA_DBG_NOLOAD
-                    ra2[u] = ld4(off_a2, soff);
+                    ra2[pu] = ld4(off_a2, soff);
 #pragma unroll
-                    for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, soff);
-                    rbias[u] = ld4(off_b, soff);
+                    for (int kp = 0; kp < KP; ++kp) ra1[pu][kp] = ld1(off_a1 + kp * 256, soff);
+                    rbias[pu] = ld4(off_b, soff);
 #endif
                     soff += RECB;
 #pragma unroll
@@ -396,10 +403,10 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     __builtin_amdgcn_sched_group_barrier(0x002, 4 * R, 0);
 #endif
                     __builtin_amdgcn_sched_group_barrier(0x008, R * KP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * R, 0);
 #ifndef NMMA_DBG_NOLOAD
                     __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
 #endif
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * R, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -413,8 +420,6 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     pk[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = s[r];
             }
         }
-        // every load older than the PF records in flight has landed -- including this item's staged rows
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * (2 + KP)) : "memory");
         sync_signal(sync + k, lane);      // item k published
         base = nbase;
 #pragma unroll
@@ -504,7 +509,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + (2 * n_items + 4) * 4);
+    L.sync = off; off = align16(off + (3 * n_items + 4) * 4);
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + TS * 4);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
-    for (int j = tid; j < 2 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
+    for (int j = tid; j < 3 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             case 3: __builtin_amdgcn_s_setprio(3); break;
             default: break;
         }
-        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, tabl, L.nbuf, sync, dbg);
+        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg);
         if (!FAST || !P.helpers) return;
         // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
     }
@@ -884,6 +889,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         if (dbt) dbg[96] = clock64();
         const ItemDesc& it = itab[k];
         const int o = it.o;
+        if (c == 0) {
+            // The wave that owns the item's first task stages its basis rows [VA | span | mins | b2] into ring slot
+            // k % NBUF by LDS-DMA (no registers).  Tasks are claimed well before their item is published, so the
+            // copy lands while this wave does stage P and waits for the MLP.
+            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), TS * itab[k - NBUF].G / 64, P.watchdog, 800 + k);
+            typedef __attribute__((address_space(3))) unsigned char* lds_bp;
+            typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+            gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
+            lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
+            for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
+                __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
+        }
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
         const int G = it.G, d0 = it.d0, nf = it.nf;
@@ -926,7 +943,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 
         if (dbt) { asm volatile("" : "+v"(x0[0]), "+v"(lo_[0])); dbg[97] = clock64(); }
         // ---- stage Q
-        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients + staged rows of item k published
+        if (c == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sync_signal(sync + 2 * W + 4 + k, lane);     // rows of item k staged
+        }
+        sync_wait(sync + 2 * W + 4 + k, 1, P.watchdog, 350 + k);
+        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
         if (dbt) dbg[98] = clock64();
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
