@@ -512,7 +512,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.sync = off; off = align16(off + (3 * n_items + 4) * 4);
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
-    L.bad = off;  off = align16(off + TS * 4);
+    L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
     L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);             // per wave (any role): 4 slots x 16 coefficients           // per VALU wave: 4 slots x 16 coefficients
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
     L.nf_max = nf_avg_max;
@@ -622,20 +622,48 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 for (int j = vt; j < P.n_cosmo; j += NV) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
             sync_signal(sync + 2 * W + 2, lane);
         }
-        if (vt < TS) {
+        int* badp = bad + TS;        // [4][TS]: non-finite input seen by prologue part 0..3 for sample s
+        if (staged) {
+            // four waves share the per-sample chain (a divergent split inside one wave would execute all parts
+            // one after the other): 0 = redshift branch (grid interpolation, log10), 1 = distance modulus, time
+            // shift, E(B-V), 2 = model parameters, 3 = systematics parameters.  Lane = sample.
+            if (vwave < 4 && lane < TS) {
+                sync_wait(sync + 2 * W + 2, NVW, P.watchdog, 200);
+                const double* row = thl + lane * (int)ld;
+                double* sc = scal + lane * 8;
+                double chk = 0.0;
+                if (vwave == 0) {
+                    const double d_l = apply_slot(P.lumdist, row);
+                    double z = 0.0;
+                    if (P.redshift_mode == NMMA_Z_SLOT) z = apply_slot(P.redshift, row);
+                    else if (P.redshift_mode == NMMA_Z_GRID) z = interp_np(d_l, dgl, zgl, P.n_cosmo, zgl[0], zgl[P.n_cosmo - 1]);
+                    sc[S_ZP1] = 1 + z;
+                    sc[S_IZP1] = 1.0 / (1 + z);
+                    sc[S_RC] = redshift_correction(z);
+                    chk = d_l + z;
+                } else if (vwave == 1) {
+                    const double d_l = apply_slot(P.lumdist, row);
+                    sc[S_DMOD] = distance_modulus(d_l);
+                    sc[S_TS] = apply_slot(P.timeshift, row);
+                    sc[S_EBV] = P.has_ebv ? apply_slot(P.ebv, row) : 0.0;
+                    chk = sc[S_TS] + sc[S_EBV];
+                } else if (vwave == 2) {
+                    for (int p = 0; p < P.NP; ++p) chk += apply_slot(P.model_param[p], row);
+                } else {
+                    for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+                    bad[lane] = 0;
+                }
+                badp[vwave * TS + lane] = (chk - chk == 0.0) ? 0 : 1;
+            }
+        } else if (vt < TS) {
             long b = tile0 + vt;
             if (b >= B) b = B - 1;
             const double* row = theta + b * ld;
             double chk;
-            if (staged) {
-                sync_wait(sync + 2 * W + 2, NVW, P.watchdog, 200);
-                row = thl + vt * (int)ld;
-                sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk, dgl, zgl);
-            } else {
-                sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
-            }
+            sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
             for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
-            scal[vt * 8 + S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+            badp[vt] = (chk - chk == 0.0) ? 0 : 1;
+            badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
         }
         for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
@@ -668,6 +696,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         sync_signal(sync + W + 1, lane);     // phase "prologue" of this wave done
     }
 
+    auto sample_bad = [&](const int s_) -> bool {      // a non-finite input of sample s_ (any prologue part)
+        const int* badp = bad + TS;
+        return (badp[s_] | badp[TS + s_] | badp[2 * TS + s_] | badp[3 * TS + s_]) != 0;
+    };
     const bool uniform = P.st_uniform != 0;
     const double st0 = P.st0, inv_dt = P.st_inv_dt;
     gcf64p g_dt = as_global(P.dt), g_dm = as_global(P.dm), g_dsig = as_global(P.dsig);
@@ -862,7 +894,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 gp_tot[k * TS + s] = gp;
                 if (chi != chi) bad[s] = 1;
                 if (chi_parts != nullptr && tile0 + s < B) {
-                    chi_parts[(long)o * B + tile0 + s] = (scal[s * 8 + S_BAD] != 0.0) ? dnan() : chi;
+                    chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
                     gp_parts[(long)o * B + tile0 + s] = gp;
                 }
             }
@@ -1003,7 +1035,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             gp_tot[o * TS + s] = gp;
             if (chi != chi) bad[s] = 1;
             if (chi_parts != nullptr && tile0 + s < B) {
-                chi_parts[(long)o * B + tile0 + s] = (sc[S_BAD] != 0.0) ? dnan() : chi;
+                chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
                 gp_parts[(long)o * B + tile0 + s] = gp;
             }
         }
@@ -1068,7 +1100,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
             double tot = c + g;
-            const bool isbad = always_floor != 0 || bad[vt] != 0 || scal[vt * 8 + S_BAD] != 0.0;
+            const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt);
             if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
             out[tile0 + vt] = tot;
         }
