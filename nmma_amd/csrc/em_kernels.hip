@@ -935,10 +935,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
-        const int G = it.G, d0 = it.d0, nf = it.nf;
+        const int G = it.G, d0 = it.d0, nf = it.nf;         // G = 16, 32 or 64 (a power of two: shifts, no division)
         const double e_const = it.e_const;
-        const int g = lane / G, gi = lane - g * G;
-        const int s = c * (64 / G) + g;                     // < TS: TS * G is a multiple of 64
+        const int lgG = (G == 16) ? 4 : (G == 32 ? 5 : 6);
+        const int g = lane >> lgG, gi = lane & (G - 1);
+        const int s = (c << (6 - lgG)) + g;                 // < TS: TS * G is a multiple of 64
         const double st0 = P.st0, inv_dt = P.st_inv_dt;
         const double* sc = scal + s * 8;
         const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
