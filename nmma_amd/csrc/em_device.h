@@ -78,6 +78,8 @@ struct EmDev {
     //   [rows NT x RS f64 (VA row | span | mins, RS = NC+2 rounded up to even) | s1_dx NS f64 | s1_off NS f64 |
     //    s1_idx NS i32 | b2 16 f32], 1-KiB padded
     const unsigned char* tab;
+    const int32_t* task_map[2];   // fast mode, per tile size R = 1, 2: task index -> (item << 8 | sample chunk)
+    int32_t n_tasks[2];
     int32_t n_data;           // total number of photometry points (all observed filters)
     int32_t tab_fast_bytes;   // 1-KiB-rounded prefix [rows | b2] staged per item by em_logl's fast mode
     int32_t tab_bytes, tab_row_stride, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;

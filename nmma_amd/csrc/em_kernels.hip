@@ -252,6 +252,10 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 // (the ring depth NBUF is a launch parameter, LdsW::nbuf: what fits in LDS, at most 4)
 // prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
 constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
+// fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
+constexpr int TMAP_MAX = 512;
+// fast mode: most photometry points (all filters) staged in LDS as [t | m | 1/sigma | log sigma]
+constexpr int DAT_MAX = 512;
 
 template <int R, int KP, int PF, int NMW, int NVW, bool FAST>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
@@ -484,13 +488,13 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, total;
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
 
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast) {
+                                     int all_fast, int n_data) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -511,6 +515,8 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     L.gp = off;   off = align16(off + n_items * TS * 8);
     L.sync = off; off = align16(off + (3 * n_items + 4) * 4);
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
+    L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
+    L.dat = off;   off = align16(off + ((all_fast && n_data <= DAT_MAX) ? 4 * n_data * 8 : 0));
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
     L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);             // per wave (any role): 4 slots x 16 coefficients           // per VALU wave: 4 slots x 16 coefficients
@@ -668,6 +674,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
         for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
+        if constexpr (FAST) {
+            int* tmap = reinterpret_cast<int*>(smem + L.tmap);
+            gci32p src = as_global(P.task_map[R - 1]);
+            for (int j = vt; j < P.n_tasks[R - 1] && j < TMAP_MAX; j += NV) tmap[j] = src[j];
+            if (P.n_data <= DAT_MAX) {
+                double* dat = reinterpret_cast<double*>(smem + L.dat);
+                const int nd = P.n_data;
+                gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
+                for (int j = vt; j < nd; j += NV) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
+            }
+        }
         {
             gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
             int* dst = reinterpret_cast<int*>(smem + L.itab);
@@ -916,6 +933,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     //     lerp, likelihood term, DPP group sum.
     // Only Q is on the critical path behind the MFMA role, and it contains no global-memory latency.
     // ---------------------------------------------------------------------------------
+    const int nd_l = P.n_data;
+    const double* dat_l = (FAST && nd_l <= DAT_MAX) ? reinterpret_cast<const double*>(smem + L.dat) : nullptr;
     auto fast_task = [&](const int k, const int c) {
         const bool dbt = dbg && blockIdx.x == 0 && lane == 0 && c == 0 && k == W - 1;
         if (dbt) dbg[96] = clock64();
@@ -924,7 +943,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         if (c == 0) {
             // The wave that owns the item's first task stages its basis rows [VA | span | mins | b2] into ring slot
             // k % NBUF by LDS-DMA (no registers).  Tasks are claimed well before their item is published, so the
-            // copy lands while this wave does stage P and waits for the MLP.
+            // copy lands while this wave does stage P and waits for the MLP.  (Sharing the copy among the item's
+            // tasks would make them wait for each other: with more tasks per item than free waves that deadlocks.)
             if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), TS * itab[k - NBUF].G / 64, P.watchdog, 800 + k);
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
             typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
@@ -956,7 +976,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int u = 0; u < NDL; ++u) {
             const int dd = gi + u * G;
             const int di = d0 + (dd < nf ? dd : 0);
-            c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di];
+            if (dat_l != nullptr) { c_t[u] = dat_l[di]; c_m[u] = dat_l[nd_l + di]; c_is[u] = dat_l[2 * nd_l + di]; c_ls[u] = dat_l[3 * nd_l + di]; }
+            else { c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di]; }
         }
 #pragma unroll
         for (int u = 0; u < NDL; ++u) {
@@ -1051,8 +1072,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // waves once their record stream is finished.  Any wave may compute any task (results go to
         // per-(item, sample) slots), so the claim order does not affect the values.
         // (task counts are made explicitly wave-uniform: the claim loop must not be compiled as a divergent loop)
-        int ntot = 0;
-        for (int k = 0; k < W; ++k) ntot += __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64);
+        const int ntot = P.n_tasks[R - 1];
+        const int* tmap = reinterpret_cast<const int*>(smem + L.tmap);
         int tstat = vwave; (void)tstat;
         int claims = 0;
         for (;;) {
@@ -1075,7 +1096,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 break;
             }
             int k = 0;
-            for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64); if (t < n) break; t -= n; }
+            if (ntot <= TMAP_MAX) {              // one LDS read instead of a serial scan over the item list
+                const int e = __builtin_amdgcn_readfirstlane(tmap[t]);
+                k = e >> 8; t = e & 255;
+            } else {
+                for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64); if (t < n) break; t -= n; }
+            }
 #ifndef NMMA_DBG_NOVALU
             fast_task(k, t);
 #else
