@@ -74,8 +74,6 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 // Hidden units are always split into NSLICE partial sums added in slice order, so the
 // fp32 result does not depend on the launch geometry (R, WPB) chosen for a batch size.
 constexpr int NSLICE = 8;
-// most likelihood-role waves of an em_logl workgroup (template NVW; next to its NMW MFMA-role waves)
-constexpr int NVW_MAX = 8;
 // zero records appended to every model filter's weight stream (deepest prefetch ring + 1)
 constexpr int NPAD_REC = 9;
 // row stride (floats) of the LDS partial-sum tiles: 16 coefficients + 1 pad (bank spread)
@@ -269,7 +267,6 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     const int W = P.n_items, NP = P.NP;
     const int HBS = P.HB / NSLICE;
     const int CPS = HBS / PF;                      // chunks per slice
-    const int CPI = NSL * CPS;                     // chunks per item (this wave)
     gci32p items = as_global(P.items);
     gci32p idesc = as_global(reinterpret_cast<const int*>(P.item_desc));   // word 4 of a descriptor = G
     gcf64p pmin = as_global(P.pmin), pinv = as_global(P.pinv);
@@ -538,7 +535,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     long long* __restrict__ dbg) {
     constexpr int TS = 16 * R;
     constexpr int PF = (R == 1) ? 8 : 4;
-    constexpr int RECF = rec_floats(KP);
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     const EmDev& P = *Pp;
@@ -728,7 +724,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const int o = it.o, ks = it.ks, nsrc = it.nsrc;
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
-        const bool identity = it.identity != 0, same_grid = it.same_grid != 0;
+        const bool identity = it.identity != 0;
         const double ebvc = it.ebvc;
         const int G = it.G;                       // lanes per sample, power of two in [16, 64]
         const int gpb = NV / G;
