@@ -69,7 +69,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("NMMA_BENCH_FORCE_DIST") == "1"   # (1-rank exercise of the exchange path)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -85,11 +86,13 @@ def main():
     thetas = [torch.as_tensor(syn.draw_theta(1000 + 97 * rank + i, B, case["names"])[1], device=dev)
               for i in range(N_THETA_SETS)]
     out = torch.empty(B, dtype=torch.float64, device=dev)
-    gathered = torch.empty(world * B, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, dtype=torch.float64, device=dev) if use_dist else None
 
     def step(i):
         eng.loglike(thetas[i % N_THETA_SETS], out=out)
-        if world > 1:
+        if use_dist:
+            # blocking form on purpose: an overlapped variant (second stream + events, or async_op) costs ~60 us of
+            # host work per step in torch.distributed -- more than the 32 us kernel it would hide the collective behind
             dist.all_gather_into_tensor(gathered, out)
 
     for i in range(args.warmup):
@@ -151,7 +154,7 @@ def main():
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if dist is not None and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
