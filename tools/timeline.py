@@ -19,13 +19,12 @@ W = 6
 print("MFMA role: item  start  end  dur")
 for k in range(W):
     print(f"   A({k}) {st[2*k]-t0:8d} {st[2*k+1]-t0:8d}  {st[2*k+1]-st[2*k]:7d}")
-print("VALU role: prologue", st[64]-t0, st[65]-t0, st[65]-st[64])
+print("likelihood role: prologue", st[64]-t0, st[65]-t0, st[65]-st[64])
 for k in range(1, W + 1):
-    print(f"   B({k-1}) {st[64+2*k]-t0:8d} {st[64+2*k+1]-t0:8d}  {st[64+2*k+1]-st[64+2*k]:7d}")
+    print(f"   Q({k-1}) {st[64+2*k]-t0:8d} {st[64+2*k+1]-t0:8d}  {st[64+2*k+1]-st[64+2*k]:7d}   (stage Q of the item's first task)")
 eng.close()
 
 print("last item, task c=0: P", st[97]-st[96], "| wait", st[98]-st[97], "| coef", st[99]-st[98], "| rows+FMA+term", st[100]-st[99], "| group_sum", st[101]-st[100])
-print("inside B(W-1): datum loads", st[97]-st[96], "| coef", st[98]-st[97], "| est", st[99]-st[98], "| terms", st[100]-st[99], "| reduce+write", st[101]-st[100], "| tail", st[102]-st[101], "| total", st[102]-st[96])
 
 print("tasks: index wave claim -> done (cycles rel. to t0)")
 for i in range(24):
