@@ -208,8 +208,22 @@ def case_generic_too_many_points():
     return _base(seed=9434, filters=filters, counts=counts, batch=24, upper_limit_filter="b")
 
 
+def case_fast_single_filter():
+    """One observed filter: a ring of one slot, a single work item."""
+    return _base(seed=9534, filters=["r"], counts=dict(r=17), batch=20, upper_limit_filter="r")
+
+
+def case_fast_wide():
+    """20 filters x 70 epochs (64 lanes per sample): with 32-sample tiles the task list (640 entries)
+    exceeds the LDS task map and takes the scan fallback."""
+    filters = [f"w{i:02d}" for i in range(20)]
+    return _base(seed=9634, filters=filters, counts=70, batch=40, upper_limit_filter="w07")
+
+
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
     "generic_too_many_points": case_generic_too_many_points,
+    "fast_single_filter": case_fast_single_filter,
+    "fast_wide": case_fast_wide,
 }
