@@ -963,33 +963,38 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const double izdt = izp1 * inv_dt;
         const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
 
-        // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid
+        // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid.
+        // A lane owns data gi, gi + G, gi + 2G, ...; they are processed in pairs (two slots in registers):
+        // the first pair before the item is published, further pairs (more than 2 G points per filter) after it.
         constexpr int NDL = 2;
         double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL];
         bool inside[NDL], hit1[NDL];
         int lo_[NDL];
+        auto stage_p = [&](const int u0) {
 #pragma unroll
-        for (int u = 0; u < NDL; ++u) {
-            const int dd = gi + u * G;
-            const int di = d0 + (dd < nf ? dd : 0);
-            if (dat_l != nullptr) { c_t[u] = dat_l[di]; c_m[u] = dat_l[nd_l + di]; c_is[u] = dat_l[2 * nd_l + di]; c_ls[u] = dat_l[3 * nd_l + di]; }
-            else { c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di]; }
-        }
-#pragma unroll
-        for (int u = 0; u < NDL; ++u) {
-            if (u * G >= nf) { inside[u] = false; hit1[u] = false; x0[u] = 0; lo_[u] = 0; continue; }   // uniform: slot unused by this item
-            const double t = c_t[u];
-            inside[u] = (jhi > jlo) && t >= t_lo && t <= t_hi;
-            int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
-            lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
-            if (lo < 0) lo = 0;
-            double a = stl[lo] * zp1 + tsh, b = stl[lo + 1] * zp1 + tsh;
-            for (int it2 = 0; it2 < 4 && inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1)); ++it2) {   // exact re-check (the guess is off by at most one)
-                lo += (a > t) ? -1 : 1;
-                a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
+            for (int u = 0; u < NDL; ++u) {
+                const int dd = gi + (u0 + u) * G;
+                const int di = d0 + (dd < nf ? dd : 0);
+                if (dat_l != nullptr) { c_t[u] = dat_l[di]; c_m[u] = dat_l[nd_l + di]; c_is[u] = dat_l[2 * nd_l + di]; c_ls[u] = dat_l[3 * nd_l + di]; }
+                else { c_t[u] = g_dt[di]; c_m[u] = g_dm[di]; c_is[u] = g_invsig[di]; c_ls[u] = g_logsig[di]; }
             }
-            x0[u] = a; hit1[u] = (b == t); lo_[u] = lo;
-        }
+#pragma unroll
+            for (int u = 0; u < NDL; ++u) {
+                if ((u0 + u) * G >= nf) { inside[u] = false; hit1[u] = false; x0[u] = 0; lo_[u] = 0; continue; }   // uniform: slot unused by this item
+                const double t = c_t[u];
+                inside[u] = (jhi > jlo) && t >= t_lo && t <= t_hi;
+                int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
+                if (lo < 0) lo = 0;
+                double a = stl[lo] * zp1 + tsh, b = stl[lo + 1] * zp1 + tsh;
+                for (int it2 = 0; it2 < 4 && inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1)); ++it2) {   // exact re-check (the guess is off by at most one)
+                    lo += (a > t) ? -1 : 1;
+                    a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
+                }
+                x0[u] = a; hit1[u] = (b == t); lo_[u] = lo;
+            }
+        };
+        stage_p(0);
 
         if (dbt) { asm volatile("" : "+v"(x0[0]), "+v"(lo_[0])); dbg[97] = clock64(); }
         // ---- stage Q
@@ -1019,31 +1024,35 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int j = 0; j < 10; ++j) cc[j] = crow[j];
         if (dbt) { asm volatile("" : "+v"(cc[0]), "+v"(cc[9])); dbg[99] = clock64(); }
         double chi = 0.0, gp = 0.0;
+        auto stage_q = [&](const int u0) {
 #pragma unroll
-        for (int u = 0; u < NDL; ++u) {
-            if (u * G >= nf) continue;
-            const double* r0 = rows_l + lo_[u] * 12;
-            const double* r1 = r0 + 12;
-            double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
+            for (int u = 0; u < NDL; ++u) {
+                if ((u0 + u) * G >= nf) continue;
+                const double* r0 = rows_l + lo_[u] * 12;
+                const double* r1 = r0 + 12;
+                double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
 #pragma unroll
-            for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
-            const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
-            const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
-            const double t = c_t[u];
-            double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
-            if (hit1[u]) est = y1;
-            if (!inside[u]) est = (t != t) ? t : dinf();
-            if (gi + u * G < nf) {
-                if (c_is[u] != 0.0) {
-                    const double x = (c_m[u] - est) * c_is[u];
-                    double v = (-(x * x) / 2.0 - kNormPdfLogC) - c_ls[u];
-                    if (!(est < dinf())) v = dnan();
-                    chi += v;
-                } else {
-                    gp += upper_limit_term(c_m[u], est, e_const);
+                for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
+                const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
+                const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
+                const double t = c_t[u];
+                double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
+                if (hit1[u]) est = y1;
+                if (!inside[u]) est = (t != t) ? t : dinf();
+                if (gi + (u0 + u) * G < nf) {
+                    if (c_is[u] != 0.0) {
+                        const double x = (c_m[u] - est) * c_is[u];
+                        double v = (-(x * x) / 2.0 - kNormPdfLogC) - c_ls[u];
+                        if (!(est < dinf())) v = dnan();
+                        chi += v;
+                    } else {
+                        gp += upper_limit_term(c_m[u], est, e_const);
+                    }
                 }
             }
-        }
+        };
+        stage_q(0);
+        for (int u0 = NDL; u0 * G < nf; u0 += NDL) { stage_p(u0); stage_q(u0); }    // uniform: only beyond 2 G points
         if (dbt) { asm volatile("" : "+v"(chi)); dbg[100] = clock64(); }
         chi = group_sum(chi, G);
         if (it.has_ul) gp = group_sum(gp, G);

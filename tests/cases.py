@@ -201,8 +201,8 @@ def case_fast_np6():
                  upper_limit_filter="g")
 
 
-def case_generic_too_many_points():
-    """One filter with more than 128 epochs next to small ones: the whole launch takes the generic path."""
+def case_many_points():
+    """One filter with 150 epochs next to small ones: three data per lane (a second pass over slot pairs)."""
     filters = ["a", "b", "c"]
     counts = dict(a=12, b=150, c=20)
     return _base(seed=9434, filters=filters, counts=counts, batch=24, upper_limit_filter="b")
@@ -223,7 +223,7 @@ def case_fast_wide():
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
-    "generic_too_many_points": case_generic_too_many_points,
+    "many_points": case_many_points,
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,
 }
