@@ -40,7 +40,7 @@ struct EmDev {
     int32_t prio_valu, prio_mfma;   // s_setprio of the two roles of em_logl (NMMA_EM_PRIO="v,m"; default 3,0)
     int* watchdog;            // [4] device words: {tripped, code, workgroup*64+wave, value*65536+target} (em_logl hand-off waits)
     int32_t helpers;          // MFMA-role waves join the likelihood workers after their stream (NMMA_EM_HELPERS, default 1)
-    int32_t all_fast;         // every work item takes em_logl's fast path (no LDS table staging needed)
+    int32_t all_fast;         // every work item takes em_logl's fast path: 1 = basic task, 2 = extended task (else 0)
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
     const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
@@ -78,6 +78,9 @@ struct EmDev {
     //   [rows NT x RS f64 (VA row | span | mins, RS = NC+2 rounded up to even) | s1_dx NS f64 | s1_off NS f64 |
     //    s1_idx NS i32 | b2 16 f32], 1-KiB padded
     const unsigned char* tab;
+    int32_t n_epar;               // fast mode: work items with a sampled systematic ...
+    const int32_t* epar_item;     // ... their item index
+    const int32_t* epar_slot;     // ... and the index of their parameter in sys_slots
     const int32_t* task_map[2];   // fast mode, per tile size R = 1, 2: task index -> (item << 8 | sample chunk)
     int32_t n_tasks[2];
     int32_t n_data;           // total number of photometry points (all observed filters)

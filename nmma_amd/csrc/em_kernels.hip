@@ -485,39 +485,34 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, epar, total;
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
 
-__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data) {
+// One candidate layout: `nbuf` ring slots, photometry staged or not.
+__host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
+                                         int NP, int all_fast, int n_data, int nbuf, bool stage_dat) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
+    L.nbuf = nbuf;
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
     L.stl = off;  off = align16(off + NS * 8);
-    // ring depth (items the MFMA role may run ahead): fast mode rings {partial sums, staged basis rows}
-    // per item and takes as many slots as fit the 160 KiB of LDS (at most 4); the generic path keeps
-    // 3 partial-sum buffers next to its double-buffered tables
-    L.nbuf = n_items < 3 ? (n_items < 1 ? 1 : n_items) : 3;
-    if (all_fast && n_items > 3) {
-        const int fixed = 44 * 1024;      // everything except the ring (generous)
-        const int slot = NSLICE * TS * PSTR * 4 + tab_fast_bytes;
-        if (fixed + 4 * slot <= 160 * 1024) L.nbuf = 4;
-    }
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
     L.sync = off; off = align16(off + (3 * n_items + 4) * 4);
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
-    L.dat = off;   off = align16(off + ((all_fast && n_data <= DAT_MAX) ? 4 * n_data * 8 : 0));
+    L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
+    if (L.dat >= 0) off = align16(off + 4 * n_data * 8);
+    L.epar = off;  off = align16(off + (all_fast ? n_items * TS * 8 : 0));   // sampled systematic sigma per (filter, sample)
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
-    L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);             // per wave (any role): 4 slots x 16 coefficients           // per VALU wave: 4 slots x 16 coefficients
-    L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);   // per-item descriptors
+    L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);              // per wave (any role): 4 slots x 16 coefficients
+    L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);     // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
     off = (off + 1023) / 1024 * 1024;
@@ -526,15 +521,35 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     return L;
 }
 
-// FAST: every work item qualifies for the fast path (EmDev::all_fast) -- the generic item phase and its
+// Ring depth (items the MFMA role may run ahead): fast mode rings {partial sums, staged basis rows} per item and
+// takes as many slots (at most 4) as fit the 160 KiB of LDS, giving up the photometry staging before the last
+// slots; the generic path keeps 3 partial-sum buffers next to its double-buffered tables.
+__host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
+                                     int all_fast, int n_data) {
+    constexpr int LDS_MAX = 160 * 1024;
+    const int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
+    LdsW L{};
+    for (int pass = 0; pass < 2; ++pass)
+        for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, nbuf, pass == 0);
+            if (L.total <= LDS_MAX) return L;
+        }
+    return L;     // does not fit: the launch fails with an explicit error
+}
+
+// FASTM = 0: generic item phase; 1: every work item qualifies for the basic fast task (constant systematics,
+// at most 2 G points per filter); 2: extended fast task (sampled systematics per datum, any number of points) --
+// separate instantiations so that the extensions cost the basic configuration nothing.
+// Fast modes: every work item qualifies for the fast path (EmDev::all_fast) -- the generic item phase and its
 // LDS table staging are not compiled in, which keeps the register budget small enough for 16-wave workgroups.
-template <int R, int KP, int NMW, int NVW, bool FAST>
+template <int R, int KP, int NMW, int NVW, int FASTM>
 __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
     long long* __restrict__ dbg) {
     constexpr int TS = 16 * R;
     constexpr int PF = (R == 1) ? 8 : 4;
+    constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     const EmDev& P = *Pp;
@@ -654,6 +669,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 } else {
                     for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
                     bad[lane] = 0;
+                    if constexpr (EXT) {           // sampled systematics of the fast path: (item, slot) pairs listed at create
+                        double* epar = reinterpret_cast<double*>(smem + L.epar);
+                        for (int q = 0; q < P.n_epar; ++q)
+                            epar[P.epar_item[q] * TS + lane] = apply_slot(P.sys_slots[P.epar_slot[q]], row);
+                    }
                 }
                 badp[vwave * TS + lane] = (chk - chk == 0.0) ? 0 : 1;
             }
@@ -667,6 +687,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
+            if constexpr (EXT) {
+                double* epar = reinterpret_cast<double*>(smem + L.epar);
+                for (int q = 0; q < P.n_epar; ++q)
+                    epar[P.epar_item[q] * TS + vt] = apply_slot(P.sys_slots[P.epar_slot[q]], row);
+            }
         }
         for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
         for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             int* tmap = reinterpret_cast<int*>(smem + L.tmap);
             gci32p src = as_global(P.task_map[R - 1]);
             for (int j = vt; j < P.n_tasks[R - 1] && j < TMAP_MAX; j += NV) tmap[j] = src[j];
-            if (P.n_data <= DAT_MAX) {
+            if (L.dat >= 0) {
                 double* dat = reinterpret_cast<double*>(smem + L.dat);
                 const int nd = P.n_data;
                 gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
@@ -930,8 +955,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // Only Q is on the critical path behind the MFMA role, and it contains no global-memory latency.
     // ---------------------------------------------------------------------------------
     const int nd_l = P.n_data;
-    const double* dat_l = (FAST && nd_l <= DAT_MAX) ? reinterpret_cast<const double*>(smem + L.dat) : nullptr;
-    auto fast_task = [&](const int k, const int c) {
+    const double* dat_l = (FAST && L.dat >= 0) ? reinterpret_cast<const double*>(smem + L.dat) : nullptr;
+    auto fast_task = [&](auto par_tag, const int k, const int c) {
+        constexpr bool par = decltype(par_tag)::value;   // sampled systematic (combined per datum) vs precomputed 1/sigma_tot
         const bool dbt = dbg && blockIdx.x == 0 && lane == 0 && c == 0 && k == W - 1;
         if (dbt) dbg[96] = clock64();
         const ItemDesc& it = itab[k];
@@ -952,7 +978,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const float* pbuf = part + (k % NBUF) * (NSLICE * TS * PSTR);
         const int jlo = it.jlo, jhi = it.jhi;
         const int G = it.G, d0 = it.d0, nf = it.nf;         // G = 16, 32 or 64 (a power of two: shifts, no division)
-        const double e_const = it.e_const;
         const int lgG = (G == 16) ? 4 : (G == 32 ? 5 : 6);
         const int g = lane >> lgG, gi = lane & (G - 1);
         const int s = (c << (6 - lgG)) + g;                 // < TS: TS * G is a multiple of 64
@@ -962,6 +987,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const double dmrc = sc[S_DMOD] + sc[S_RC];
         const double izdt = izp1 * inv_dt;
         const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
+        const double e_sys = par ? reinterpret_cast<const double*>(smem + L.epar)[k * TS + s] : it.e_const;
 
         // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid.
         // A lane owns data gi, gi + G, gi + 2G, ...; they are processed in pairs (two slots in registers):
@@ -1040,19 +1066,29 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (hit1[u]) est = y1;
                 if (!inside[u]) est = (t != t) ? t : dinf();
                 if (gi + (u0 + u) * G < nf) {
-                    if (c_is[u] != 0.0) {
-                        const double x = (c_m[u] - est) * c_is[u];
-                        double v = (-(x * x) / 2.0 - kNormPdfLogC) - c_ls[u];
-                        if (!(est < dinf())) v = dnan();
+                    double isig = c_is[u], lsig = c_ls[u];
+                    bool sig_bad = false;
+                    if constexpr (par) {             // sampled systematic, combined per datum
+                        const double sd = c_is[u];   // (the slot carries sigma_data for these filters)
+                        const double sig = sqrt(sd * sd + e_sys * e_sys);
+                        if (sig - sig == 0.0) { isig = 1.0 / sig; lsig = log(sig); sig_bad = !(sig > 0); }
+                        else isig = 0.0;             // infinite data error: upper limit
+                        if (sig != sig) sig_bad = true;
+                    }
+                    if (isig != 0.0 || sig_bad) {
+                        const double x = (c_m[u] - est) * isig;
+                        double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
+                        if (!(est < dinf()) || sig_bad) v = dnan();
                         chi += v;
                     } else {
-                        gp += upper_limit_term(c_m[u], est, e_const);
+                        gp += upper_limit_term(c_m[u], est, e_sys);
                     }
                 }
             }
         };
         stage_q(0);
-        for (int u0 = NDL; u0 * G < nf; u0 += NDL) { stage_p(u0); stage_q(u0); }    // uniform: only beyond 2 G points
+        if constexpr (EXT)
+            for (int u0 = NDL; u0 * G < nf; u0 += NDL) { stage_p(u0); stage_q(u0); }    // uniform: only beyond 2 G points
         if (dbt) { asm volatile("" : "+v"(chi)); dbg[100] = clock64(); }
         chi = group_sum(chi, G);
         if (it.has_ul) gp = group_sum(gp, G);
@@ -1108,7 +1144,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64); if (t < n) break; t -= n; }
             }
 #ifndef NMMA_DBG_NOVALU
-            fast_task(k, t);
+            if constexpr (EXT) {
+                if (itab[k].kind == NMMA_SYS_PARAM) fast_task(std::true_type{}, k, t);
+                else fast_task(std::false_type{}, k, t);
+            } else {
+                fast_task(std::false_type{}, k, t);
+            }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
 #endif
