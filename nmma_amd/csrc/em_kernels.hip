@@ -988,6 +988,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const double izdt = izp1 * inv_dt;
         const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
         const double e_sys = par ? reinterpret_cast<const double*>(smem + L.epar)[k * TS + s] : it.e_const;
+        const bool lim_finite = EXT && (it.lim - it.lim == 0.0);
+        const double ext = (EXT && sc[S_EBV] != 0.0) ? it.ebvc * sc[S_EBV] : 0.0;
 
         // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid.
         // A lane owns data gi, gi + G, gi + 2G, ...; they are processed in pairs (two slots in registers):
@@ -1059,8 +1061,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
 #pragma unroll
                 for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
-                const double y0 = (a0 * r0[10] + r0[11]) + dmrc;
-                const double y1 = (a1 * r1[10] + r1[11]) + dmrc;
+                double y0 = a0 * r0[10] + r0[11], y1 = a1 * r1[10] + r1[11];
+                if constexpr (EXT) { if (ext != 0.0) { y0 = y0 + ext; y1 = y1 + ext; } }     // uniform per sample group
+                y0 = y0 + dmrc; y1 = y1 + dmrc;
                 const double t = c_t[u];
                 double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
                 if (hit1[u]) est = y1;
@@ -1076,9 +1079,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         if (sig != sig) sig_bad = true;
                     }
                     if (isig != 0.0 || sig_bad) {
-                        const double x = (c_m[u] - est) * isig;
-                        double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
-                        if (!(est < dinf()) || sig_bad) v = dnan();
+                        double v;
+                        if (EXT && lim_finite) {         // uniform: truncated Gaussian with a finite detection limit
+                            v = sig_bad ? dnan() : detection_term(c_m[u], est, 1.0 / isig, lsig, it.lim);
+                        } else {
+                            const double x = (c_m[u] - est) * isig;
+                            v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
+                            if (!(est < dinf()) || sig_bad) v = dnan();
+                        }
                         chi += v;
                     } else {
                         gp += upper_limit_term(c_m[u], est, e_sys);

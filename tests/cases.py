@@ -220,10 +220,22 @@ def case_fast_wide():
     return _base(seed=9634, filters=filters, counts=70, batch=40, upper_limit_filter="w07")
 
 
+def case_extinction_limit():
+    """Sampled E(B-V) with per-filter extinction coefficients (A_f = k_f * Ebv, the role of
+    get_extinction_mags, em/model.py:323-342) and a finite detection limit on the default grid:
+    both handled by the extended fast task."""
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind", "Ebv"]
+    c = _base(seed=9734, batch=48, names=names)
+    c["ebv_coeff"] = {f: 3.1 - 0.45 * i for i, f in enumerate(c["model_filters"])}
+    c["detection_limit"] = 24.5
+    return c
+
+
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
     "many_points": case_many_points,
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,
+    "extinction_limit": case_extinction_limit,
 }

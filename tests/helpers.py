@@ -14,7 +14,8 @@ def engine_from_case(case, device=0):
                     data=case["data"], observed_filters=obs,
                     sources=resolve_sources(obs, case["model_filters"],
                                             known_filters=[f for f in obs if f not in FILTER_AVERAGES]),
-                    detection_limit=lim, systematics=case["systematics"], device=device)
+                    detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
+                    device=device)
 
 
 def oracle_from_case(case, **kw):
