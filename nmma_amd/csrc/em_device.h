@@ -78,9 +78,6 @@ struct EmDev {
     //   [rows NT x RS f64 (VA row | span | mins, RS = NC+2 rounded up to even) | s1_dx NS f64 | s1_off NS f64 |
     //    s1_idx NS i32 | b2 16 f32], 1-KiB padded
     const unsigned char* tab;
-    int32_t n_epar;               // fast mode: work items with a sampled systematic ...
-    const int32_t* epar_item;     // ... their item index
-    const int32_t* epar_slot;     // ... and the index of their parameter in sys_slots
     const int32_t* task_map[2];   // fast mode, per tile size R = 1, 2: task index -> (item << 8 | sample chunk)
     int32_t n_tasks[2];
     int32_t n_data;           // total number of photometry points (all observed filters)

@@ -492,7 +492,7 @@ struct LdsW {
 
 // One candidate layout: `nbuf` ring slots, photometry staged or not.
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
-                                         int NP, int all_fast, int n_data, int nbuf, bool stage_dat) {
+                                         int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -508,7 +508,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
     if (L.dat >= 0) off = align16(off + 4 * n_data * 8);
-    L.epar = off;  off = align16(off + (all_fast ? n_items * TS * 8 : 0));   // sampled systematic sigma per (filter, sample)
+    L.epar = off;  off = align16(off + (all_fast == 2 ? n_sys_slots * TS * 8 : 0));   // extended fast mode: sysv[slot][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
     L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);              // per wave (any role): 4 slots x 16 coefficients
@@ -525,13 +525,13 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // takes as many slots (at most 4) as fit the 160 KiB of LDS, giving up the photometry staging before the last
 // slots; the generic path keeps 3 partial-sum buffers next to its double-buffered tables.
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data) {
+                                     int all_fast, int n_data, int n_sys_slots) {
     constexpr int LDS_MAX = 160 * 1024;
     const int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     LdsW L{};
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, nbuf, pass == 0);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
@@ -667,13 +667,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 } else if (vwave == 2) {
                     for (int p = 0; p < P.NP; ++p) chk += apply_slot(P.model_param[p], row);
                 } else {
-                    for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
-                    bad[lane] = 0;
-                    if constexpr (EXT) {           // sampled systematics of the fast path: (item, slot) pairs listed at create
-                        double* epar = reinterpret_cast<double*>(smem + L.epar);
-                        for (int q = 0; q < P.n_epar; ++q)
-                            epar[P.epar_item[q] * TS + lane] = apply_slot(P.sys_slots[P.epar_slot[q]], row);
+                    for (int q = 0; q < P.n_sys_slots; ++q) {
+                        const double v = apply_slot(P.sys_slots[q], row);
+                        chk += v;
+                        if constexpr (EXT) reinterpret_cast<double*>(smem + L.epar)[q * TS + lane] = v;   // sysv[slot][sample]
                     }
+                    bad[lane] = 0;
+
                 }
                 badp[vwave * TS + lane] = (chk - chk == 0.0) ? 0 : 1;
             }
@@ -683,15 +683,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const double* row = theta + b * ld;
             double chk;
             sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
-            for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+            for (int q = 0; q < P.n_sys_slots; ++q) {
+                const double v = apply_slot(P.sys_slots[q], row);
+                chk += v;
+                if constexpr (EXT) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
+            }
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
-            if constexpr (EXT) {
-                double* epar = reinterpret_cast<double*>(smem + L.epar);
-                for (int q = 0; q < P.n_epar; ++q)
-                    epar[P.epar_item[q] * TS + vt] = apply_slot(P.sys_slots[P.epar_slot[q]], row);
-            }
         }
         for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
         for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
@@ -956,8 +955,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // ---------------------------------------------------------------------------------
     const int nd_l = P.n_data;
     const double* dat_l = (FAST && L.dat >= 0) ? reinterpret_cast<const double*>(smem + L.dat) : nullptr;
-    auto fast_task = [&](auto par_tag, const int k, const int c) {
-        constexpr bool par = decltype(par_tag)::value;   // sampled systematic (combined per datum) vs precomputed 1/sigma_tot
+    auto fast_task = [&](auto kind_tag, const int k, const int c) {
+        // systematics of the item: 0 = constant (1/sigma_tot precomputed), 1 = one sampled parameter, 2 = sampled time nodes
+        constexpr int SK = decltype(kind_tag)::value;
+        constexpr bool par = SK != 0;
         const bool dbt = dbg && blockIdx.x == 0 && lane == 0 && c == 0 && k == W - 1;
         if (dbt) dbg[96] = clock64();
         const ItemDesc& it = itab[k];
@@ -987,7 +988,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const double dmrc = sc[S_DMOD] + sc[S_RC];
         const double izdt = izp1 * inv_dt;
         const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
-        const double e_sys = par ? reinterpret_cast<const double*>(smem + L.epar)[k * TS + s] : it.e_const;
+        const double* sysv = reinterpret_cast<const double*>(smem + L.epar) + s;        // sysv[slot * TS]: this sample's values
+        const int sv0 = par ? P.sys_off[o] : 0;                                            // first slot of the filter's group
+        double e_sys = (SK == 1) ? sysv[sv0 * TS] : it.e_const;
         const bool lim_finite = EXT && (it.lim - it.lim == 0.0);
         const double ext = (EXT && sc[S_EBV] != 0.0) ? it.ebvc * sc[S_EBV] : 0.0;
 
@@ -1072,6 +1075,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     double isig = c_is[u], lsig = c_ls[u];
                     bool sig_bad = false;
                     if constexpr (par) {             // sampled systematic, combined per datum
+                        if constexpr (SK == 2) {     // time nodes: constant outside, linear in between (systematics.py:288-291)
+                            const int di = d0 + gi + (u0 + u) * G;
+                            const int K = P.sys_nn[o], ni = P.sys_nidx[di];
+                            if (ni < 0) e_sys = sysv[sv0 * TS];
+                            else if (ni >= K - 1) e_sys = sysv[(sv0 + K - 1) * TS];
+                            else {
+                                const double v0 = sysv[(sv0 + ni) * TS], v1 = sysv[(sv0 + ni + 1) * TS];
+                                const double sl2 = (v1 - v0) / P.sys_ndx[di];
+                                e_sys = sl2 * P.sys_noff[di] + v0;
+                            }
+                        }
                         const double sd = c_is[u];   // (the slot carries sigma_data for these filters)
                         const double sig = sqrt(sd * sd + e_sys * e_sys);
                         if (sig - sig == 0.0) { isig = 1.0 / sig; lsig = log(sig); sig_bad = !(sig > 0); }
@@ -1153,10 +1167,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
 #ifndef NMMA_DBG_NOVALU
             if constexpr (EXT) {
-                if (itab[k].kind == NMMA_SYS_PARAM) fast_task(std::true_type{}, k, t);
-                else fast_task(std::false_type{}, k, t);
+                const int kind = itab[k].kind;
+                if (kind == NMMA_SYS_PARAM) fast_task(std::integral_constant<int, 1>{}, k, t);
+                else if (kind == NMMA_SYS_NODES) fast_task(std::integral_constant<int, 2>{}, k, t);
+                else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
-                fast_task(std::false_type{}, k, t);
+                fast_task(std::integral_constant<int, 0>{}, k, t);
             }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
