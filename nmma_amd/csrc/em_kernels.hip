@@ -992,6 +992,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const int sv0 = par ? P.sys_off[o] : 0;                                            // first slot of the filter's group
         double e_sys = (SK == 1) ? sysv[sv0 * TS] : it.e_const;
         const bool lim_finite = EXT && (it.lim - it.lim == 0.0);
+        const bool two = EXT && !(it.identity != 0 && it.same_grid != 0);
         const double ext = (EXT && sc[S_EBV] != 0.0) ? it.ebvc * sc[S_EBV] : 0.0;
 
         // ---- stage P: this lane's data and their brackets on the sample's observer-frame grid.
@@ -1040,6 +1041,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
         const double* rows_l = reinterpret_cast<const double*>(tbl);          // [NT][12]: VA row | span | mins
         const float* b2l = reinterpret_cast<const float*>(tbl + P.tab_off_b2);
+        const double* s1dx_l = reinterpret_cast<const double*>(tbl + P.tab_off_s1dx);   // (staged only when some item needs them)
+        const double* s1of_l = reinterpret_cast<const double*>(tbl + P.tab_off_s1of);
+        const int* s1i_l = reinterpret_cast<const int*>(tbl + P.tab_off_s1i);
         if (gi < 16) {
             const int rb = s >> 4, sidx = s & 15;
             const float* pp = pbuf + (rb * 16 + sidx) * PSTR + gi;
@@ -1059,12 +1063,34 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 #pragma unroll
             for (int u = 0; u < NDL; ++u) {
                 if ((u0 + u) * G >= nf) continue;
-                const double* r0 = rows_l + lo_[u] * 12;
-                const double* r1 = r0 + 12;
-                double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
+                double y0, y1;
+                if (EXT && two) {
+                    // sample_times differ from the SVD grid (uniform per item): each of the two sample nodes is itself a
+                    // lerp between two SVD nodes (stage 1, lightcurve_generation.py:177) -- up to four basis rows
+                    auto mag_row = [&](const int i) -> double {
+                        const double* r = rows_l + i * 12;
+                        double a = r[0] * cc[0];
 #pragma unroll
-                for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
-                double y0 = a0 * r0[10] + r0[11], y1 = a1 * r1[10] + r1[11];
+                        for (int j = 1; j < 10; ++j) a = fma(r[j], cc[j], a);
+                        return a * r[10] + r[11];
+                    };
+                    auto stage1 = [&](const int j) -> double {
+                        const int i1 = s1i_l[j];
+                        const double ya = mag_row(i1);
+                        if (it.identity) return ya;
+                        const double yb = mag_row(i1 + 1 < NT ? i1 + 1 : NT - 1);
+                        return ((yb - ya) / s1dx_l[j]) * s1of_l[j] + ya;
+                    };
+                    y0 = stage1(lo_[u]);
+                    y1 = stage1(lo_[u] + 1);
+                } else {
+                    const double* r0 = rows_l + lo_[u] * 12;
+                    const double* r1 = r0 + 12;
+                    double a0 = r0[0] * cc[0], a1 = r1[0] * cc[0];
+#pragma unroll
+                    for (int j = 1; j < 10; ++j) { a0 = fma(r0[j], cc[j], a0); a1 = fma(r1[j], cc[j], a1); }
+                    y0 = a0 * r0[10] + r0[11]; y1 = a1 * r1[10] + r1[11];
+                }
                 if constexpr (EXT) { if (ext != 0.0) { y0 = y0 + ext; y1 = y1 + ext; } }     // uniform per sample group
                 y0 = y0 + dmrc; y1 = y1 + dmrc;
                 const double t = c_t[u];
