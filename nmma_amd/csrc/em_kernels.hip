@@ -999,7 +999,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // A lane owns data gi, gi + G, gi + 2G, ...; they are processed in pairs (two slots in registers):
         // the first pair before the item is published, further pairs (more than 2 G points per filter) after it.
         constexpr int NDL = 2;
-        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL];
+        double c_t[NDL], c_m[NDL], c_is[NDL], c_ls[NDL], x0[NDL], x1[NDL];
         bool inside[NDL], hit1[NDL];
         int lo_[NDL];
         auto stage_p = [&](const int u0) {
@@ -1012,18 +1012,29 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
 #pragma unroll
             for (int u = 0; u < NDL; ++u) {
-                if ((u0 + u) * G >= nf) { inside[u] = false; hit1[u] = false; x0[u] = 0; lo_[u] = 0; continue; }   // uniform: slot unused by this item
+                if ((u0 + u) * G >= nf) { inside[u] = false; hit1[u] = false; x0[u] = 0; x1[u] = 0; lo_[u] = 0; continue; }   // uniform: slot unused by this item
                 const double t = c_t[u];
                 inside[u] = (jhi > jlo) && t >= t_lo && t <= t_hi;
-                int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
-                lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
+                int lo;
+                if (!EXT || uniform) {
+                    lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                    lo = lo < jlo ? jlo : (lo > jhi - 1 ? jhi - 1 : lo);
+                } else {                     // sample_times not equally spaced (e.g. the CLI's log-spaced grid): bisection
+                    lo = jlo;
+                    int hi = jhi;
+                    while (inside[u] && hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+                    }
+                    if (lo > jhi - 1) lo = jhi - 1;
+                }
                 if (lo < 0) lo = 0;
                 double a = stl[lo] * zp1 + tsh, b = stl[lo + 1] * zp1 + tsh;
                 for (int it2 = 0; it2 < 4 && inside[u] && ((a > t && lo > jlo) || (b <= t && lo < jhi - 1)); ++it2) {   // exact re-check (the guess is off by at most one)
                     lo += (a > t) ? -1 : 1;
                     a = stl[lo] * zp1 + tsh; b = stl[lo + 1] * zp1 + tsh;
                 }
-                x0[u] = a; hit1[u] = (b == t); lo_[u] = lo;
+                x0[u] = a; x1[u] = b; hit1[u] = (b == t); lo_[u] = lo;
             }
         };
         stage_p(0);
@@ -1095,6 +1106,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 y0 = y0 + dmrc; y1 = y1 + dmrc;
                 const double t = c_t[u];
                 double est = ((y1 - y0) * izdt) * (t - x0[u]) + y0;
+                if (EXT && !uniform) est = ((y1 - y0) / (x1[u] - x0[u])) * (t - x0[u]) + y0;
                 if (hit1[u]) est = y1;
                 if (!inside[u]) est = (t != t) ? t : dinf();
                 if (gi + (u0 + u) * G < nf) {

@@ -231,6 +231,13 @@ def case_extinction_limit():
     return c
 
 
+def case_log_grid():
+    """The CLI's default grid when --em-tmin/--em-tmax are given (150 log-spaced sample times,
+    em/utils.py:87-88): two-stage interpolation on a non-uniform grid (bisection instead of an index guess)."""
+    c = _base(seed=9834, batch=40, sample_times=np.geomspace(0.2, 20.0, 150))
+    return c
+
+
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
@@ -238,4 +245,5 @@ SHAPE_CASES = {
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,
     "extinction_limit": case_extinction_limit,
+    "log_grid": case_log_grid,
 }
