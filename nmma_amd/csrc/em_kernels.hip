@@ -646,14 +646,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             // shift, E(B-V), 2 = model parameters, 3 = systematics parameters.  Lane = sample.
             if (vwave < 4 && lane < TS) {
                 sync_wait(sync + 2 * W + 2, NVW, P.watchdog, 200);
-                const double* row = thl + lane * (int)ld;
+                // (LDS-address-space pointers: ds_read instead of flat_load for the staged rows and grids)
+                typedef const __attribute__((address_space(3))) double* lds_cdp;
+                const lds_cdp row = (lds_cdp)(thl + lane * (int)ld);
+                const lds_cdp dgl_l = (lds_cdp)dgl, zgl_l = (lds_cdp)zgl;
                 double* sc = scal + lane * 8;
                 double chk = 0.0;
                 if (vwave == 0) {
                     const double d_l = apply_slot(P.lumdist, row);
                     double z = 0.0;
                     if (P.redshift_mode == NMMA_Z_SLOT) z = apply_slot(P.redshift, row);
-                    else if (P.redshift_mode == NMMA_Z_GRID) z = interp_np(d_l, dgl, zgl, P.n_cosmo, zgl[0], zgl[P.n_cosmo - 1]);
+                    else if (P.redshift_mode == NMMA_Z_GRID) z = interp_np(d_l, dgl_l, zgl_l, P.n_cosmo, zgl_l[0], zgl_l[P.n_cosmo - 1]);
                     sc[S_ZP1] = 1 + z;
                     sc[S_IZP1] = 1.0 / (1 + z);
                     sc[S_RC] = redshift_correction(z);
@@ -1193,7 +1196,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             if (dbg && blockIdx.x == 0 && lane == 0 && t < 24) { dbg[16 + t] = clock64(); dbg[40 + t] = wave; }
             if (t >= ntot) break;
             if (++claims > ntot + 64) {          // cannot happen; fail loudly instead of spinning
-                if (lane == 0) { P.watchdog[0] = 1; P.watchdog[1] = 900; P.watchdog[2] = (int)blockIdx.x * 64 + wave; P.watchdog[3] = t; }
+                if (lane == 0) { g_ip wd = (g_ip)(uintptr_t)P.watchdog; wd[0] = 1; wd[1] = 900; wd[2] = (int)blockIdx.x * 64 + wave; wd[3] = t; }
                 break;
             }
             int k = 0;

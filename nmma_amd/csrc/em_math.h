@@ -48,7 +48,9 @@ NM_HD_COLD double apply_slot_op(double v, int op) {
     }
 }
 
-NM_HD double apply_slot(const nmma_slot& s, const double* row) {
+// (RowPtr: any pointer to double -- generic, or an LDS/global address-space pointer in device code)
+template <class RowPtr>
+NM_HD double apply_slot(const nmma_slot& s, RowPtr row) {
     if (s.col < 0) return s.value;
     const double v = row[s.col];
     if (s.op == NMMA_OP_IDENT) return v;
@@ -71,7 +73,8 @@ NM_HD double lerp_np(double x, double x0, double x1, double y0, double y1) {
 }
 
 // np.interp(x, xp[0..n), fp[0..n), left, right); xp increasing, n >= 1.
-NM_HD double interp_np(double x, const double* xp, const double* fp, int n, double left, double right) {
+template <class XPtr, class FPtr>
+NM_HD double interp_np(double x, XPtr xp, FPtr fp, int n, double left, double right) {
     if (x != x) return x;
     if (n == 1) return x < xp[0] ? left : (x > xp[0] ? right : fp[0]);
     if (x < xp[0]) return left;
