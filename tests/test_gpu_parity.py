@@ -185,3 +185,22 @@ def test_check_reports_clean_handle(torch_cuda):
     eng.loglike(torch.as_tensor(case["theta"], device="cuda:0"))
     eng.check()
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2_default", "syserr_time_nodes", "c2_dt05_limit"])
+def test_wide_theta_rows(name, torch_cuda):
+    """theta with unused trailing columns (row stride > 24 doubles): the prologue reads the rows straight from
+    memory instead of staging them in LDS -- same numbers, bit for bit, on the device and the host entry point."""
+    torch = torch_cuda
+    case = cases.CASES[name]()
+    eng = engine_from_case(case)
+    theta = np.asarray(case["theta"], float)
+    wide = np.zeros((theta.shape[0], 40))
+    wide[:, :theta.shape[1]] = theta
+    wide[:, theta.shape[1]:] = np.nan          # unused columns must never be read into the result
+    a = eng.loglike(torch.as_tensor(theta, device="cuda:0")).cpu().numpy()
+    b = eng.loglike(torch.as_tensor(wide, device="cuda:0")).cpu().numpy()
+    c = eng.loglike(wide)
+    eng.check()
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    eng.close()
