@@ -85,9 +85,41 @@ class FlatLambdaCDM:
         return 0.5 * (lo + hi)
 
 
+def native_cosmology(cosmology=None):
+    """Map whatever a prior carries as ``cosmology`` onto the native :class:`FlatLambdaCDM`:
+    None / a name -> Planck18 (nmma/core/constants.py:43); an object with the native interface is
+    used as is; an astropy-like flat cosmology is rebuilt from its H0 / Om0 / Tcmb0 / Neff / m_nu."""
+    if cosmology is None or isinstance(cosmology, str):
+        return FlatLambdaCDM(**PLANCK18)
+    if hasattr(cosmology, "z_at_luminosity_distance"):
+        return cosmology
+
+    def val(x):
+        return getattr(x, "value", x)
+    try:
+        kw = dict(H0=float(val(cosmology.H0)), Om0=float(val(cosmology.Om0)))
+        for key in ("Tcmb0", "Neff"):
+            if hasattr(cosmology, key):
+                kw[key] = float(val(getattr(cosmology, key)))
+        if hasattr(cosmology, "m_nu"):
+            kw["m_nu"] = tuple(np.atleast_1d(val(cosmology.m_nu)).astype(float))
+        return FlatLambdaCDM(**kw)
+    except (AttributeError, TypeError, ValueError) as exc:
+        raise ValueError(f"cannot map cosmology {cosmology!r} onto the native FlatLambdaCDM") from exc
+
+
+def redshift_at_distance(d_lum, cosmo_grid=None, cosmology=None):
+    """z of ONE fixed luminosity distance: through the caller's grid when it covers the distance
+    (what the reference's redshift_from_dlum does), else the native root-find (get_redshift)."""
+    d_lum = float(d_lum)
+    if cosmo_grid is not None and cosmo_grid[0][0] <= d_lum <= cosmo_grid[0][-1]:
+        return float(np.interp(d_lum, cosmo_grid[0], cosmo_grid[1]))
+    return float(native_cosmology(cosmology).z_at_luminosity_distance(d_lum))
+
+
 def get_cosmo_grids(distance_min, distance_max, cosmology=None, n=50):
     """(dist_grid, z_grid) with the layout of nmma/core/conversion.py:49-55."""
-    cosmology = cosmology or FlatLambdaCDM(**PLANCK18)
+    cosmology = native_cosmology(cosmology)
     zmin = cosmology.z_at_luminosity_distance(distance_min)
     zmax = cosmology.z_at_luminosity_distance(distance_max)
     z_grid = np.geomspace(zmin, zmax, n)

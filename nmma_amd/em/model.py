@@ -68,7 +68,9 @@ class LightCurveModelContainer:
         if "redshift" not in priors and "luminosity_distance" in priors:
             pr = priors["luminosity_distance"]
             lo, hi = getattr(pr, "minimum", None), getattr(pr, "maximum", None)
-            if lo is not None and hi is not None and hi > lo and self.cosmo_grid is None:
+            if lo is not None and hi is not None and self.cosmo_grid is None and np.isfinite([lo, hi]).all():
+                # hi == lo (a DeltaFunction): a constant grid, np.interp then returns z(d_L) -- the engine
+                # applies that redshift as a constant (never z = 0 for a fixed distance)
                 self.cosmo_grid = get_cosmo_grids(lo, hi, getattr(pr, "cosmology", None))
 
     def sanity_checks(self, parameters):
@@ -196,6 +198,7 @@ class SVDLightCurveModel(LightCurveModelContainer):
         if sample_times is not None and not np.array_equal(sample_times, self.model_times):
             self.model_times = np.asarray(sample_times, float)
             self._lc_engine = None
+        parameters = _with_host_redshift(parameters, self.cosmo_grid)
         names = sorted(k for k, v in parameters.items() if np.ndim(v) <= 1 and _is_number(v))
         if self._lc_engine is None or names != self._lc_names:
             if self._lc_engine is not None:
@@ -221,8 +224,9 @@ class SVDLightCurveModel(LightCurveModelContainer):
         """Absolute-magnitude light curves (model.py:707-728): the detector-frame result with
         distance / redshift / timeshift neutralised."""
         p = dict(parameters)
-        p.update(luminosity_distance=1e-5, timeshift=0.0, Ebv=0.0)
+        p.update(timeshift=0.0, Ebv=0.0)
         p.pop("redshift", None)
+        p.pop("luminosity_distance", None)        # absent: 10 pc and z = 0 (model.py:291-293, conversion.py:57-64)
         grid, self.cosmo_grid = self.cosmo_grid, None
         try:
             self._lc_engine = None
@@ -233,6 +237,21 @@ class SVDLightCurveModel(LightCurveModelContainer):
         if filters not in ("all", None):
             lc = {f: lc[f] for f in filters}
         return lc
+
+
+def _with_host_redshift(parameters, cosmo_grid):
+    """Without a z(d_L) grid the reference root-finds the redshift of every sample's distance
+    (get_redshift, conversion.py:36-47, :57-64); do the same on the host and hand it over as a
+    ``redshift`` column."""
+    if "redshift" in parameters or "luminosity_distance" not in parameters or cosmo_grid is not None:
+        return parameters
+    from ..core.conversion import native_cosmology
+    cosmo = native_cosmology()
+    d = np.asarray(parameters["luminosity_distance"], float)
+    z = np.array([cosmo.z_at_luminosity_distance(x) for x in np.atleast_1d(d)])
+    out = dict(parameters)
+    out["redshift"] = float(z[0]) if d.ndim == 0 else z
+    return out
 
 
 def _is_number(v):

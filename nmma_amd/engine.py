@@ -177,7 +177,16 @@ class EMEngine:
         if "redshift" in names or "redshift" in fixed:
             cfg.redshift_mode = L.Z_SLOT
             cfg.redshift = _plain_slot("redshift", names, fixed, 0.0)
-        elif cosmo_grid is not None and ("luminosity_distance" in names or "luminosity_distance" in fixed):
+        elif "luminosity_distance" in fixed and "luminosity_distance" not in names:
+            # a FIXED distance still carries its redshift: the reference's get_cosmo_grids(d, d) is a constant
+            # grid, so np.interp returns z(d_L) (model.py:255-267, conversion.py:49-55)
+            from .core.conversion import redshift_at_distance
+            cfg.redshift_mode = L.Z_SLOT
+            cfg.redshift = L.Slot.constant(redshift_at_distance(fixed["luminosity_distance"], cosmo_grid))
+        elif "luminosity_distance" in names:
+            if cosmo_grid is None:
+                raise L.NMMAHipError("luminosity_distance is sampled but no z(d_L) grid was supplied: call "
+                                     "check_vs_priors() with a bounded prior, or pass cosmo_grid / a redshift column")
             dg, zg = _f64(cosmo_grid[0]), _f64(cosmo_grid[1])
             keep += [dg, zg]
             cfg.redshift_mode, cfg.n_cosmo = L.Z_GRID, len(dg)

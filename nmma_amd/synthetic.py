@@ -160,6 +160,13 @@ def draw_theta(seed, batch, names=None):
             cols.append(rng.uniform(0.1, 2.0, batch))
         elif n == "Ebv":
             cols.append(rng.uniform(0.0, 0.5, batch))
+        elif n == "theta_jn":                             # isotropic viewing angle on [0, pi]: folded by the conversion
+            cols.append(np.arccos(rng.uniform(-1.0, 1.0, batch)))
+        elif n == "cos_theta_jn":
+            cols.append(rng.uniform(-1.0, 1.0, batch))
+        elif n in ("mej_dyn", "mej_wind"):                # linear masses: the model's log10_ alias applies
+            lo, hi = PARAM_BOX["log10_" + n]
+            cols.append(10.0 ** rng.uniform(lo, hi, batch))
         elif n in PARAM_BOX:
             lo, hi = PARAM_BOX[n]
             cols.append(rng.uniform(lo, hi, batch))

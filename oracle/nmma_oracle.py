@@ -79,19 +79,26 @@ def distance_modulus_nmma(d_lum=1e-5):
     return 5.0 * (5 + np.log10(d_lum))
 
 
-def redshift_from_parameters(parameters, cosmo_grid=None):
+def redshift_from_parameters(parameters, cosmo_grid=None, z_of_dl=None):
     """nmma/core/conversion.py:57-64 + nmma/em/model.py:255-267.
 
     ``cosmo_grid = (dist_grid[50], z_grid[50])`` is an *input* (astropy's Planck18
     root-find builds it once in the reference, nmma/core/conversion.py:49-55; astropy
-    is not installed here -- SURVEY.md section 8c).  Without a grid the reference
-    falls back to ``redshift`` if sampled, else zeros.
+    is not installed here -- SURVEY.md section 8c).  A FIXED distance gives a constant
+    grid (get_cosmo_grids(d, d)), i.e. np.interp returns z(d_L).  Without a grid the
+    reference root-finds z for the sample's distance (get_redshift ->
+    luminosity_distance_to_redshift, conversion.py:36-47): ``z_of_dl`` stands in for
+    that call (astropy-free callable); zeros only when no distance is present at all.
     """
     if "redshift" in parameters:
         return parameters["redshift"]
-    if "luminosity_distance" in parameters and cosmo_grid is not None:
-        dist_grid, z_grid = cosmo_grid
-        return np.interp(parameters["luminosity_distance"], dist_grid, z_grid)
+    if "luminosity_distance" in parameters:
+        if cosmo_grid is not None:
+            dist_grid, z_grid = cosmo_grid
+            return np.interp(parameters["luminosity_distance"], dist_grid, z_grid)
+        if z_of_dl is None:
+            raise ValueError("oracle: a luminosity_distance needs cosmo_grid or z_of_dl (the reference never uses z = 0 here)")
+        return z_of_dl(parameters["luminosity_distance"])
     return 0.0
 
 
@@ -447,11 +454,15 @@ class OracleLikelihood:
 # ---------------------------------------------------------------------------
 # Vectorised variant (NOT what the reference does; used to check big batches fast)
 # ---------------------------------------------------------------------------
-def log_likelihood_batch(lik: OracleLikelihood, names, theta):
-    """Loop of ``log_likelihood`` over the rows of ``theta[B, D]`` (columns = names)."""
+def log_likelihood_batch(lik: OracleLikelihood, names, theta, fixed=None):
+    """Loop of ``log_likelihood`` over the rows of ``theta[B, D]`` (columns = names); ``fixed`` holds the
+    delta-function parameters every sample dict also carries (bilby hands them to the likelihood)."""
     out = np.empty(len(theta))
     for i, row in enumerate(theta):
-        out[i] = lik.log_likelihood(dict(zip(names, (float(v) for v in row))))
+        p = dict(zip(names, (float(v) for v in row)))
+        if fixed:
+            p.update(fixed)
+        out[i] = lik.log_likelihood(p)
     return out
 
 

@@ -145,6 +145,31 @@ def case_c4_shape():
     return c
 
 
+def case_fixed_distance():
+    """luminosity_distance FIXED by its prior (DeltaFunction): the reference's constant z(d_L) grid still applies
+    the redshift of that distance (model.py:255-267 with get_cosmo_grids(d, d)) -- time stretch and K-correction."""
+    names = ["KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"]
+    c = _base(seed=8334, batch=32, names=names)
+    d = 40.0
+    z = float(np.interp(d, *c["cosmo_grid"]))
+    c["fixed"] = {"luminosity_distance": d}
+    c["cosmo_grid"] = (np.full(50, d), np.full(50, z))          # what get_cosmo_grids(d, d) returns
+    return c
+
+
+def case_conversions():
+    """Every device conversion slot: KNtheta from theta_jn (folded to [0, pi/2], conversion.py:119-126) and the
+    log10_ alias of a linear mass (model.py:276-281)."""
+    names = ["luminosity_distance", "KNphi", "theta_jn", "timeshift", "mej_dyn", "log10_mej_wind"]
+    return _base(seed=8434, batch=32, names=names)
+
+
+def case_conversions_cos():
+    """KNtheta from cos_theta_jn; both masses linear."""
+    names = ["luminosity_distance", "KNphi", "cos_theta_jn", "timeshift", "mej_dyn", "mej_wind"]
+    return _base(seed=8534, batch=32, names=names)
+
+
 def case_small_hidden():
     """Tiny surrogate (NH=64) for fast pure-Python loops."""
     return _base(seed=8234, n_hidden=64, batch=16)
@@ -160,6 +185,9 @@ CASES = {
     "edges": case_edges,
     "c4_shape": case_c4_shape,
     "small_hidden": case_small_hidden,
+    "fixed_distance": case_fixed_distance,
+    "conversions": case_conversions,
+    "conversions_cos": case_conversions_cos,
 }
 
 
@@ -181,8 +209,7 @@ def weights_digest(svd):
 
 
 # ---------------------------------------------------------------------------------------
-# Shape cases without golden vectors: they exercise geometry branches of the HIP path
-# (lanes per sample, ring wrap-around, KP = 2) and are checked against the oracle only.
+# Shape cases: they exercise geometry branches of the HIP path (lanes per sample, ring wrap-around, KP = 2).
 # ---------------------------------------------------------------------------------------
 def case_fast_many_filters():
     """10 filters, 1 ... 128 epochs each: every lanes-per-sample variant of the fast path
@@ -203,8 +230,8 @@ def case_fast_np6():
 
 def case_many_points():
     """One filter with 150 epochs next to small ones: three data per lane (a second pass over slot pairs)."""
-    filters = ["a", "b", "c"]
-    counts = dict(a=12, b=150, c=20)
+    filters = ["a", "b", "d"]          # (not "c": the reference reads that name as the ATLAS cyan average of g and r)
+    counts = dict(a=12, b=150, d=20)
     return _base(seed=9434, filters=filters, counts=counts, batch=24, upper_limit_filter="b")
 
 
@@ -238,6 +265,8 @@ def case_log_grid():
     return c
 
 
+#: geometry cases: the reference runs all of them unchanged except `extinction_limit` (its dust law is third-party),
+#: so they are golden cases too (tools/make_golden.py writes tests/golden/<name>.npz for every entry of CASES)
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
@@ -247,3 +276,4 @@ SHAPE_CASES = {
     "extinction_limit": case_extinction_limit,
     "log_grid": case_log_grid,
 }
+CASES.update({k: v for k, v in SHAPE_CASES.items() if k != "extinction_limit"})

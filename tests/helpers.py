@@ -10,7 +10,7 @@ def engine_from_case(case, device=0):
     if not isinstance(lim, dict):
         lim = {f: float(lim) for f in obs}
     return EMEngine(case["svd"], case["model_filters"], case["model_parameters"], case["names"],
-                    sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
+                    fixed=case.get("fixed"), sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
                     data=case["data"], observed_filters=obs,
                     sources=resolve_sources(obs, case["model_filters"],
                                             known_filters=[f for f in obs if f not in FILTER_AVERAGES]),

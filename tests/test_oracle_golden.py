@@ -27,7 +27,7 @@ def test_logl_matches_reference(loaded, use_scipy):
     name, case, gold = loaded
     lik = build_oracle_likelihood(case, use_scipy=use_scipy)
     n = len(case["theta"]) if use_scipy else min(len(case["theta"]), 24)
-    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:n])
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:n], case.get("fixed"))
     want = gold["logl"][:n]
     floor = want == orc.LOGL_FLOOR
     assert np.array_equal(got == orc.LOGL_FLOOR, floor)
@@ -38,7 +38,7 @@ def test_stages_match_reference(loaded):
     name, case, gold = loaded
     lik = build_oracle_likelihood(case)
     for i in range(min(N_STAGE_ROWS, len(case["theta"]))):
-        p = dict(zip(case["names"], (float(v) for v in case["theta"][i])))
+        p = dict(zip(case["names"], (float(v) for v in case["theta"][i])), **(case.get("fixed") or {}))
         p = lik.model.parameter_conversion(p)
         obs_times, lc = lik.model.gen_detector_lc(p)
         np.testing.assert_allclose(obs_times, gold[f"s{i}_obs_times"], rtol=1e-15)

@@ -1,5 +1,6 @@
 """Re-run the reference's own source (when /root/reference is present, i.e. in the
-build container) and check it still reproduces the committed golden vectors."""
+build container) and check it still reproduces EVERY committed golden vector: all SVD cases
+(every row), the Me2017 model (config 1) and the combined model (config 3 shape)."""
 import os
 
 import numpy as np
@@ -11,13 +12,34 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/nmma"),
                                 reason="reference tree not available (GPU box)")
 
 
-@pytest.mark.parametrize("name", ["c2_default", "edges", "syserr_time_nodes", "averaging"])
+def _rows(lik, names, theta, fixed=None):
+    return np.array([lik.log_likelihood(dict(zip(names, (float(v) for v in row)), **(fixed or {}))) for row in theta])
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
 def test_reference_reproduces_golden(name):
     from tools.make_golden import build_reference_likelihood
     case = cases.CASES[name]()
     gold = cases.load_golden(name)
     _, lik, _ = build_reference_likelihood(case)
-    n = min(12, len(case["theta"]))
-    got = np.array([lik.log_likelihood(dict(zip(case["names"], (float(v) for v in row))))
-                    for row in case["theta"][:n]])
-    np.testing.assert_allclose(got, gold["logl"][:n], rtol=1e-13)
+    got = _rows(lik, case["names"], case["theta"], case.get("fixed"))
+    assert len(got) == len(gold["logl"])
+    np.testing.assert_allclose(got, gold["logl"], rtol=1e-13)
+
+
+def test_reference_reproduces_me2017_golden():
+    from tests import cases_me2017
+    from tools.make_golden_me2017 import build_reference
+    case = cases_me2017.case_me2017()
+    lik, _ = build_reference(case)
+    got = _rows(lik, case["names"], case["theta"])
+    np.testing.assert_allclose(got, cases.load_golden("me2017")["logl"], rtol=1e-13)
+
+
+def test_reference_reproduces_combined_golden():
+    from tests import cases_combined
+    from tools.make_golden_combined import build_reference
+    case = cases_combined.case_combined()
+    lik, _ = build_reference(case)
+    got = _rows(lik, case["names"], case["theta"])
+    np.testing.assert_allclose(got, cases.load_golden("combined")["logl"], rtol=1e-13)

@@ -99,11 +99,12 @@ def run_case(name):
     names, theta = case["names"], case["theta"]
     out = {"digest": np.float64(cases.weights_digest(case["svd"]))}
     logl = np.empty(len(theta))
+    fixed = case.get("fixed") or {}
     for i, row in enumerate(theta):
-        p = dict(zip(names, (float(v) for v in row)))
+        p = dict(zip(names, (float(v) for v in row)), **fixed)
         logl[i] = lik.log_likelihood(p)
         if i < N_STAGE_ROWS:
-            pc = lik.parameter_conversion(dict(zip(names, (float(v) for v in row))))
+            pc = lik.parameter_conversion(dict(zip(names, (float(v) for v in row)), **fixed))
             obs_times, lc = m.gen_detector_lc(pc)
             out[f"s{i}_obs_times"] = np.asarray(obs_times, float)
             for k, f in enumerate(case["model_filters"]):
@@ -116,7 +117,7 @@ def run_case(name):
     out["logl"] = logl
     # cross-check with the restatement right away
     olik = build_oracle_likelihood(case)
-    ol = orc.log_likelihood_batch(olik, names, theta)
+    ol = orc.log_likelihood_batch(olik, names, theta, fixed)
     rel = np.max(np.abs(ol - logl) / np.maximum(1.0, np.abs(logl)))
     n_floor = int(np.sum(logl == orc.LOGL_FLOOR))
     print(f"{name:20s} B={len(theta):4d} floor={n_floor:3d} "

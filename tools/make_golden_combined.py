@@ -17,8 +17,8 @@ from tests import cases_combined  # noqa: E402
 from tools.make_golden import _KerasStandIn  # noqa: E402
 
 
-def main():
-    case = cases_combined.case_combined()
+def build_reference(case):
+    """(likelihood, combined model) built from the reference's own classes for a tests.cases_combined case."""
     ref = ref_harness.reference_modules()
     ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in case["filters"]]
     ref.utils.M4OPT_INSTALLED = False
@@ -60,6 +60,12 @@ def main():
                                                        light_curve_times=times)
     lik = ref.em_likelihood.EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors,
                                                   filters=list(case["filters"]), detection_limit=np.inf)
+    return lik, comb
+
+
+def main():
+    case = cases_combined.case_combined()
+    lik, comb = build_reference(case)
     names, theta = case["names"], case["theta"]
     logl = np.array([lik.log_likelihood(dict(zip(names, (float(v) for v in row)))) for row in theta])
     olik, _ = cases_combined.oracle_likelihood(case)
