@@ -24,7 +24,8 @@ struct ItemDesc {
     int32_t G, d0, nf, kind;
     int32_t jlo, jhi, identity, same_grid;
     double lim, e_const, ebvc, pad;
-    int32_t fast, has_ul, pad2[2];
+    int32_t fast, has_ul;
+    int32_t ntask[2];         // fast modes: tasks of this item per tile of 16 / 32 samples (index R - 1)
 };
 static_assert(sizeof(ItemDesc) == 24 * 4, "ItemDesc must be ITEM_WORDS words");
 
@@ -40,7 +41,8 @@ struct EmDev {
     int32_t prio_valu, prio_mfma;   // s_setprio of the two roles of em_logl (NMMA_EM_PRIO="v,m"; default 3,0)
     int* watchdog;            // [4] device words: {tripped, code, workgroup*64+wave, value*65536+target} (em_logl hand-off waits)
     int32_t helpers;          // MFMA-role waves join the likelihood workers after their stream (NMMA_EM_HELPERS, default 1)
-    int32_t all_fast;         // every work item takes em_logl's fast path: 1 = basic task, 2 = extended task (else 0)
+    int32_t all_fast;         // every work item takes em_logl's fast path: 1 = lean task (constant systematics, <= 32 points per
+                              // filter, photometry staged in LDS), 2 = extended task (else 0: generic item phase)
     const float* b2;          // [M][16]
     const double* VAt;        // [M][NC][NT]   (transposed: coalesced along the time grid; MODE_LC)
     const double* VA;         // [M][NT][NC]   (rows gathered per datum; MODE_LOGL)
@@ -70,6 +72,7 @@ struct EmDev {
     const double* dsigtot;    // [N]  sqrt(sig^2 + e^2) for NMMA_SYS_CONST filters
     const double* dlogsig;    // [N]  log of the above
     const double* dinvsig;    // [N]  1 / dsigtot (0 for upper limits: infinite sigma)
+    const double* dat4;       // [N][4]  {t, m, 1/sigma_tot, log sigma_tot} per datum (lean fast task: two 16-byte LDS reads)
     const double* lim;        // [O]
     const int32_t* nsrc;      // [O]
     const int32_t* src;       // [O][3]

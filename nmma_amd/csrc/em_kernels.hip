@@ -70,6 +70,7 @@ __device__ __forceinline__ float relu1(float x) {
 // which would move every prefetched weight load back to its use (no latency hiding).
 __device__ __forceinline__ void opaque(f32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void opaque(double& v) { asm volatile("" : "+v"(v)); }
 
 // Hidden units are always split into NSLICE partial sums added in slice order, so the
 // fp32 result does not depend on the launch geometry (R, WPB) chosen for a batch size.
@@ -268,7 +269,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     const int HBS = P.HB / NSLICE;
     const int CPS = HBS / PF;                      // chunks per slice
     gci32p items = as_global(P.items);
-    gci32p idesc = as_global(reinterpret_cast<const int*>(P.item_desc));   // word 4 of a descriptor = G
+    gci32p idesc = as_global(reinterpret_cast<const int*>(P.item_desc));   // words 22, 23 of a descriptor = ntask[R - 1]
     gcf64p pmin = as_global(P.pmin), pinv = as_global(P.pinv);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(uintptr_t)P.wrec, 0, P.wrec_bytes, 0x00020000);
@@ -347,7 +348,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         bool slot_free = k < NBUF;
         auto wait_slot = [&]() {
             if (!slot_free) {
-                sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? TS * idesc[(k - NBUF) * ITEM_WORDS + 4] / 64 : NVW, P.watchdog, 100 + k);
+                sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? idesc[(k - NBUF) * ITEM_WORDS + 22 + (R - 1)] : NVW, P.watchdog, 100 + k);
                 slot_free = true;
             }
         };
@@ -511,7 +512,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.epar = off;  off = align16(off + (all_fast == 2 ? n_sys_slots * TS * 8 : 0));   // extended fast mode: sysv[slot][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
-    L.cdl = off;  off = align16(off + 16 * 4 * 16 * 8);              // per wave (any role): 4 slots x 16 coefficients
+    L.cdl = off;  off = align16(off + 16 * 2 * 4 * 16 * 8);          // per wave (any role): 2 x 4 slots x 16 coefficients
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);     // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
@@ -531,7 +532,8 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     LdsW L{};
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0);
+            // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
@@ -704,8 +706,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             if (L.dat >= 0) {
                 double* dat = reinterpret_cast<double*>(smem + L.dat);
                 const int nd = P.n_data;
-                gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
-                for (int j = vt; j < nd; j += NV) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
+                if constexpr (!EXT) {      // lean task: one {t, m, 1/sigma, ln sigma} record per datum
+                    gcf64p src4 = as_global(P.dat4);
+                    for (int j = vt; j < 4 * nd; j += NV) dat[j] = src4[j];
+                } else {
+                    gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
+                    for (int j = vt; j < nd; j += NV) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
+                }
             }
         }
         {
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             // k % NBUF by LDS-DMA (no registers).  Tasks are claimed well before their item is published, so the
             // copy lands while this wave does stage P and waits for the MLP.  (Sharing the copy among the item's
             // tasks would make them wait for each other: with more tasks per item than free waves that deadlocks.)
-            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), TS * itab[k - NBUF].G / 64, P.watchdog, 800 + k);
+            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), itab[k - NBUF].ntask[R - 1], P.watchdog, 800 + k);
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
             typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
             gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
@@ -1166,7 +1173,207 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
-        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += TS * itab[q].G / 64; if (tt < 24) dbg[104 + tt] = clock64(); }
+        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
+        sync_signal(sync + W + 2 + k, lane);     // one signal per task
+    };
+
+    // ---------------------------------------------------------------------------------
+    // Lean task (FASTM == 1: every item has constant systematics, no detection limit, no extinction, sample_times =
+    // the equally spaced SVD grid, at most 32 points per filter, photometry staged in LDS as {t, m, 1/sigma, ln sigma}).
+    // Straight-line code, two independent slots per lane whose instruction streams the compiler interleaves:
+    //   TYPEB = false (17..32 points): a task = 4 samples x 16 lanes, slot u = datum gi + 16 u of the lane's sample;
+    //   TYPEB = true  (<= 16 points) : a task = 8 samples, slot u = datum gi of sample 8 c + 4 u + g.
+    // Every VALU instruction of a likelihood wave takes issue time from the f32 MFMA stream of its SIMD (f32 MFMA and
+    // VALU share the SIMD's vector pipe: tools/ubench/valu_mix2.hip), and a chain of dependent instructions advances one
+    // instruction per MFMA issued in between -- hence few instructions and two chains per wave.
+    // The bracket of a datum on the sample's observer-frame grid is taken from the index guess without the exact
+    // re-check of the extended task: the guess can differ from np.interp's bracket only when the epoch lies within
+    // ~1e-13 of a grid node, where both brackets give the same value to rounding (linear interpolation is continuous).
+    // ---------------------------------------------------------------------------------
+    auto lean_task = [&](auto typeb_tag, const int k, const int c) {
+        constexpr bool TYPEB = decltype(typeb_tag)::value;
+        const ItemDesc& it = itab[k];
+        const int o = it.o;
+        if (c == 0) {      // this wave stages the item's basis rows (see fast_task)
+            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), itab[k - NBUF].ntask[R - 1], P.watchdog, 800 + k);
+            typedef __attribute__((address_space(3))) unsigned char* lds_bp;
+            typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+            gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
+            lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
+            for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
+                __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
+        }
+        typedef const __attribute__((address_space(3))) double* lds_cdp;
+        typedef const __attribute__((address_space(3))) float* lds_cfp;
+        typedef __attribute__((address_space(3))) double* lds_dp;
+        const lds_cfp pbuf = (lds_cfp)(part + (k % NBUF) * (NSLICE * TS * PSTR));
+        // (uniform descriptor words as scalars: comparisons on them are SALU work)
+        const int jlo = __builtin_amdgcn_readfirstlane(it.jlo), jhi = __builtin_amdgcn_readfirstlane(it.jhi);
+        const int d0 = __builtin_amdgcn_readfirstlane(it.d0), nf = __builtin_amdgcn_readfirstlane(it.nf);
+        const int g = lane >> 4, gi = lane & 15;
+        const double st0 = P.st0, inv_dt = P.st_inv_dt;
+        const lds_cdp stl_l = (lds_cdp)stl;
+        typedef __attribute__((ext_vector_type(2))) double f64x2;
+        typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
+        const lds_c2p dat4 = (lds_c2p)(smem + L.dat);
+        const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
+        const bool range_ok = jhi > jlo;
+        constexpr int NSL = 2;
+        int s_[NSL];
+        s_[0] = TYPEB ? 8 * c + g : 4 * c + g;
+        s_[1] = TYPEB ? s_[0] + 4 : s_[0];
+        // ---- stage P (needs only the prologue)
+        // (only what depends on the bracket stays in registers across the wait for the MLP: the photometry record and
+        //  the sample scalars are read again from LDS in stage Q -- LDS reads cost the MFMA stream nothing, registers
+        //  are what limits the workgroup to 16 waves)
+        double dtx_[NSL];
+        bool inside_[NSL], valid_[NSL];
+        int lo_[NSL];
+        lds_c2p D_[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int dd = TYPEB ? gi : gi + 16 * u;
+            valid_[u] = dd < nf;
+            D_[u] = dat4 + 2 * (d0 + (valid_[u] ? dd : 0));
+            const double t = D_[u][0][0];
+            const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
+            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
+            const double t_lo = st_lo * zp1 + tsh, t_hi = st_hi * zp1 + tsh;
+            inside_[u] = range_ok & (t >= t_lo) & (t <= t_hi);
+            int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+            lo = lo > jhi - 1 ? jhi - 1 : lo;
+            lo = lo < jlo ? jlo : lo;
+            dtx_[u] = t - (stl_l[lo] * zp1 + tsh);            // t - x0
+            lo_[u] = lo;
+            asm volatile("" : "+v"(dtx_[u]), "+v"(lo_[u]));   // (evaluated here, before the wait for the MLP)
+        }
+        // ---- stage Q (needs the coefficients of item k)
+        if (c == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sync_signal(sync + 2 * W + 4 + k, lane);     // rows of item k staged
+        }
+        sync_wait(sync + 2 * W + 4 + k, 1, P.watchdog, 350 + k);
+        sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
+        const lds_cfp b2l = (lds_cfp)(tbl + P.tab_off_b2);
+        const float b2v = b2l[gi];
+        constexpr int NCC = TYPEB ? 2 : 1;
+        lds_c2p cc_[NCC];          // the sample's 10 coefficients (fp64) in this wave's LDS slots: [wave][q][g][16]
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) {
+            // slice reduction (fixed order) + bias of the second Dense: lane gi owns coefficient gi of its sample
+            const int s = s_[q];
+            const lds_cfp pp = pbuf + ((s >> 4) * 16 + (s & 15)) * PSTR + gi;
+            float cmine = pp[0];
+#pragma unroll
+            for (int w = 1; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
+            cmine += b2v;
+            const lds_dp cslot = (lds_dp)(cdl + ((wave * 2 + q) * 4 + g) * 16);
+            cslot[gi] = (double)cmine;
+            cc_[q] = (lds_c2p)cslot;
+        }
+        // the two basis rows of every slot, read as 16-byte pairs [VA[2j], VA[2j+1]] (pair 5 = [span, mins]); the four FMA
+        // chains (2 slots x 2 rows) advance together, one pair per step, so that no instruction waits for its predecessor
+        lds_c2p row_[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) row_[u] = (lds_c2p)(tbl) + lo_[u] * 6;
+        double a0_[NSL], a1_[NSL];
+        f64x2 p0_[NSL], p1_[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) { p0_[u] = row_[u][0]; p1_[u] = row_[u][6]; }
+        f64x2 cq_[NCC];
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) cq_[q] = cc_[q][0];
+#pragma unroll
+        for (int jp = 0; jp < 5; ++jp) {
+            f64x2 n0_[NSL], n1_[NSL], nq_[NCC];
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) { n0_[u] = row_[u][jp + 1]; n1_[u] = row_[u][6 + jp + 1]; }
+            if (jp < 4) {
+#pragma unroll
+                for (int q = 0; q < NCC; ++q) nq_[q] = cc_[q][jp + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const f64x2 cq = cq_[TYPEB ? u : 0];
+                if (jp == 0) { a0_[u] = p0_[u][0] * cq[0]; a1_[u] = p1_[u][0] * cq[0]; }
+                else { a0_[u] = fma(p0_[u][0], cq[0], a0_[u]); a1_[u] = fma(p1_[u][0], cq[0], a1_[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const f64x2 cq = cq_[TYPEB ? u : 0];
+                a0_[u] = fma(p0_[u][1], cq[1], a0_[u]); a1_[u] = fma(p1_[u][1], cq[1], a1_[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) { p0_[u] = n0_[u]; p1_[u] = n1_[u]; }
+            if (jp < 4) {
+#pragma unroll
+                for (int q = 0; q < NCC; ++q) cq_[q] = nq_[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double v_[NSL], est_[NSL], m_[NSL];
+        bool ul_[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
+            const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
+            const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * inv_dt;
+            double y0 = a0_[u] * p0_[u][0] + p0_[u][1], y1 = a1_[u] * p1_[u][0] + p1_[u][1];
+            y0 = y0 + dmrc; y1 = y1 + dmrc;
+            const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
+            const double x = (tm[1] - est) * sl[0];
+            double v = (-(x * x) / 2.0 - kNormPdfLogC) - sl[1];
+            opaque(v);                                        // (computed on every lane: no exec-masked region around the chain)
+            // outside the model window est = +inf: truncnorm.logpdf(loc = inf) = NaN (em_likelihood.py:252-256)
+            v = inside_[u] ? v : dnan();
+            ul_[u] = valid_[u] & (sl[0] == 0.0);              // infinite data error: an upper limit
+            v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
+            est_[u] = est; m_[u] = tm[1];
+        }
+        double gp_[NSL] = {0.0, 0.0};
+        if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
+#pragma unroll
+            for (int u = 0; u < NSL; ++u)
+                if (ul_[u]) gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), it.e_const);
+        }
+        lds_dp chi_l = (lds_dp)chi_tot;
+        lds_dp gp_l = (lds_dp)gp_tot;
+        if constexpr (TYPEB) {
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const double chi = group_sum(v_[u], 16);
+                double gp = 0.0;
+                if (it.has_ul) gp = group_sum(gp_[u], 16);
+                if (gi == 0) {
+                    const int s = s_[u];
+                    chi_l[o * TS + s] = chi;
+                    gp_l[o * TS + s] = gp;
+                    if (chi != chi) bad[s] = 1;
+                    if (chi_parts != nullptr && tile0 + s < B) {
+                        chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
+                        gp_parts[(long)o * B + tile0 + s] = gp;
+                    }
+                }
+            }
+        } else {
+            const double chi = group_sum(v_[0] + v_[1], 16);
+            double gp = 0.0;
+            if (it.has_ul) gp = group_sum(gp_[0] + gp_[1], 16);
+            if (gi == 0) {
+                const int s = s_[0];
+                chi_l[o * TS + s] = chi;
+                gp_l[o * TS + s] = gp;
+                if (chi != chi) bad[s] = 1;
+                if (chi_parts != nullptr && tile0 + s < B) {
+                    chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
+                    gp_parts[(long)o * B + tile0 + s] = gp;
+                }
+            }
+        }
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
+        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
     };
 
@@ -1204,7 +1411,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const int e = __builtin_amdgcn_readfirstlane(tmap[t]);
                 k = e >> 8; t = e & 255;
             } else {
-                for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(TS * itab[k].G / 64); if (t < n) break; t -= n; }
+                for (;; ++k) { const int n = __builtin_amdgcn_readfirstlane(itab[k].ntask[R - 1]); if (t < n) break; t -= n; }
             }
 #ifndef NMMA_DBG_NOVALU
             if constexpr (EXT) {
@@ -1213,7 +1420,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 else if (kind == NMMA_SYS_NODES) fast_task(std::integral_constant<int, 2>{}, k, t);
                 else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
-                fast_task(std::integral_constant<int, 0>{}, k, t);
+                if (itab[k].nf <= 16) lean_task(std::true_type{}, k, t);
+                else lean_task(std::false_type{}, k, t);
             }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
@@ -1233,7 +1441,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     }
     // ---- sum over filters + floor (core/base.py:178-182)
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
-        for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? TS * itab[k].G / 64 : NVW, P.watchdog, 700 + k);
+        for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         if (vt < TS && tile0 + vt < B) {
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
