@@ -209,7 +209,7 @@ int32_t nmma_em_last_launch_geometry(const nmma_em_handle* h, int32_t* grid_x, i
  * watchdog of the log-likelihood kernel).  No reference counterpart: the reference is synchronous. */
 int32_t nmma_em_check(nmma_em_handle* h);
 
-/* Diagnostics: run nmma_em_loglike once and return 128 shader-clock stamps taken inside
+/* Diagnostics: run nmma_em_loglike once and return 512 shader-clock stamps taken inside
  * workgroup 0: entries 2k, 2k+1 = MFMA role (wave 0) around the MLP of work item k; 64, 65 = prologue of
  * the likelihood role; 66+2k, 67+2k = stage Q of the first task of item k; for task t < 24 (fast mode):
  * 16+t = claim time, 40+t = claiming wave, 104+t = completion time; 96..101 = stages of the last item's

@@ -440,8 +440,10 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    // (no "old" value: rows a row_mask leaves out are undefined -- they never hold the group's total, see group_sum --
+    //  so no v_mov is needed to initialise the destination)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -1957,4 +1959,5 @@ __global__ void lc_to_detector(const EmDev* __restrict__ Pp, const double* __res
 
 }  // namespace nmma
 
+#include "em_logl_iw.inc"
 #include "em_api.inc"

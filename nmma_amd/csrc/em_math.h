@@ -49,11 +49,14 @@ NM_HD_COLD double apply_slot_op(double v, int op) {
 }
 
 // (RowPtr: any pointer to double -- generic, or an LDS/global address-space pointer in device code)
+// The cheap conversions are evaluated in line; only the transcendental ones take the out-of-line call.
 template <class RowPtr>
 NM_HD double apply_slot(const nmma_slot& s, RowPtr row) {
     if (s.col < 0) return s.value;
     const double v = row[s.col];
     if (s.op == NMMA_OP_IDENT) return v;
+    if (s.op == NMMA_OP_RAD2DEG) return v * 180.0 / kPi;
+    if (s.op == NMMA_OP_DEG2RAD) return v / 180.0 * kPi;
     return apply_slot_op(v, s.op);
 }
 
@@ -116,11 +119,12 @@ NM_HD double ndtr(double a) {
 }
 
 // xsf::log_ndtr (scipy >= 1.9): log(erfcx(-t)/2) - t^2 for x < -1, log1p(-erfc(t)/2) otherwise
-NM_HD_COLD double log_ndtr(double x) {
+NM_HD double log_ndtr_inline(double x) {
     const double t = x * kSqrt1_2;
     if (x < -1.0) return log(erfcx_pos_or_neg(-t) / 2) - t * t;
     return log1p(-erfc(t) / 2);
 }
+NM_HD_COLD double log_ndtr(double x) { return log_ndtr_inline(x); }
 
 // scipy.stats._continuous_distns._log_gauss_mass(a = -inf, b)
 NM_HD_COLD double log_gauss_mass_neginf(double b) {
@@ -156,6 +160,15 @@ NM_HD double upper_limit_term(double m, double est, double sigma_sys) {
     if (x == -dinf()) return 0.0;
     if (x == dinf()) return -dinf();
     return log_ndtr(-x);
+}
+// the same without a function call (for a kernel whose register file is full of in-flight loads: a call would spill)
+NM_HD double upper_limit_term_inline(double m, double est, double sigma_sys) {
+    if (!(sigma_sys > 0)) return dnan();
+    const double x = (m - est) / sigma_sys;
+    if (x != x) return dnan();
+    if (x == -dinf()) return 0.0;
+    if (x == dinf()) return -dinf();
+    return log_ndtr_inline(-x);
 }
 
 // ---------------------------------------------------------------------------

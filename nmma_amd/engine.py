@@ -396,7 +396,7 @@ class EMEngine:
         t = self._dev_theta(theta)
         out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
         torch.cuda.synchronize()
-        stamps = (C.c_int64 * 128)()
+        stamps = (C.c_int64 * 512)()
         L.check(self._lib.nmma_em_debug_timeline(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
                                                  C.c_void_p(out.data_ptr()), stamps), "nmma_em_debug_timeline")
         return np.array(stamps[:], dtype=np.int64)
