@@ -87,7 +87,7 @@ struct EmDev {
     int32_t tab_fast_bytes;   // 1-KiB-rounded prefix [rows | b2] staged per item by em_logl's fast mode
     int32_t tab_bytes, tab_row_stride, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
     const ItemDesc* item_desc;   // [n_items]
-    const int32_t* iw_items;     // [n_items][8] compact copy for em_logl_iw: d0, nf, jlo, jhi, m, o, has_ul, record byte base
+    const int32_t* iw_items;     // [n_items][8] compact copy for em_logl_iw: d0, nf, jlo, jhi, o, has_ul, m, record byte base
     int32_t lc_nf_max, model_kind;   // widest observed filter; enum nmma_model_kind
     const double* nu0;           // [M] filter frequencies (Hz) for analytic blackbody models
     // work items of em_logl: (observed filter, source index, model filter, n sources) x n_items

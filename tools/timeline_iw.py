@@ -2,6 +2,7 @@
 """In-kernel timeline of em_logl_iw, workgroup 0: per wave the shader-clock stamps
 0 entry | 1 after the barrier | 2 prologue done | 3+2k stream k starts | 4+2k stream k ends | 15 before the store."""
 import os, sys
+os.environ.setdefault("NMMA_EM_IW", "1")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmma_amd import synthetic as syn
