@@ -9,8 +9,12 @@ sigma_sys = 1 mag): theta[B, 6] resident in HBM -> logL[B] in HBM.  With N > 1 e
 evaluates its own 4096-point shard (no data-path collective inside the evaluation) and the
 shards' logL are exchanged with ONE RCCL all-gather per step (weak scaling).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Without a launcher (RANK unset) and N > 1 the script starts ``torch.distributed.run`` itself as a CHILD process --
+before anything here touches the GPU -- and relays the child's JSON line.  ``--scaling weak`` (default) keeps 4096
+live points per GPU; ``--scaling strong`` splits ONE 4096-point batch over the ranks (north_star's 8-GPU target).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
 MLP on the f32 MFMA pipe, SVD reconstruction, interpolation and likelihood terms in one launch)
@@ -35,17 +39,35 @@ BATCH_PER_GPU = 4096
 N_THETA_SETS = 8
 
 
-def _measured_traffic():
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json)."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)["bytes_per_launch"]
-    except Exception:
-        return None
+def _profiled_traffic():
+    """HBM bytes per launch from the newest committed PMC passes (profiles/rNN_hbm_traffic.json); NOT measured in
+    this run -- the line says so in roofline.traffic_source."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    for path in reversed(paths):
+        try:
+            with open(path) as fh:
+                return json.load(fh)["bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
-TRAFFIC = _measured_traffic()
+TRAFFIC, TRAFFIC_SOURCE = _profiled_traffic()
+
+
+def _relaunch_under_torchrun(args):
+    """--gpus N > 1 without a launcher: run N ranks as a child of this (GPU-untouched) process, relay its output."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def main():
@@ -56,7 +78,14 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="live points per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch live points per GPU; strong: one --batch-point batch split over the ranks")
+    ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)   # child of the all-cores baseline
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return _cpu_worker(args.cpu_worker)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _relaunch_under_torchrun(args)
 
     import numpy as np
     import torch
@@ -64,16 +93,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # test mode (1-GPU boxes): all ranks on device 0, logL exchanged over gloo -- exercises the launcher, the sharding and
+    # the JSON plumbing of the N > 1 path; the line says so in config.exchange
+    share_gpu = os.environ.get("NMMA_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = world > 1 or os.environ.get("NMMA_BENCH_FORCE_DIST") == "1"   # (1-rank exercise of the exchange path)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from nmma_amd import synthetic as syn
     from tests import cases
@@ -81,19 +118,35 @@ def main():
 
     case = cases.case_c2_default()          # model + photometry of BASELINE config 2
     eng = engine_from_case(case, device=local_rank)
-    B = args.batch
+    if args.scaling == "strong":
+        from nmma_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(args.batch, world, rank)
+        B = hi - lo
+    else:
+        B = args.batch
+    global_batch = args.batch if args.scaling == "strong" else world * args.batch
     dev = torch.device(f"cuda:{local_rank}")
     thetas = [torch.as_tensor(syn.draw_theta(1000 + 97 * rank + i, B, case["names"])[1], device=dev)
               for i in range(N_THETA_SETS)]
     out = torch.empty(B, dtype=torch.float64, device=dev)
-    gathered = torch.empty(world * B, dtype=torch.float64, device=dev) if use_dist else None
+    slot = -(-global_batch // world)         # equal-sized all-gather slots (ragged strong-scaling shards are padded)
+    send = torch.zeros(slot, dtype=torch.float64, device=dev) if use_dist else None
+    gathered = torch.empty(world * slot, dtype=torch.float64, device=dev) if use_dist else None
 
     def step(i):
         eng.loglike(thetas[i % N_THETA_SETS], out=out)
         if use_dist:
             # blocking form on purpose: an overlapped variant (second stream + events, or async_op) costs ~60 us of
             # host work per step in torch.distributed -- more than the 32 us kernel it would hide the collective behind
-            dist.all_gather_into_tensor(gathered, out)
+            if share_gpu:
+                send[:B] = out
+                parts = [torch.empty(slot, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, send.cpu())
+            elif slot == B:
+                dist.all_gather_into_tensor(gathered, out)
+            else:
+                send[:B] = out
+                dist.all_gather_into_tensor(gathered, send)
 
     for i in range(args.warmup):
         step(i)
@@ -127,36 +180,113 @@ def main():
 
     if rank == 0:
         geom = eng.last_launch_geometry()
-        evals = world * B * args.steps
+        evals = global_batch * args.steps
         fused_ms = prof["fused_ms_total"] / max(1, prof["n_launches"])
         achieved = eng.flops_per_eval * B / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None
         line = {
             "metric": "log-likelihood evals/sec (Bu2019lm, AT2017gfo filters)",
             "value": evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 MLP + f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 MLP + f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: Bu2019lm SVD surrogate (NP=4, NH=2048, NC=10, NT=211), "
                                    "AT2017gfo 6-filter synthetic photometry (99 epochs, 1 upper limit), "
                                    f"batch={B} live points per GPU, sigma_sys=1, detection_limit=inf",
-                       "batch_per_gpu": B, "global_batch": world * B,
-                       "exchange": "RCCL all_gather of logL per step" if world > 1 else "none",
+                       "batch_per_gpu": B, "global_batch": global_batch,
+                       "exchange": ("gloo all_gather (TEST MODE: ranks share one GPU)" if share_gpu else
+                                    "RCCL all_gather of logL per step") if world > 1 else "none",
                        "launch": geom},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
-                         "traffic": TRAFFIC, "kernel": "em_logl", "kernel_ms": fused_ms,
+                         "traffic": TRAFFIC, "traffic_source": (f"{TRAFFIC_SOURCE}: rocprofv3 --pmc passes of this command, "
+                                                                "not collected in this run") if TRAFFIC_SOURCE else None,
+                         "kernel": "em_logl", "kernel_ms": fused_ms,
                          "kernel_launches_timed": prof["n_launches"], "flops_per_eval": eng.flops_per_eval,
-                         "traffic_unit": "bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
-                                         "rocprofv3 --pmc, profiles/r01_*)"},
+                         "traffic_unit": "bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"},
         }
-        if not args.no_cpu_baseline:
+        if world == 1:
+            line["host_call_ms"] = host_call_ms(eng, case, syn)
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_call_ms(eng, case, syn):
+    """PCIe-inclusive cost of the reference-shaped call: numpy theta in host memory -> logL in host memory
+    (nmma_em_loglike_host), for the full batch and for the single point an unmodified sampler sends.  Never `value`."""
+    import numpy as np
+    res = {}
+    for b in (4096, 1):
+        th = np.ascontiguousarray(syn.draw_theta(4321, b, case["names"])[1])
+        for _ in range(5):
+            eng.loglike(th)
+        n = 50 if b > 1 else 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.loglike(th)
+        res[f"batch_{b}"] = 1e3 * (time.perf_counter() - t0) / n
+    return res
+
+
+def _oracle_rows():
+    from nmma_amd import synthetic as syn
+    from tests import cases
+    from tests.helpers import oracle_from_case
+    case = cases.case_c2_default()
+    lik = oracle_from_case(case, use_scipy=True)
+    names, theta = syn.draw_theta(555, 4096, case["names"])
+    return lik, [dict(zip(names, (float(v) for v in r))) for r in theta]
+
+
+def _cpu_worker(budget_s):
+    """Child process of cpu_baseline_all_cores: the 1-core loop, prints `evals seconds`."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    lik, rows = _oracle_rows()
+    for r in rows[:10]:
+        lik.log_likelihood(r)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        lik.log_likelihood(rows[n % len(rows)])
+        n += 1
+    print(f"{n} {time.perf_counter() - t0}", flush=True)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_all_cores(budget_s):
+    """The MPI task farm of the reference (one likelihood per rank, core/mpi_setup.py:651-667) as independent
+    single-threaded processes, one per host core -- children that never touch the GPU."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    budget = min(budget_s, 10.0)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(cores)]
+    total, slowest = 0, 0.0
+    for pr in procs:
+        out, _ = pr.communicate()
+        try:
+            n, dt = out.split()[-2:]
+            total += int(n); slowest = max(slowest, float(dt))
+        except (ValueError, IndexError):
+            pass
+    return {"value": total / slowest if slowest > 0 else None, "unit": "evals/s", "cores": cores, "cpu_model": _cpu_model(),
+            "kind": "port", "sample": f"{cores} independent single-threaded processes x {budget:.0f} s of the same loop"}
 
 
 def cpu_baseline(case, budget_s):
@@ -183,7 +313,7 @@ def cpu_baseline(case, budget_s):
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits()
-    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+    return {"value": n / dt, "unit": "evals/s", "cores": 1, "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{n} evaluations cycling through the 4096 live points of the same workload, one parameter vector per call "
                       f"({dt:.1f} s, numpy fp32 MLP + scipy.stats as in the reference)"}
 

@@ -142,10 +142,31 @@ class EMTransientLikelihood(NMMALikelihood):
         """Batched ``log_likelihood``: every row of ``theta`` is one parameter vector.
         Conversions (KNtheta <- inclination_EM, log10 aliases), z(d_L), distance modulus,
         systematics and the floor are all applied on the device."""
+        out = self.sub_model.log_likelihood_batch(theta, names, external_lc)
         if self.constraints:
-            raise NotImplementedError("Constraint priors are evaluated per sample by the sampler; "
-                                      "use log_likelihood() or filter theta beforehand")
-        return self.sub_model.log_likelihood_batch(theta, names, external_lc)
+            out = self._apply_constraints_batch(out, theta, names)
+        return out
+
+    def _apply_constraints_batch(self, out, theta, names):
+        """core/base.py:67-68, :77-82 for a batch: the conversion functions run on columns (they are numpy-vectorised),
+        every Constraint's ``prob`` is evaluated on its derived column, and rows whose product is 0 get the floor."""
+        import torch
+        cols = list(names) if names is not None else self.sub_model.engine().parameter_names
+        th = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta, dtype=float)
+        params = {n: th[:, i] for i, n in enumerate(cols)}
+        _, fixed = self.sub_model.sampling_layout()
+        for key, val in fixed.items():
+            params.setdefault(key, np.full(len(th), val))
+        params = self.parameter_conversion(params)
+        ok = np.ones(len(th), dtype=bool)
+        for key, con in self.constraints.items():
+            ok &= np.asarray(con.prob(np.asarray(params[key])), dtype=float) > 0
+        if isinstance(out, torch.Tensor):
+            mask = torch.as_tensor(~ok, device=out.device)
+            return torch.where(mask, torch.full_like(out, LOGL_FLOOR), out)
+        out = np.array(out, dtype=float, copy=True)
+        out[~ok] = LOGL_FLOOR
+        return out
 
     def parameter_names(self):
         return self.sub_model.sampling_layout()[0]

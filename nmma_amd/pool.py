@@ -11,7 +11,9 @@ Usage with dynesty / parallel-bilby style drivers::
                                     pool=pool, queue_size=pool.size, use_pool={"loglikelihood": True})
 
 ``pool.map(pool.log_likelihood, thetas)`` recognises its own callable and sends the list
-to the GPU as one batch; any other function is mapped serially on the host.
+to the GPU as one batch; ``pool.map(walker, sampler_arguments)`` with a lock-step walker
+(:class:`nmma_amd.sampler.LockstepEnsembleWalk`, the ``sample=`` object) advances all chains of the queue
+together, one launch per MCMC step; any other function is mapped serially on the host.
 """
 from __future__ import annotations
 
@@ -19,10 +21,11 @@ import numpy as np
 
 
 class GPUPool:
-    def __init__(self, likelihood, queue_size=4096, names=None):
+    def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None):
         self.likelihood = likelihood
         self.size = int(queue_size)
         self.names = names
+        self.prior_transform_many = prior_transform_many     # e.g. nmma_amd.sampler.BatchedPriorTransform
         self.n_batches = 0
         self.n_evals = 0
 
@@ -64,6 +67,10 @@ class GPUPool:
             return []
         if getattr(func, "__self__", None) is self and getattr(func, "__func__", None) is GPUPool.log_likelihood:
             res = list(self.log_likelihood_many(items))
+        elif hasattr(func, "run_many"):
+            # a lock-step walker (nmma_amd.sampler.LockstepEnsembleWalk) as dynesty's `sample=` object: the queue of
+            # chains advances together, one likelihood launch per MCMC step
+            res = func.run_many(items, self.log_likelihood_many, self.prior_transform_many)
         else:
             res = [func(it) for it in items]
         if callback is not None:
