@@ -204,9 +204,8 @@ def main():
                          "kernel_launches_timed": prof["n_launches"], "flops_per_eval": eng.flops_per_eval,
                          "traffic_unit": "bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"},
         }
-        if world == 1:
+        if not args.no_cpu_baseline and world == 1:      # (the profiled command lines pass --no-cpu-baseline: device launches only)
             line["host_call_ms"] = host_call_ms(eng, case, syn)
-        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)

@@ -218,6 +218,10 @@ __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
 // A wait that does not complete within ~2^20 polls (tens of milliseconds; a healthy launch needs
 // microseconds) records where it was stuck in the handle's watchdog words and gives up, so that a
 // protocol bug surfaces as an error code from the C ABI instead of a hung GPU.
+// Set by a wait that gave up (one word of static LDS per workgroup, zeroed before the workgroup's first barrier): the
+// epilogue then writes the floor for the whole tile instead of whatever the unfinished hand-off left behind.
+__shared__ int g_wd_trip;
+
 __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog_generic = nullptr, const int code = 0) {
     g_ip watchdog = (g_ip)(uintptr_t)watchdog_generic;
     // Every VALU instruction of a polling wave takes an issue slot from the MFMA waves of its SIMD (a poll is
@@ -226,6 +230,7 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
     while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
         __builtin_amdgcn_s_sleep(6);
         if (++spins > (1 << 18)) {
+            if ((threadIdx.x & 63) == 0) g_wd_trip = 1;
             if (watchdog_generic != nullptr && (threadIdx.x & 63) == 0) {
                 watchdog[0] = 1; watchdog[1] = code; watchdog[2] = (int)blockIdx.x * 64 + (int)(threadIdx.x >> 6);
                 watchdog[3] = __hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 65536 + target;
@@ -577,6 +582,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
     for (int j = tid; j < 3 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
+    if (tid == 0) g_wd_trip = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
@@ -1448,7 +1454,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
             for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
             double tot = c + g;
-            const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt);
+            const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
             if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
             out[tile0 + vt] = tot;
         }

@@ -290,7 +290,7 @@ class EMEngine:
         import torch
         if isinstance(theta, torch.Tensor):
             t = theta
-            if t.dtype != torch.float64 or not t.is_cuda:
+            if t.dtype != torch.float64 or not t.is_cuda or t.device.index != self.device:
                 t = t.to(device=f"cuda:{self.device}", dtype=torch.float64)
         else:
             t = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(f"cuda:{self.device}")
@@ -298,10 +298,16 @@ class EMEngine:
             raise L.NMMAHipError(f"theta must be [B, >={len(self.parameter_names)}], got {tuple(t.shape)}")
         return t.contiguous()
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
+        """torch's current stream OF THE HANDLE'S DEVICE (the C side launches there)."""
         import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_out(self, out, n):
+        import torch
+        if (not isinstance(out, torch.Tensor) or out.dtype != torch.float64 or not out.is_cuda
+                or out.device.index != self.device or out.numel() < n or not out.is_contiguous()):
+            raise L.NMMAHipError(f"out must be a contiguous float64 tensor on cuda:{self.device} with >= {n} elements")
 
     def loglike(self, theta, out=None):
         """logL for every row of ``theta[B, D]``.  torch CUDA tensor in -> torch tensor out
@@ -319,6 +325,8 @@ class EMEngine:
         t = self._dev_theta(theta)
         if out is None:
             out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        else:
+            self._check_out(out, t.shape[0])
         L.check(self._lib.nmma_em_loglike(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
                                           C.c_void_p(out.data_ptr()), self._stream()), "nmma_em_loglike")
         return out

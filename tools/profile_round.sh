@@ -1,16 +1,29 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun): bench line + rocprofv3 kernel stats + PMC passes for em_logl.
-# Usage: tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>_*)
-tag=${1:-r01}
-o=gpurun_out
-mkdir -p $o
+# Runs ON THE GPU BOX (gpurun): the evidence behind the bench line, written under gpurun_out/<tag>/ (wiped first) and
+# condensed by tools/summarize_profiles.py into the tracked profiles/<tag>_*:
+#   bench line (with cpu baselines)          -> <tag>/bench_line.json
+#   rocprofv3 --kernel-trace --stats         -> <tag>/stats_<what>/   for: bench (config 2, lean task), c2_dt05_limit @ 4096
+#                                               (extended task), c4_shape @ 8192 (config 4 shape), models (Me2017, combined,
+#                                               em_fused outputs), bench with the opt-in in-wave kernel
+#   rocprofv3 --pmc (separate passes)        -> <tag>/pmc_<set>/      for the bench command
+# Under rocprofv3 the program goes directly after `--` (no env / bash -c hops).
+tag=${1:-r02}
+o=gpurun_out/$tag
+rm -rf $o; mkdir -p $o
 export TMPDIR=/tmp
-python3 bench.py --steps 200 --warmup 20 > $o/${tag}_bench_line.json 2> $o/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/${tag}_stats.log 2>&1
+python3 bench.py --steps 200 --warmup 20 > $o/bench_line.json 2> $o/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05 -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
+export NMMA_EM_IW=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_iw -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_iw.log 2>&1
+unset NMMA_EM_IW
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_pmc_sq2.log 2>&1
-find $o/${tag}_stats $o/${tag}_pmc_* -name "*.csv" | head -40
-cat $o/${tag}_bench_line.json
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $o/pmc_sq3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq3.log 2>&1
+find $o -name "*kernel_stats.csv" | head
+cat $o/bench_line.json

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Turn the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>_*) into the tracked
-summaries under profiles/: kernel stats CSV, PMC means, HBM traffic per launch, bench line."""
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh, which wipes the directory first) into the tracked
+summaries under profiles/: one kernel-stats CSV per profiled command, PMC means per dispatch of the likelihood kernel,
+HBM traffic per launch, the bench line."""
 import collections
 import csv
 import glob
@@ -10,27 +11,43 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+def newest(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+for what in ("bench", "dt05", "c4", "models", "iw"):
+    f = newest(os.path.join(src, f"stats_{what}", "**", "*kernel_stats.csv"))
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_{what}_kernel_stats.csv"))
+        rows = list(csv.DictReader(open(f)))
+        top = sorted(rows, key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))[:4]
+        for r in top:
+            print(f"{what:7s} {r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs']) / 1e3:9.2f} us")
 
 pmc = {}
-for sub in ("FETCH_SIZE", "WRITE_SIZE", "sq", "sq2"):
-    for f in glob.glob(os.path.join(src, f"{tag}_pmc_{sub}", "**", "*counter_collection.csv"), recursive=True):
-        acc = collections.defaultdict(list)
-        for row in csv.DictReader(open(f)):
-            if "em_logl" in row.get("Kernel_Name", ""):
-                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for k, v in sorted(acc.items()):
-            v = v[5:] if len(v) > 10 else v          # drop the warm-up launches
-            pmc[k] = {"n_dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+for sub in ("FETCH_SIZE", "WRITE_SIZE", "sq", "sq2", "sq3"):
+    f = newest(os.path.join(src, f"pmc_{sub}", "**", "*counter_collection.csv"))
+    if not f:
+        continue
+    acc = collections.defaultdict(list)
+    rows = [r for r in csv.DictReader(open(f)) if "em_logl" in r.get("Kernel_Name", "")]
+    # the bench also times single-point host calls: keep the full-batch launches (largest grid) only
+    full = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for row in rows:
+        if int(row["Grid_Size"]) == full:
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        v = v[5:] if len(v) > 10 else v          # drop the warm-up launches
+        pmc[k] = {"n_dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
 pmc["_note"] = ("rocprofv3 --pmc (separate passes, --kernel-trace only) on `python3 bench.py --steps 20 --warmup 5 "
-                "--no-cpu-baseline`; kernel em_logl, B=4096, per dispatch over the whole GPU (1024 SIMDs)")
+                "--no-cpu-baseline`; likelihood kernel em_logl, B=4096, per dispatch over the whole GPU (1024 SIMDs)")
 json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_em_logl_summary.json"), "w"), indent=1)
 
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -41,14 +58,17 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     traffic = {
         "bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 20 "
-                  "--warmup 5`, kernel em_logl, B=4096; FETCH_SIZE in KiB doubled per MI355X_MICROARCH.md (HBM section)",
+                  "--warmup 5`, likelihood kernel, B=4096; FETCH_SIZE in KiB doubled per MI355X_MICROARCH.md (HBM section)",
         # theta in + logL out + every weight/table byte once
         "algorithmic_bytes": 1088432,
     }
     json.dump(traffic, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
-line = os.path.join(src, f"{tag}_bench_line.json")
+line = os.path.join(src, "bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(dst, f"{tag}_bench_line.json"))
-print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:400] if stats else "no stats")
+for name in ("stats_models.log", "stats_dt05.log", "stats_c4.log"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps({k: v["mean"] for k, v in pmc.items() if isinstance(v, dict)}, indent=1))
