@@ -195,6 +195,19 @@ int32_t nmma_em_loglike_lc(nmma_em_handle* h, const double* theta_dev, int64_t B
 int32_t nmma_lc_stack(nmma_em_handle* h, const double* const* lc_dev_sets, int32_t n_models, int64_t B,
                       double* out_dev, void* stream);
 
+/* One sub-model's light curves moved onto the handle's sample_times and filter list, as the combined model does before it
+ * stacks (model.py:1434-1448 + the per-filter lookup of stack_magnitudes, :1490-1503):
+ *   lc_src_dev[B][n_src_filters][n_src_times] on src_times_host[n_src_times] (increasing);
+ *   for output filter m: n_sources_host[m] in 0..3 source filters src_index_host[m*3 + k] of the sub-model --
+ *     1 = the filter itself (or its renamed equivalent), 2-3 = arithmetic mean of helper bands (utils.average_mags),
+ *     0 = the sub-model has nothing for this filter (+inf everywhere: it does not contribute to the flux sum);
+ *   every source curve is interpolated with np.interp over its FINITE nodes, +inf outside them and when fewer than two
+ *   are finite (autocomplete_data(..., extrapolate=np.inf), utils.py:626-645).
+ * out_dev[B][M][NS] in the handle's layout.  The three small host arrays are copied per call. */
+int32_t nmma_lc_regrid(nmma_em_handle* h, const double* lc_src_dev, int32_t n_src_filters, int32_t n_src_times,
+                       const double* src_times_host, const int32_t* src_index_host, const int32_t* n_sources_host,
+                       int64_t B, double* out_dev, void* stream);
+
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                              float* coeff_dev, void* stream);

@@ -19,7 +19,9 @@ class MultiFilterTransient:
     def __init__(self, filters, light_curve_model, light_curve_data, systematics_handler, priors,
                  detection_limit, verbose):
         self.observed_filters = list(filters)
-        known = set(getattr(light_curve_model, "filters", None) or []) | \
+        # (stand-in for the bandpass registry the reference consults: every model / observed filter name EXCEPT the averaged
+        #  ones -- w, o, c, V, I ... are never registry names, so they keep their helper-band mean even when a model lists them)
+        known = {f for f in (getattr(light_curve_model, "filters", None) or []) if f not in utils.FILTER_AVERAGES} | \
             {f for f in self.observed_filters if f not in utils.FILTER_AVERAGES}
         self.model_filter_mapping, self.obs_average_mapping = utils.get_filter_name_mapping(
             self.observed_filters, known)

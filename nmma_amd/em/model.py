@@ -371,25 +371,55 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
 
 
 class CombinedLightCurveModelContainer(_TensorModelMixin):
-    """Flux sum of several models on a common ``sample_times`` grid and filter list
-    (reference: model.py:1342-1510).  Restrictions of this implementation: every sub-model
-    uses the same sample_times and filters (the canonical CLI case ``--em-tmin/--em-tmax/--em-tstep``)."""
+    """Flux sum of several models (reference: model.py:1342-1510).  Sub-models may bring their own ``sample_times``
+    and filter lists: the combination lives on the sorted union of the time grids (:1372-1374) and on the union of the
+    filters (:1368); every sub-model's curves are interpolated onto the union grid with +inf outside their finite
+    nodes (:1440-1448) and looked up per filter as ``stack_magnitudes`` does (:1490-1503: the filter itself or its
+    renamed equivalent, else the mean of the helper bands of an averaged filter, else no contribution)."""
 
     gpu_model_kind = "external"
 
     def __init__(self, models, cosmo_grid=None, device=0):
+        from . import utils
         self.lc_models = list(models)
         self.model = [m.model for m in self.lc_models]
         first = self.lc_models[0]
-        for m in self.lc_models[1:]:
-            if list(m.filters) != list(first.filters) or not np.array_equal(m.model_times, first.model_times):
-                raise ValueError("CombinedLightCurveModelContainer: sub-models must share filters and sample_times")
-        self.filters = list(first.filters)
-        self.model_times = np.asarray(first.model_times, float)
+        self.filters = []
+        for m in self.lc_models:
+            for f in m.filters:
+                if f not in self.filters:
+                    self.filters.append(f)
+        self.all_filters = list(self.filters)
+        self.model_times = np.array(sorted(set().union(*[np.asarray(m.model_times, float).tolist() for m in self.lc_models])))
         self.model_parameters = []
         self.cosmo_grid = cosmo_grid if cosmo_grid is not None else getattr(first, "cosmo_grid", None)
         self.device = device
         self._lc_engine, self._lc_names = None, None
+        # per sub-model: None when it already lives on the union grid with the union filters, else the source indices of
+        # every union filter in the sub-model's own filter list
+        averaging = utils.FILTER_AVERAGES
+        direct = {}
+        for f in self.filters:
+            if f in utils.FILTER_RENAMES:
+                direct[f] = utils.FILTER_RENAMES[f]
+            elif f not in averaging:
+                direct[f] = f
+        self._regrid = []
+        for m in self.lc_models:
+            mf = list(m.gpu_filters) if hasattr(m, "gpu_filters") else list(m.filters)
+            same = mf == self.filters and np.array_equal(np.asarray(m.model_times, float), self.model_times)
+            if same:
+                self._regrid.append(None)
+                continue
+            srcs = []
+            for f in self.filters:
+                if f in direct and direct[f] in mf:
+                    srcs.append([mf.index(direct[f])])
+                elif f in averaging and all(g in mf for g in averaging[f]):
+                    srcs.append([mf.index(g) for g in averaging[f]])
+                else:
+                    srcs.append([])
+            self._regrid.append(srcs)
 
     def __repr__(self):
         return "Combination of " + " and ".join(repr(m) for m in self.lc_models)
@@ -416,15 +446,28 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         return parameters
 
     def stacked_lightcurves_abs(self, theta, names, external_lc=None, stack_engine=None):
-        """[B, M, NS] flux-summed source-frame curves; ``external_lc`` maps the name of each
-        :class:`ExternalLightCurveModel` to its tensor."""
+        """[B, M, NS] flux-summed source-frame curves on the union grid / filters.  ``external_lc`` maps the name of each
+        :class:`ExternalLightCurveModel` to its tensor ``[B, M_k, NS_k]`` (on that model's own filters and times), or to a
+        pair ``(tensor, ok[B])``: rows with ``ok == False`` are the sub-model's "no light curve for these parameters"
+        (an empty dict in the reference, model.py:1423-1426) and floor the sample."""
         import torch
         external_lc = external_lc or {}
-        sets = []
-        for m in self.lc_models:
-            if isinstance(m, ExternalLightCurveModel):
-                sets.append(torch.as_tensor(external_lc[m.model]).to(f"cuda:{self.device}"))
-            else:
-                sets.append(m.lightcurves_abs(theta, names))
         eng = stack_engine or self._model_engine(names)
-        return eng.stack(sets)
+        sets, failed = [], None
+        for m, plan in zip(self.lc_models, self._regrid):
+            if isinstance(m, ExternalLightCurveModel):
+                val = external_lc[m.model]
+                if isinstance(val, (tuple, list)):
+                    val, ok = val
+                    bad = ~torch.as_tensor(np.asarray(ok, dtype=bool))
+                    failed = bad if failed is None else (failed | bad)
+                lc = torch.as_tensor(val).to(f"cuda:{self.device}")
+            else:
+                lc = m.lightcurves_abs(theta, names)
+            if plan is not None:
+                lc = eng.regrid(lc, np.asarray(m.model_times, float), plan)
+            sets.append(lc)
+        out = eng.stack(sets)
+        if failed is not None and bool(failed.any()):
+            out[failed.to(out.device)] = float("nan")
+        return out

@@ -77,8 +77,10 @@ def resolve_sources(observed_filters, model_filters, known_filters=()):
     Reference quirk kept: helper bands of an averaged filter are looked up in the map
     built from the *observed* filters (em_likelihood.py:330), so each helper must itself
     be observed; and a mapped band the model does not provide is an error."""
-    direct, averaging = get_filter_name_mapping(observed_filters,
-                                                set(known_filters) | set(model_filters))
+    # (an averaged name -- w, o, c, V, I ... -- is never a registry name: it keeps its helper-band mean even when a
+    #  combined model lists a band of that name, utils.py:478-546)
+    direct, averaging = get_filter_name_mapping(
+        observed_filters, {f for f in set(known_filters) | set(model_filters) if f not in FILTER_AVERAGES})
     sources = {}
     for f in observed_filters:
         if f in direct:

@@ -389,6 +389,29 @@ class EMEngine:
                                         self._stream()), "nmma_lc_stack")
         return out
 
+    def regrid(self, lc, src_times, sources):
+        """One sub-model's curves ``lc[B, Ms, NSs]`` (on ``src_times``) moved onto this engine's sample_times and model
+        filters: ``sources[m]`` = list of 0-3 source-filter indices of output filter m (1: the filter itself, 2-3: mean of
+        helper bands, 0: nothing -> +inf).  CombinedLightCurveModelContainer.gen_detector_lc, model.py:1434-1448."""
+        import torch
+        lc = lc.to(device=f"cuda:{self.device}", dtype=torch.float64).contiguous()
+        if lc.dim() != 3 or lc.shape[2] != len(src_times):
+            raise L.NMMAHipError(f"lc must be [B, Ms, {len(src_times)}], got {tuple(lc.shape)}")
+        m = len(self.model_filters)
+        if len(sources) != m:
+            raise L.NMMAHipError("sources needs one entry per model filter of the engine")
+        st = _f64(src_times)
+        idx = np.zeros((m, L.MAX_SOURCES), dtype=np.int32)
+        ns = np.zeros(m, dtype=np.int32)
+        for i, src in enumerate(sources):
+            ns[i] = len(src)
+            idx[i, :len(src)] = src
+        out = torch.empty((lc.shape[0], m, self.n_sample_times), dtype=torch.float64, device=lc.device)
+        L.check(self._lib.nmma_lc_regrid(self._handle, C.c_void_p(lc.data_ptr()), lc.shape[1], lc.shape[2],
+                                         _ptr(st, C.c_double), _ptr(idx, C.c_int32), _ptr(ns, C.c_int32), lc.shape[0],
+                                         C.c_void_p(out.data_ptr()), self._stream()), "nmma_lc_regrid")
+        return out
+
     def coefficients(self, theta):
         """SVD coefficients c[B, M, NC] (fp32), the surrogate output (lightcurve_generation.py:198)."""
         import torch

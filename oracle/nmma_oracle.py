@@ -471,12 +471,20 @@ def log_likelihood_batch(lik: OracleLikelihood, names, theta, fixed=None):
 # ---------------------------------------------------------------------------
 class OracleCombinedModel:
     """CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes
-    (nmma/em/model.py:1411-1459, :1486-1510) for sub-models that share filters."""
+    (nmma/em/model.py:1362-1374, :1411-1459, :1486-1510): union of the sub-models' filters and time grids,
+    per-model re-interpolation with +inf outside, per-filter lookup (direct / renamed name, else the mean of the
+    helper bands of an averaged filter, else the model does not contribute)."""
 
     def __init__(self, models):
         self.lc_models = list(models)
-        self.filters = list(self.lc_models[0].filters)
-        self.model_times = np.array(sorted(set().union(*[m.model_times for m in self.lc_models])))
+        self.filters = []
+        for m in self.lc_models:
+            for f in m.filters:
+                if f not in self.filters:
+                    self.filters.append(f)
+        self.model_times = np.array(sorted(set().union(*[np.asarray(m.model_times, float).tolist() for m in self.lc_models])))
+        # model.py:1370 -- compatible_filters: direct map of the union filters (averaged names are absent from it)
+        self.compatible = {f: _RENAMES.get(f, f) for f in self.filters if f not in _AVERAGES}
         self.good_parameters = True
 
     def parameter_conversion(self, parameters):
@@ -493,13 +501,22 @@ class OracleCombinedModel:
                 return t, lc
             per_model.append(lc)
             times.append(t)
-        connected = np.array(sorted(set().union(*times))) if sample_times is None else times[-1]
+        connected = np.array(sorted(set().union(*[np.asarray(t).tolist() for t in times]))) if sample_times is None else times[-1]
         joint = [{f: autocomplete_data(connected, t, v, extrapolate=np.inf) for f, v in lc.items()}
                  for t, lc in zip(times, per_model)]
         ln10 = np.log(10)
         out = {}
-        for f in self.filters:
-            terms = [-2.0 / 5.0 * ln10 * np.array(j[f]) for j in joint if f in j]
+        for f in self.filters:                      # stack_magnitudes, model.py:1490-1510
+            terms = []
+            for mag in joint:
+                try:
+                    mag_f = mag[self.compatible[f]]
+                except KeyError:
+                    if f in _AVERAGES and all(g in mag for g in _AVERAGES[f]):
+                        mag_f = np.sum([mag[g] for g in _AVERAGES[f]], axis=0) / float(len(_AVERAGES[f]))
+                    else:
+                        continue
+                terms.append(-2.0 / 5.0 * ln10 * np.array(mag_f))
             out[f] = (-5.0 / 2.0 * logsumexp(terms, axis=0) / ln10) if terms else np.full_like(connected, np.inf)
         return connected, out
 

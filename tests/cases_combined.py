@@ -33,3 +33,42 @@ def oracle_likelihood(case, use_scipy=True):
     return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in case["filters"]}),
                                 case["filters"], detection_limit=np.inf, known_filters=case["filters"],
                                 use_scipy=use_scipy), grb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# General combination (model.py:1362-1374, :1434-1448, :1490-1503): the two sub-models bring DIFFERENT time grids and
+# filter lists -- union grid, per-model re-interpolation with +inf outside, per-filter lookup with the averaged-band
+# fallback ("w" is listed by the second model only: both then contribute the mean of their g, r, i).
+# ---------------------------------------------------------------------------------------------------------------
+KN_FILTERS_U = ["g", "r", "i", "z", "y"]
+GRB_FILTERS_U = ["g", "r", "i", "J", "w"]
+OBS_FILTERS_U = ["g", "r", "i", "z", "y", "J", "w"]
+
+
+def case_combined_union(seed=9223, batch=40):
+    mp, svd = syn.make_svd_model(seed, KN_FILTERS_U, model="Bu2019lm")
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    counts = dict(g=13, r=19, i=20, z=18, y=15)
+    times, mags, sigmas = syn.make_photometry(seed + 1, svd, mp, filters=KN_FILTERS_U, counts=counts, cosmo_grid=grid,
+                                              upper_limit_filter="i")
+    rng = np.random.default_rng(seed + 4)
+    for f, n in (("J", 9), ("w", 11)):
+        t = np.sort(rng.uniform(0.6, 13.0, n))
+        base = np.mean([np.interp(t, times[g], mags[g]) for g in ("g", "r", "i")], axis=0)
+        times[f], mags[f], sigmas[f] = t, base + (0.4 if f == "J" else 0.0) + 0.05 * rng.standard_normal(n), rng.uniform(0.03, 0.15, n)
+    names, theta = syn.draw_theta(seed + 2, batch, NAMES[:6])
+    theta = np.concatenate([theta, rng.uniform(-17.5, -14.0, (batch, 1)), rng.uniform(0.8, 1.6, (batch, 1))], axis=1)
+    return dict(model="Bu2019lm", model_parameters=mp, svd=svd, filters=KN_FILTERS_U, grb_filters=GRB_FILTERS_U,
+                observed_filters=OBS_FILTERS_U, sample_times=np.arange(0.1, 20.5, 0.5),
+                grb_times=np.geomspace(0.25, 30.0, 36), cosmo_grid=grid, data=(times, mags, sigmas), names=NAMES, theta=theta)
+
+
+def oracle_likelihood_union(case, use_scipy=True):
+    from oracle import nmma_oracle as orc
+    kn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=case["filters"],
+                            sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = orc.OraclePowerLawModel(case["grb_filters"], case["grb_times"], cosmo_grid=case["cosmo_grid"])
+    comb = orc.OracleCombinedModel([kn, grb])
+    obs = case["observed_filters"]
+    return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in obs}), obs,
+                                detection_limit=np.inf, known_filters=[f for f in obs if f != "w"], use_scipy=use_scipy), grb

@@ -89,3 +89,32 @@ def test_loglike_lc_reproduces_svd_path():
         assert np.array_equal(got == FLOOR, floor), name
         assert rel_err(got[~floor], gold[~floor]).max() <= 1e-6, name
         eng.close()
+
+
+def test_combined_union_grids_and_filter_fallbacks():
+    """The general combination (model.py:1362-1374, :1434-1448, :1490-1503): sub-models with different sample_times
+    and filter lists, an averaged band listed by one model only, a band only one model provides, an early failure."""
+    import torch
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    case = cases_combined.case_combined_union()
+    gold = cases.load_golden("combined_union")
+    _, grb_oracle = cases_combined.oracle_likelihood_union(case)
+    kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"],
+                            model_parameters=case["model_parameters"], sample_times=case["sample_times"],
+                            cosmo_grid=case["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", case["grb_filters"], case["grb_times"])
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
+    assert comb.filters == ["g", "r", "i", "z", "y", "J", "w"]
+    assert len(comb.model_times) == len(set(case["sample_times"]) | set(case["grb_times"]))
+    lik = _likelihood(comb, case, case["observed_filters"])
+    ext = np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), case["grb_times"])[f]
+                              for f in case["grb_filters"]]) for row in case["theta"]])
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    err = rel_err(got, gold["logl"])
+    print(f"combined_union: max rel err {err.max():.3e}")
+    assert not np.any(got == FLOOR) and err.max() <= 1e-6
+    # the sub-model reports "no light curve" for two samples (an empty dict in the reference): floor, others unchanged
+    ok = np.ones(len(ext), dtype=bool)
+    ok[[3, 17]] = False
+    got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
+    assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])

@@ -27,3 +27,19 @@ def test_combined_oracle_matches_golden():
     lik, _ = cases_combined.oracle_likelihood(case)
     got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
     np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)
+
+
+def test_combined_union_oracle_matches_golden():
+    case = cases_combined.case_combined_union()
+    gold = cases.load_golden("combined_union")
+    lik, _ = cases_combined.oracle_likelihood_union(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
+    np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)
+    p = lik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in case["theta"][0]))))
+    tobs, lc = lik.model.gen_detector_lc(p)
+    np.testing.assert_allclose(tobs, gold["s0_obs_times"], rtol=1e-15)
+    for f in ("g", "z", "J", "w"):
+        want = gold[f"s0_app_{f}"]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(lc[f]), fin)
+        np.testing.assert_allclose(lc[f][fin], want[fin], rtol=1e-13)

@@ -18,9 +18,14 @@ from tools.make_golden import _KerasStandIn  # noqa: E402
 
 
 def build_reference(case):
-    """(likelihood, combined model) built from the reference's own classes for a tests.cases_combined case."""
+    """(likelihood, combined model) built from the reference's own classes for a tests.cases_combined case
+    (shared grid / filters, or -- keys grb_filters, grb_times, observed_filters -- the general union case)."""
     ref = ref_harness.reference_modules()
-    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in case["filters"]]
+    grb_filters = list(case.get("grb_filters", case["filters"]))
+    grb_times = case.get("grb_times", case["sample_times"])
+    obs_filters = list(case.get("observed_filters", case["filters"]))
+    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in set(case["filters"]) | set(grb_filters)
+                                                   if n not in ("w", "o", "c", "V", "I", "F606W", "F814W")]
     ref.utils.M4OPT_INSTALLED = False
     grid = case["cosmo_grid"]
     zfun = lambda p: np.interp(p["luminosity_distance"], grid[0], grid[1])
@@ -33,18 +38,18 @@ def build_reference(case):
         svd_ref[f] = d
     kn.model, kn.model_parameters, kn.filters = case["model"], list(case["model_parameters"]), list(case["filters"])
     kn.svd_mag_model, kn.mag_ncoeff, kn.lbol_ncoeff, kn.good_parameters = svd_ref, None, None, True
-    kn.default_filts, kn.lambdas, kn.nu_0s = list(case["filters"]), np.ones(9), np.ones(9)
+    kn.default_filts, kn.lambdas, kn.nu_0s = list(case["filters"]), np.ones(len(case["filters"])), np.ones(len(case["filters"]))
     kn.model_times, kn.redshift_func = case["sample_times"], zfun
     kn.check_vs_priors = lambda priors: None
 
-    helper = orc.OraclePowerLawModel(case["filters"], case["sample_times"])
+    helper = orc.OraclePowerLawModel(grb_filters, grb_times)
 
     class PowerLawGRB(ref.model.LightCurveModelContainer):
         def __init__(self):
             self.model, self.model_parameters = "PLGRB", ["grb_mag0", "grb_slope"]
-            self.filters, self.default_filts = list(case["filters"]), list(case["filters"])
-            self.lambdas = self.nu_0s = np.ones(9)
-            self.good_parameters, self.model_times, self.redshift_func = True, case["sample_times"], zfun
+            self.filters, self.default_filts = list(grb_filters), list(grb_filters)
+            self.lambdas = self.nu_0s = np.ones(len(grb_filters))
+            self.good_parameters, self.model_times, self.redshift_func = True, np.asarray(grb_times, float), zfun
 
         def check_vs_priors(self, priors):
             pass
@@ -56,15 +61,36 @@ def build_reference(case):
     comb = ref.model.CombinedLightCurveModelContainer([kn, PowerLawGRB()])
     times, mags, sigmas = case["data"]
     priors = ref.base.PriorDict({n: object() for n in case["names"]})
-    handler = ref.systematics.FilterSystematicsHandler(list(case["filters"]), error_budget=1.0,
-                                                       light_curve_times=times)
+    handler = ref.systematics.FilterSystematicsHandler(obs_filters, error_budget=1.0, light_curve_times=times)
     lik = ref.em_likelihood.EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors,
-                                                  filters=list(case["filters"]), detection_limit=np.inf)
+                                                  filters=obs_filters, detection_limit=np.inf)
     return lik, comb
+
+
+def run(case, oracle_builder, name, n_stage=3):
+    lik, comb = build_reference(case)
+    names, theta = case["names"], case["theta"]
+    logl = np.array([lik.log_likelihood(dict(zip(names, (float(v) for v in row)))) for row in theta])
+    olik, _ = oracle_builder(case)
+    ol = orc.log_likelihood_batch(olik, names, theta)
+    floor = logl == orc.LOGL_FLOOR
+    assert np.array_equal(ol == orc.LOGL_FLOOR, floor)
+    rel = np.max(np.abs(ol[~floor] - logl[~floor]) / np.maximum(1, np.abs(logl[~floor])))
+    print(f"{name}: B={len(theta)} floor={floor.sum()} logL range ({logl[~floor].min():.2f}, {logl[~floor].max():.2f})"
+          f" oracle-vs-reference max rel diff {rel:.3e}")
+    out = {"logl": logl}
+    for i in range(n_stage):
+        p = lik.parameter_conversion(dict(zip(names, (float(v) for v in theta[i]))))
+        tobs, lc = comb.gen_detector_lc(p)
+        out[f"s{i}_obs_times"] = np.asarray(tobs, float)
+        for k, f in enumerate(comb.all_filters if hasattr(comb, "all_filters") else case["filters"]):
+            out[f"s{i}_app_{f}"] = np.asarray(lc[f], float)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"{name}.npz"), **out)
 
 
 def main():
     case = cases_combined.case_combined()
+    # (the shared-grid golden keeps its original key layout: s<i>_app_<filter index>)
     lik, comb = build_reference(case)
     names, theta = case["names"], case["theta"]
     logl = np.array([lik.log_likelihood(dict(zip(names, (float(v) for v in row)))) for row in theta])
@@ -73,8 +99,7 @@ def main():
     floor = logl == orc.LOGL_FLOOR
     assert np.array_equal(ol == orc.LOGL_FLOOR, floor)
     rel = np.max(np.abs(ol[~floor] - logl[~floor]) / np.maximum(1, np.abs(logl[~floor])))
-    print(f"combined: B={len(theta)} floor={floor.sum()} logL range ({logl[~floor].min():.2f}, {logl[~floor].max():.2f})"
-          f" oracle-vs-reference max rel diff {rel:.3e}")
+    print(f"combined: B={len(theta)} floor={floor.sum()} oracle-vs-reference max rel diff {rel:.3e}")
     out = {"logl": logl}
     for i in range(3):
         p = lik.parameter_conversion(dict(zip(names, (float(v) for v in theta[i]))))
@@ -83,6 +108,7 @@ def main():
         for k, f in enumerate(case["filters"]):
             out[f"s{i}_app_{k}"] = np.asarray(lc[f], float)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "combined.npz"), **out)
+    run(cases_combined.case_combined_union(), cases_combined.oracle_likelihood_union, "combined_union")
 
 
 if __name__ == "__main__":
