@@ -53,22 +53,32 @@ def load_svd_model(path):
 
 
 def _dense_weights_from_h5(path):
-    """Kernel/bias pairs of a two-layer Keras model saved as legacy HDF5."""
+    """(W1, b1, W2, b2) of a Dense -> (Dropout) -> Dense Keras model saved as legacy HDF5
+    (``model_weights/<layer>/<layer>/{kernel,bias}:0``; layers in the order of the ``layer_names`` attribute,
+    nmma/em/training.py:353-364)."""
     import h5py
-    out = []
     with h5py.File(path, "r") as f:
         grp = f["model_weights"] if "model_weights" in f else f
+        names = [n.decode() if isinstance(n, bytes) else str(n) for n in grp.attrs.get("layer_names", list(grp.keys()))]
+        dense = []
+        for ln in names:
+            if ln not in grp:
+                continue
+            found = {}
 
-        def visit(name, obj):
-            if isinstance(obj, h5py.Dataset) and name.endswith(("kernel:0", "bias:0", "kernel", "bias")):
-                out.append((name, np.array(obj)))
-        grp.visititems(visit)
-    kernels = sorted((n, a) for n, a in out if "kernel" in n)
-    biases = sorted((n, a) for n, a in out if "bias" in n)
-    kernels.sort(key=lambda na: na[1].shape[0] != min(k[1].shape[0] for k in kernels))
-    (_, w1), (_, w2) = kernels
-    b1 = next(a for _, a in biases if a.shape[0] == w1.shape[1])
-    b2 = next(a for _, a in biases if a.shape[0] == w2.shape[1] and a is not b1)
+            def visit(name, obj, found=found):
+                if isinstance(obj, h5py.Dataset):
+                    leaf = name.rsplit("/", 1)[-1].split(":")[0]
+                    if leaf in ("kernel", "bias"):
+                        found[leaf] = np.array(obj)
+            grp[ln].visititems(visit)
+            if "kernel" in found and "bias" in found:
+                dense.append((found["kernel"], found["bias"]))
+    if len(dense) != 2:
+        raise ValueError(f"{path}: expected two Dense layers, found {len(dense)}")
+    (w1, b1), (w2, b2) = dense
+    if w1.shape[1] != w2.shape[0] or b1.shape != (w1.shape[1],) or b2.shape != (w2.shape[1],):
+        raise ValueError(f"{path}: layer shapes do not chain: {w1.shape}, {b1.shape}, {w2.shape}, {b2.shape}")
     return w1, b1, w2, b2
 
 

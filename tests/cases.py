@@ -170,6 +170,28 @@ def case_conversions_cos():
     return _base(seed=8534, batch=32, names=names)
 
 
+def case_real_nets():
+    """The three TRAINED networks the reference ships for its tests (Bu2019nsbh_tf: Dense(3 -> 2048, relu) -> Dense(2048 -> 10),
+    fp32; fixture tests/golden/bu2019nsbh_tf_weights.npz written by tools/convert_h5_weights.py) on a synthetic SVD basis
+    (the reference tree holds no .joblib metadata for this model).  First case with non-Gaussian, trained weights."""
+    filters = ["ztfr", "sdssu", "2massks"]
+    names = ["luminosity_distance", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"]
+    mp, svd = syn.make_svd_model(8634, filters, model="Bu2019nsbh")
+    with np.load(os.path.join(GOLDEN_DIR, "bu2019nsbh_tf_weights.npz")) as z:
+        for f in filters:
+            for k in ("W1", "b1", "W2", "b2"):
+                assert svd[f][k].shape == z[f"{f}/{k}"].shape
+                svd[f][k] = np.ascontiguousarray(z[f"{f}/{k}"], dtype=np.float32)
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    data = syn.make_photometry(8635, svd, mp, filters=filters, counts=dict(ztfr=21, sdssu=9, **{"2massks": 14}),
+                               cosmo_grid=grid, upper_limit_filter="ztfr")
+    names, theta = syn.draw_theta(8636, 48, names)
+    return dict(model="Bu2019nsbh", model_parameters=mp, svd=svd, model_filters=filters, sample_times=None,
+                cosmo_grid=grid, data=data, observed_filters=filters, detection_limit=np.inf,
+                systematics=dict(mode="budget", values={f: 1.0 for f in filters}),
+                systematics_ref=dict(error_budget=1.0, systematics_file=None), names=names, theta=theta)
+
+
 def case_small_hidden():
     """Tiny surrogate (NH=64) for fast pure-Python loops."""
     return _base(seed=8234, n_hidden=64, batch=16)
@@ -186,6 +208,7 @@ CASES = {
     "c4_shape": case_c4_shape,
     "small_hidden": case_small_hidden,
     "fixed_distance": case_fixed_distance,
+    "real_nets": case_real_nets,
     "conversions": case_conversions,
     "conversions_cos": case_conversions_cos,
 }
