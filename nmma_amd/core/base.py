@@ -1,27 +1,38 @@
-"""Likelihood plugin boundary: the classes samplers call (``nmma/core/base.py:37-185``).
+"""The likelihood plugin boundary: what a sampler holds and calls.
 
-``NMMALikelihood`` subclasses ``bilby.core.likelihood.Likelihood`` when bilby is
-importable (drop-in for ``bilby.run_sampler`` / parallel-bilby); otherwise a duck-typed
-base with the same surface (``parameters``, ``log_likelihood_ratio``, ``meta_data``).
+The surface is the reference's (``nmma/core/base.py``: the mixin at :37-131, ``NMMALikelihood``
+at :133-185) -- ``priors`` / ``constraints`` properties, ``conv_functions``,
+``parameter_conversion``, ``log_likelihood``, ``sub_log_likelihood``, ``noise_log_likelihood``,
+``sanity_checks`` -- because the drivers (``bilby.run_sampler``, parallel-bilby, the reference's
+``analysis.py``) use exactly those names.  The organisation underneath is this package's:
+constraint priors live in a :class:`ConstraintSet` that evaluates a whole batch of samples at
+once (the batched GPU path uses the same object as the per-sample path), and the parameter
+equivalence rules are a table.
+
+When bilby is importable ``NMMALikelihood`` derives from ``bilby.core.likelihood.Likelihood``;
+otherwise from a stand-in with the few attributes the drivers touch.
 """
 from __future__ import annotations
 
 import numpy as np
 
+#: np.nan_to_num(-np.inf): the value every failed evaluation gets (reference core/base.py:82, :181)
+LOGL_FLOOR = float(np.finfo(np.float64).min)
+
 try:  # pragma: no cover - bilby is not installed in the build image
-    from bilby.core.likelihood import Likelihood as _BilbyLikelihood
-    from bilby.core.prior import Constraint as _BilbyConstraint
+    from bilby.core.likelihood import Likelihood
+    from bilby.core.prior import Constraint
     HAVE_BILBY = True
 except Exception:  # noqa: BLE001
     HAVE_BILBY = False
 
-    class _BilbyLikelihood:
-        """Surface of bilby.core.likelihood.Likelihood used by NMMA's drivers."""
+    class Likelihood:
+        """The part of ``bilby.core.likelihood.Likelihood`` a sampler driver touches."""
+        meta_data = None
+        marginalized_parameters = ()
 
         def __init__(self, parameters=None):
-            self.parameters = parameters if parameters is not None else {}
-            self._meta_data = None
-            self._marginalized_parameters = []
+            self.parameters = {} if parameters is None else parameters
 
         def log_likelihood(self, parameters=None):
             return np.nan
@@ -32,30 +43,16 @@ except Exception:  # noqa: BLE001
         def log_likelihood_ratio(self, parameters=None):
             return self.log_likelihood(parameters) - self.noise_log_likelihood()
 
-        @property
-        def meta_data(self):
-            return getattr(self, "_meta_data", None)
+    class Constraint:
+        """Open-interval constraint prior (``bilby.core.prior.Constraint``)."""
 
-        @meta_data.setter
-        def meta_data(self, meta_data):
-            self._meta_data = meta_data
-
-        @property
-        def marginalized_parameters(self):
-            return self._marginalized_parameters
-
-    class _BilbyConstraint:
-        def __init__(self, minimum, maximum, name=None, **kw):
+        def __init__(self, minimum, maximum, name=None, **_unused):
             self.minimum, self.maximum, self.name = minimum, maximum, name
 
         def prob(self, val):
             return (val > self.minimum) & (val < self.maximum)
 
-Likelihood = _BilbyLikelihood
-Constraint = _BilbyConstraint
-
-#: np.nan_to_num(-np.inf): the reference's universal failure value (core/base.py:82, :181)
-LOGL_FLOOR = float(np.nan_to_num(-np.inf))
+_BilbyLikelihood = Likelihood     # name kept for nmma_amd.joint
 
 
 def is_constraint(prior):
@@ -63,21 +60,63 @@ def is_constraint(prior):
 
 
 def fixed_value(prior):
-    """Value of a delta-function / plain-number prior, else None."""
-    if isinstance(prior, (int, float, np.floating, np.integer)):
+    """The number a prior pins its parameter to (plain number or delta function), else None."""
+    if isinstance(prior, (int, float, np.integer, np.floating)):
         return float(prior)
-    if type(prior).__name__ == "DeltaFunction" or (hasattr(prior, "peak") and not hasattr(prior, "sample_chain")):
-        peak = getattr(prior, "peak", None)
-        if peak is not None:
-            return float(peak)
-    return None
+    looks_like_delta = type(prior).__name__ == "DeltaFunction" or (
+        hasattr(prior, "peak") and not hasattr(prior, "sample_chain"))
+    peak = getattr(prior, "peak", None) if looks_like_delta else None
+    return None if peak is None else float(peak)
+
+
+class ConstraintSet(dict):
+    """name -> constraint prior.  ``mask`` works on scalars and on columns alike."""
+
+    @classmethod
+    def of(cls, priors):
+        if is_constraint(priors):
+            return cls({priors.name: priors})
+        items = priors.items() if hasattr(priors, "items") else ()
+        return cls({key: p for key, p in items if is_constraint(p)})
+
+    def mask(self, sample):
+        """True where every constraint has non-zero probability (reference :67-68: the product of
+        the ``prob`` values, used as a truth value)."""
+        ok = True
+        for key, con in self.items():
+            ok = ok & (np.asarray(con.prob(np.asarray(sample[key])), dtype=float) > 0)
+        return ok
+
+
+#: (names, how many of them may be sampled together, wording) -- reference :112-130
+PARAMETER_GROUPS = (
+    (("inclination_EM", "KNtheta", "theta_jn", "cos_theta_jn", "thetaObs"), 1,
+     "Multiple equivalent parameters found: {found}. Please only provide one of these."),
+    (("redshift", "luminosity_distance", "Hubble_constant"), 2,
+     "Mutually dependent parameters found: {found}. Please only provide up to two of these."),
+    (("mass_1", "mass_1_source", "chirp_mass", "mass_ratio", "eta", "mass_2", "mass_2_source"), 2,
+     "Mutually dependent parameters found: {found}. Please only provide up to two of these."),
+)
+
+
+def floor_rows(values, keep):
+    """``values`` with LOGL_FLOOR wherever ``keep`` is False; torch in -> torch out, numpy in -> numpy out."""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        torch = None
+    if torch is not None and isinstance(values, torch.Tensor):
+        keep_t = torch.as_tensor(np.asarray(keep, dtype=bool), device=values.device)
+        return torch.where(keep_t, values, torch.full_like(values, LOGL_FLOOR))
+    out = np.array(values, dtype=float, copy=True)
+    out[~np.asarray(keep, dtype=bool)] = LOGL_FLOOR
+    return out
 
 
 class NMMALikelihoodMixin:
-    """core/base.py:37-131."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
+    """Prior bookkeeping and the guarded evaluation shared by single- and multi-messenger
+    likelihoods.  Subclasses supply ``parameter_conversion``, ``sub_log_likelihood`` and,
+    where they have one, ``sanity_checks``."""
 
     @property
     def priors(self):
@@ -85,9 +124,8 @@ class NMMALikelihoodMixin:
 
     @priors.setter
     def priors(self, value):
-        self.constraints = value
-        sampling_keys = [k for k in value.keys() if k not in self.constraints]
-        self.check_parameter_equivalencies(sampling_keys)
+        self._constraints = ConstraintSet.of(value)
+        self.check_parameter_equivalencies([k for k in value.keys() if k not in self._constraints])
         self._priors = value
 
     @property
@@ -96,78 +134,74 @@ class NMMALikelihoodMixin:
 
     @constraints.setter
     def constraints(self, value):
-        if is_constraint(value):
-            constr = {value.name: value}
-        elif hasattr(value, "items"):
-            constr = {k: v for k, v in value.items() if is_constraint(v)}
-        else:
-            constr = {}
-        self._constraints = constr
+        self._constraints = ConstraintSet.of(value)
+
+    @staticmethod
+    def check_parameter_equivalencies(parameter_names):
+        sampled = set(parameter_names)
+        for group, allowed, wording in PARAMETER_GROUPS:
+            found = sampled.intersection(group)
+            if len(found) > allowed:
+                raise ValueError(wording.format(found=found))
 
     def evaluate_constraints(self, out_sample):
-        return np.prod([con.prob(out_sample[k]) for k, con in self.constraints.items()])
+        return self._constraints.mask(out_sample)
 
     def identity_conversion(self, parameters):
         return parameters
 
-    def __call__(self, parameters):
-        return np.exp(self.log_likelihood(parameters))
-
-    def log_likelihood(self, parameters):
-        parameters = self.parameter_conversion(parameters)
-        if self.evaluate_constraints(parameters) and self.sanity_checks():
-            return self.sub_log_likelihood(parameters)
-        return np.nan_to_num(-np.inf)
-
     def sanity_checks(self):
         return True
 
-    def check_parameter_equivalencies(self, parameter_names):
-        """core/base.py:112-130."""
-        for group in [["inclination_EM", "KNtheta", "theta_jn", "cos_theta_jn", "thetaObs"]]:
-            inter = set(parameter_names).intersection(group)
-            if len(inter) > 1:
-                raise ValueError(f"Multiple equivalent parameters found: {inter}. Please only provide one of these.")
-        for group in [["redshift", "luminosity_distance", "Hubble_constant"],
-                      ["mass_1", "mass_1_source", "chirp_mass", "mass_ratio", "eta", "mass_2", "mass_2_source"]]:
-            inter = set(parameter_names).intersection(group)
-            if len(inter) > 2:
-                raise ValueError(f"Mutually dependent parameters found: {inter}. Please only provide up to two of these.")
+    def log_likelihood(self, parameters):
+        """One sample: convert, then the sub-likelihood if constraints and sanity checks pass,
+        else the floor (reference :77-82)."""
+        converted = self.parameter_conversion(parameters)
+        if np.all(self.evaluate_constraints(converted)) and self.sanity_checks():
+            return self.sub_log_likelihood(converted)
+        return LOGL_FLOOR
+
+    def __call__(self, parameters):
+        return np.exp(self.log_likelihood(parameters))
+
+    def floor_constrained_rows(self, logl, columns):
+        """Batched counterpart of the guard in ``log_likelihood``: ``columns`` maps every sampled
+        and fixed parameter to an array of length B; rows that violate a constraint get the floor."""
+        if not self._constraints:
+            return logl
+        return floor_rows(logl, self.evaluate_constraints(self.parameter_conversion(dict(columns))))
 
 
 class NMMALikelihood(NMMALikelihoodMixin, Likelihood):
-    """core/base.py:133-185."""
+    """One messenger: wraps ``sub_model`` (anything with ``log_likelihood(parameters)``) and the
+    chain of conversion functions that prepares its parameters."""
 
     def __init__(self, sub_model, priors, **kwargs):
-        super().__init__()
+        Likelihood.__init__(self)
         self.sub_model = sub_model
-        try:
-            self._noise_logl = self.sub_model.noise_log_likelihood()
-        except AttributeError:
-            self._noise_logl = 0.0
+        noise = getattr(sub_model, "noise_log_likelihood", None)
+        self._noise_logl = noise() if callable(noise) else 0.0
         self.conv_functions = []
         self.priors = priors
         self.setup_submodel_conversion()
 
     def __repr__(self):
-        return self.__class__.__name__ + " with " + self.sub_model.__repr__()
+        return f"{type(self).__name__} with {self.sub_model!r}"
 
     def setup_submodel_conversion(self):
-        pass
+        """Hook: append to ``self.conv_functions``.  They run last-appended first (reference :163-167)."""
 
     def parameter_conversion(self, parameters):
-        for conv in reversed(self.conv_functions):
-            parameters = conv(parameters)
+        for convert in self.conv_functions[::-1]:
+            parameters = convert(parameters)
         return parameters
 
     def posterior_conversion(self, parameters):
         return self.parameter_conversion(parameters)
 
     def sub_log_likelihood(self, parameters):
-        logl = self.sub_model.log_likelihood(parameters)
-        if not np.isfinite(logl):
-            return np.nan_to_num(-np.inf)
-        return logl
+        value = self.sub_model.log_likelihood(parameters)
+        return value if np.isfinite(value) else LOGL_FLOOR
 
     def noise_log_likelihood(self):
         return self._noise_logl

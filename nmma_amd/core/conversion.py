@@ -2,7 +2,8 @@
 by the single-sample convenience API; the batched path does them on the device).
 
 Mirrors ``nmma/core/conversion.py``: :30-34 distance modulus, :49-55 z(d_L) grid,
-:57-64 get_redshift, :119-126 observation_angle_conversion.
+:57-64 get_redshift, :66-103 cosmology_to_distance, :119-126 observation_angle_conversion,
+:184-192 convert_mtot_mni.
 """
 from __future__ import annotations
 
@@ -33,7 +34,7 @@ class FlatLambdaCDM:
     UNPINNED (astropy is absent from the build image) -- expected agreement ~1e-6."""
 
     def __init__(self, H0=67.66, Om0=0.30966, Tcmb0=2.7255, Neff=3.046, m_nu=(0.0, 0.0, 0.06)):
-        self.H0, self.Om0 = H0, Om0
+        self.H0, self.Om0, self.Tcmb0 = H0, Om0, Tcmb0
         h = H0 / 100.0
         # photon density: 4 sigma T^4 / c^3 / rho_crit
         a_rad = 7.565733250280007e-15            # erg cm^-3 K^-4
@@ -45,6 +46,12 @@ class FlatLambdaCDM:
         self.neff_per_nu = Neff / len(self.m_nu)
         self.Onu0 = self.Ogamma0 * self._nu_rel(0.0)
         self.Ode0 = 1.0 - Om0 - self.Ogamma0 - self.Onu0
+
+    def clone(self, **changes):
+        """A copy with some of H0 / Om0 / Tcmb0 / Neff / m_nu replaced (astropy's ``clone``)."""
+        args = dict(H0=self.H0, Om0=self.Om0, Tcmb0=self.Tcmb0, Neff=self.Neff, m_nu=tuple(self.m_nu))
+        args.update(changes)
+        return FlatLambdaCDM(**args)
 
     def _nu_rel(self, z):
         prefac = 0.22710731766       # 7/8 (4/11)^(4/3)
@@ -124,3 +131,64 @@ def get_cosmo_grids(distance_min, distance_max, cosmology=None, n=50):
     zmax = cosmology.z_at_luminosity_distance(distance_max)
     z_grid = np.geomspace(zmin, zmax, n)
     return cosmology.luminosity_distance(z_grid), z_grid
+
+
+def luminosity_distance_to_redshift(distance, cosmology=None):
+    """z(d_L [Mpc]) by root-finding on the native cosmology; scalar or array."""
+    cosmo = native_cosmology(cosmology)
+    d = np.asarray(distance, dtype=float)
+    if d.ndim == 0:
+        return float(cosmo.z_at_luminosity_distance(float(d)))
+    return np.array([cosmo.z_at_luminosity_distance(float(x)) for x in d.ravel()]).reshape(d.shape)
+
+
+def cosmology_to_distance(parameters, cosmology=None):
+    """Fill in ``redshift`` from ``luminosity_distance`` (or the reverse) under a cosmology whose H0 / Om0
+    are overridden by ``Hubble_constant`` / ``Omega_matter`` when those are in ``parameters``
+    (nmma/core/conversion.py:66-103).  Values may be scalars or equal-length arrays (one cosmology per row)."""
+    base = native_cosmology(cosmology)
+    over = {}
+    if "Hubble_constant" in parameters:
+        over["H0"] = parameters["Hubble_constant"]
+    if "Omega_matter" in parameters:
+        over["Om0"] = parameters["Omega_matter"]
+    if "luminosity_distance" not in parameters and "redshift" not in parameters:
+        raise KeyError("Either redshift or luminosity_distance must be in parameters")
+
+    def variant(**kw):
+        return base.clone(**{k: float(v) for k, v in kw.items()})
+
+    def one(cosmo, row):
+        if "luminosity_distance" in parameters:
+            return cosmo.z_at_luminosity_distance(float(row["luminosity_distance"]))
+        return float(cosmo.luminosity_distance(float(row["redshift"]))[0])
+
+    target = "redshift" if "luminosity_distance" in parameters else "luminosity_distance"
+    given = "luminosity_distance" if target == "redshift" else "redshift"
+    per_row = [k for k, v in over.items() if np.ndim(v) > 0]
+    if not per_row:
+        cosmo = variant(**over)
+        vals = np.asarray(parameters[given], dtype=float)
+        if vals.ndim == 0:
+            parameters[target] = one(cosmo, {given: vals})
+        else:
+            parameters[target] = np.array([one(cosmo, {given: v}) for v in vals])
+        return parameters
+    n = len(np.atleast_1d(over[per_row[0]]))
+    rows = np.broadcast_to(np.asarray(parameters[given], dtype=float), (n,))
+    parameters[target] = np.array([
+        one(variant(**{k: (np.broadcast_to(v, (n,))[i]) for k, v in over.items()}), {given: rows[i]})
+        for i in range(n)])
+    return parameters
+
+
+def convert_mtot_mni(params):
+    """Derived quantities of the AnBa2022 supernova grids (nmma/core/conversion.py:184-192): linear masses
+    from their log10 aliases, the nickel fraction ``mni_c`` and the mixing margin ``mrp_c`` that
+    the priors constrain.  Works on scalars and on columns."""
+    for par in ("mni", "mtot", "mrp"):
+        if par not in params:
+            params[par] = 10 ** np.asarray(params[f"log10_{par}"], dtype=float)
+    params["mni_c"] = params["mni"] / params["mtot"]
+    params["mrp_c"] = params["xmix"] * (params["mtot"] - params["mni"]) - params["mrp"]
+    return params

@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..core.base import LOGL_FLOOR, NMMALikelihood, fixed_value, is_constraint
+from ..core.conversion import convert_mtot_mni
 from . import utils
 
 
@@ -127,7 +128,13 @@ class EMTransientLikelihood(NMMALikelihood):
         super().__init__(sub_model, priors, **kwargs)
 
     def setup_submodel_conversion(self):
-        self.conv_functions.append(self.sub_model.light_curve_model.parameter_conversion)
+        """em_likelihood.py:91-100: the AnBa2022 grids add their derived masses (which priors may
+        constrain) ahead of the model's own conversion."""
+        lc_model = self.sub_model.light_curve_model
+        model_names = lc_model.model if isinstance(lc_model.model, (list, tuple)) else [lc_model.model]
+        if any(name in ("AnBa2022_linear", "AnBa2022_log") for name in model_names):
+            self.conv_functions.append(convert_mtot_mni)
+        self.conv_functions.append(lc_model.parameter_conversion)
 
     def sanity_checks(self):
         return self.sub_model.light_curve_model.good_parameters
@@ -159,16 +166,7 @@ class EMTransientLikelihood(NMMALikelihood):
         _, fixed = self.sub_model.sampling_layout()
         for key, val in fixed.items():
             params.setdefault(key, np.full(len(th), val))
-        params = self.parameter_conversion(params)
-        ok = np.ones(len(th), dtype=bool)
-        for key, con in self.constraints.items():
-            ok &= np.asarray(con.prob(np.asarray(params[key])), dtype=float) > 0
-        if isinstance(out, torch.Tensor):
-            mask = torch.as_tensor(~ok, device=out.device)
-            return torch.where(mask, torch.full_like(out, LOGL_FLOOR), out)
-        out = np.array(out, dtype=float, copy=True)
-        out[~ok] = LOGL_FLOOR
-        return out
+        return self.floor_constrained_rows(out, params)
 
     def parameter_names(self):
         return self.sub_model.sampling_layout()[0]
@@ -178,10 +176,33 @@ class EMTransientLikelihood(NMMALikelihood):
         if "log10_mej_dyn" in posterior_samples and "log10_mej_wind" in posterior_samples:
             posterior_samples["log10_mej"] = np.log10(10 ** posterior_samples["log10_mej_wind"]
                                                       + 10 ** posterior_samples["log10_mej_dyn"])
+        if "thetaCore" in posterior_samples:            # afterglow jet wing: angle <-> ratio to the core
+            if "thetaWing" in posterior_samples:
+                posterior_samples["alphaWing"] = posterior_samples["thetaWing"] / posterior_samples["thetaCore"]
+            elif "alphaWing" in posterior_samples:
+                posterior_samples["thetaWing"] = posterior_samples["alphaWing"] * posterior_samples["thetaCore"]
         return posterior_samples
 
     def final_diagnostics(self, bestfit_params, args, result=None):
         return self.sub_model.final_diagnostics(bestfit_params, args, result)
+
+
+def build_em_likelihood(light_curve_model, light_curve_data, trigger_time, priors, filters=None,
+                        systematics_file=None, error_budget=None, injection=None, detection_limit=np.inf,
+                        verbose=False):
+    """Raw photometry -> ready likelihood, in the order the reference's drivers use (em/analysis.py:135-170,
+    em_likelihood.py:12-40): times relative to the trigger, the model-window consistency check (which
+    trims injected data and rejects real data the model cannot cover), the systematics handler on the
+    final epochs, then the likelihood.
+
+    ``light_curve_data``: ``{filter: {"time": mjd, "mag": ..., "mag_error": ...}}``."""
+    from .systematics import FilterSystematicsHandler
+    data = utils.setup_filtered_lc_data(light_curve_data, trigger_time)
+    data = utils.check_model_time_consistency(data, light_curve_model, priors, injection)
+    filters = list(filters) if filters else list(data[0].keys())
+    handler = FilterSystematicsHandler(filters, systematics_file, error_budget, data[0])
+    return EMTransientLikelihood(light_curve_model, data, handler, priors, filters=filters,
+                                 detection_limit=detection_limit, verbose=verbose)
 
 
 #: legacy (<= 0.2.x) name used by BASELINE.json's north_star

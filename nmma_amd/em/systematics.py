@@ -1,197 +1,211 @@
-"""Systematic-uncertainty handling of the EM likelihood (``nmma/em/systematics.py``).
+"""Systematic-uncertainty setup of the EM likelihood: YAML / error budget -> the flat table
+the HIP kernel reads.
 
-``FilterSystematicsHandler`` keeps the reference's selection logic (:212-263, legacy
-YAML :298-336) so the same YAML / error-budget inputs pick the same evaluator, and adds
-``kernel_spec()``: the flat description the HIP kernel consumes.  ``__call__`` keeps the
-reference's per-sample API (a dict of sigma arrays) for diagnostics and plotting; the
-likelihood itself never calls it -- sigma_sys is evaluated on the device.
+The reference (``nmma/em/systematics.py``) picks one of several evaluator methods per call
+and builds sigma_sys arrays on the host for every sample.  Here sigma_sys is evaluated on
+the device, so the host side is only a compiler from the user's inputs to ONE table:
+
+    filter -> Entry(prior names, node times)        # node times None: one sampled scalar
+
+It is built in two passes: the document is first lowered to an ordered list of ``Rule``s
+(who, which prior stem, which node grid, whether the rule only fills gaps), then the rules
+are applied in order.  The accepted documents and the resulting assignment are the
+reference's (:131-160 time ranges, :212-263 document forms, :298-336 the legacy
+``config:`` form), which ``tests/test_host_logic.py`` checks against the reference's own
+handler.  ``kernel_spec()`` is what ``nmma_amd.engine.EMEngine`` consumes; ``__call__``
+keeps the reference's per-sample dict-of-arrays API for plots and diagnostics only.
 """
 from __future__ import annotations
 
 from ast import literal_eval
+from typing import NamedTuple, Optional
 
 import numpy as np
 
 from .utils import set_filter_associated_dict
 
+#: keys that describe ONE entry; a document whose top level holds them is a single global entry
+ENTRY_KEYS = ("time_range", "time_nodes", "prior", "params", "each", "filters")
 
-def _interp_constant(x, nodes, vals):
-    return np.interp(x, nodes, vals, left=vals[0], right=vals[-1])
+
+class Rule(NamedTuple):
+    filters: tuple            # filters it addresses; () = every filter no rule has claimed yet
+    stem: str                 # prior name (scalar) or prefix of <stem>_<i> (node grid)
+    nodes: Optional[np.ndarray]
+    fills_gaps: bool = False
+
+
+class Entry(NamedTuple):
+    names: tuple
+    nodes: Optional[np.ndarray]
+
+
+def node_grid(info, span, default_spacing="linear"):
+    """Node times of one entry, or None when it has none (reference :131-160).
+
+    ``time_nodes: n`` alone spans the model's time range; ``time_range`` is
+    "[spacing] [start] end [n]" with the count taken from its last token when
+    ``time_nodes`` is absent."""
+    count = info.get("time_nodes")
+    tokens = str(info.get("time_range", "")).split()
+    if count is None:
+        if not tokens:
+            return None
+        count = tokens.pop()
+    spacing, (start, stop) = default_spacing, span
+    if len(tokens) == 3:
+        spacing, start, stop = tokens
+    elif len(tokens) == 2:
+        try:
+            start, stop = float(tokens[0]), tokens[1]
+        except ValueError:
+            spacing, stop = tokens
+    elif tokens:
+        raise ValueError(f"time range specification invalid: {info.get('time_range')!r}")
+    maker = np.linspace if "lin" in spacing else np.geomspace if ("log" in spacing or "geo" in spacing) else None
+    if maker is None:
+        raise ValueError(f"unknown time grid type {spacing!r}")
+    return maker(float(start), float(stop), int(count))
+
+
+def lower_document(doc, filters, span, stem):
+    """YAML document -> ordered rules (reference :212-263)."""
+    def named(key):
+        return f"{stem}_{key}" if key else stem
+
+    if "config" in doc:
+        return lower_legacy(doc["config"], filters, span, stem)
+    rules = []
+    for key, info in doc.items():
+        if key in ENTRY_KEYS:
+            # the document itself is one entry for every filter; the reference stops reading here
+            rules.append(Rule(tuple(filters), named(""), node_grid(doc, span)))
+            break
+        rules.extend(_lower_entry(key, info, filters, span, named))
+    return rules
+
+
+def _lower_entry(key, info, filters, span, named):
+    nodes = node_grid(info, span)
+    if key in filters:
+        return [Rule((key,), named(key), nodes)]
+    if "filters" in info:
+        return [Rule(tuple(info["filters"]), named(key), nodes)]
+    if "each" in info:
+        return [Rule((f,), named(key).replace(key, f), nodes) for f in info["each"]]
+    return [Rule((), named(key), nodes, fills_gaps=True)]
+
+
+def lower_legacy(cfg, filters, span, stem):
+    """The pre-0.2 ``config: {withTime, withoutTime}`` document (reference :298-336)."""
+    timed = cfg["withTime"]
+    flat = cfg.get("withoutTime", {"value": False})
+    if bool(timed["value"]) == bool(flat["value"]):
+        raise ValueError("Only one of withTime / withoutTime may be true")
+    if flat["value"]:
+        return [Rule(tuple(filters), stem, None)]
+    nodes = np.round(np.linspace(span[0], span[1], timed["time_nodes"]), decimals=2)
+    rules = []
+    for group in timed["filters"]:
+        if group is None:
+            return [Rule(tuple(filters), f"{stem}_all", nodes)]
+        members = tuple(group) if isinstance(group, list) else (group,)
+        rules.append(Rule(members, f"{stem}_" + "___".join(members), nodes))
+    return rules
+
+
+def apply_rules(rules, filters, priors):
+    """Rules in order -> {filter: Entry}.  A filter may be addressed once (a second addressed rule
+    is a KeyError, as in the reference's bookkeeping, :265-269); a gap-filling rule takes every
+    filter no ADDRESSED rule has claimed so far (so two of them stack, and -- as in the
+    reference's evaluator -- a node grid then wins over a scalar)."""
+    table, unclaimed, gap_filled = {}, list(filters), False
+    for rule in rules:
+        if rule.nodes is None:
+            entry = Entry((rule.stem,), None)
+        else:
+            entry = Entry(tuple(f"{rule.stem}_{i}" for i in range(len(rule.nodes))), np.asarray(rule.nodes, float))
+        for name in entry.names:
+            if name not in priors:
+                raise AssertionError(f"Required systematics prior missing: {name}")
+        if rule.fills_gaps:
+            gap_filled = True
+            for f in unclaimed:
+                if f not in table or entry.nodes is not None or table[f].nodes is None:
+                    table[f] = entry
+        else:
+            for f in rule.filters:
+                if f not in unclaimed:
+                    raise KeyError(f"filter {f!r} is addressed twice (or not observed) in the systematics document")
+                unclaimed.remove(f)
+                table[f] = entry
+    if unclaimed and not gap_filled:
+        raise AssertionError(f"Some filters are missing systematic uncertainty definitions: {set(unclaimed)}")
+    return table
 
 
 class FilterSystematicsHandler:
-    allowed_keys = ["time_range", "time_nodes", "prior", "params", "each", "filters"]
+    """Same constructor, ``reset`` and per-sample call as the reference's handler (:163-210)."""
 
     def __init__(self, filters, systematics_file=None, error_budget=None,
                  light_curve_times=np.linspace(0.1, 14, 10), base_prior_name="em_syserr"):
         self.filters = list(filters)
-        if not isinstance(light_curve_times, dict):
-            light_curve_times = {f: light_curve_times for f in self.filters}
+        self.light_curve_times = (light_curve_times if isinstance(light_curve_times, dict)
+                                  else {f: light_curve_times for f in self.filters})
         self.base_prior_name = base_prior_name
-        self.default_t_grid_type = "linear"
-        self.light_curve_times = light_curve_times
         self.adjust_error_budget(error_budget)
-        self.mode = "budget"
-        self.direct_sys_map, self.interpolate_map = {}, {}
         if isinstance(systematics_file, str):
             import yaml
             with open(systematics_file) as fh:
-                self.systematics_dict = yaml.safe_load(fh) or {}
-        elif isinstance(systematics_file, dict):
-            self.systematics_dict = systematics_file
-        else:
-            self.systematics_dict = {}
+                systematics_file = yaml.safe_load(fh)
+        self.systematics_dict = systematics_file if isinstance(systematics_file, dict) else {}
+        self.table = None          # None: fixed error budget (no sampled systematic)
 
-    # systematics.py:203-210
     def adjust_error_budget(self, error_budget):
-        if error_budget is None:
-            error_budget = 1.0
-        elif isinstance(error_budget, str):
-            error_budget = literal_eval(error_budget)
-        self.error_budget_values = set_filter_associated_dict(error_budget, self.filters, 1.0)
+        budget = 1.0 if error_budget is None else error_budget
+        if isinstance(budget, str):
+            budget = literal_eval(budget)
+        self.error_budget_values = set_filter_associated_dict(budget, self.filters, 1.0)
 
-    def prior_name(self, key):
-        return f"{self.base_prior_name}_{key}" if key else self.base_prior_name
-
-    # systematics.py:131-160
-    def get_time_range(self, info):
-        num = info.get("time_nodes", None)
-        t_range = info.get("time_range", "").split()
-        if num is None and t_range:
-            num = t_range.pop(-1)
-        if num is None:
-            return None
-        if len(t_range) == 3:
-            grid_type, t_start, t_end = t_range
-        elif len(t_range) == 2:
-            t_start, t_end = t_range
-            grid_type = self.default_t_grid_type
-            try:
-                float(t_start)
-            except ValueError:
-                grid_type, t_end = t_range
-                t_start = self.time_range[0]
-        elif len(t_range) == 0:
-            t_start, t_end = self.time_range
-            grid_type = self.default_t_grid_type
-        else:
-            raise ValueError("time range specfication invalid")
-        if "lin" in grid_type:
-            return np.linspace(float(t_start), float(t_end), int(num))
-        if "log" in grid_type or "geo" in grid_type:
-            return np.geomspace(float(t_start), float(t_end), int(num))
-        raise ValueError(f"unknown time grid type {grid_type}")
-
-    def get_name_and_times(self, key, info):
-        return self.prior_name(key), self.get_time_range(info)
-
-    # systematics.py:187-192
     def reset(self, model_times, priors):
+        """Bind to a model's time span and a prior set (reference :187-192): a systematics
+        document wins, else a prior named ``base_prior_name`` means one global sampled scalar,
+        else the fixed budget."""
         self.time_range = (model_times[0], model_times[-1])
         if self.systematics_dict:
-            self.setup_systematics_sampling(priors)
+            rules = lower_document(self.systematics_dict, self.filters, self.time_range, self.base_prior_name)
+            self.table = apply_rules(rules, self.filters, priors)
         elif self.base_prior_name in priors:
-            self.mode = "param"
-
-    # systematics.py:212-263
-    def setup_systematics_sampling(self, priors):
-        self.direct_sys_map, self.interpolate_map = {}, {}
-        self.missing_filters = set(self.filters)
-        cleared = False
-        for key, info in self.systematics_dict.items():
-            if key == "config":
-                self.legacy_systematics_setup(self.systematics_dict)
-                break
-            if key in self.allowed_keys:
-                name, tr = self.get_name_and_times("", self.systematics_dict)
-                for f in self.filters:
-                    self._register(f, tr, name, priors)
-                break
-            if key in self.filters:
-                name, tr = self.get_name_and_times(key, info)
-                self._register(key, tr, name, priors)
-            elif "filters" in info:
-                name, tr = self.get_name_and_times(key, info)
-                for f in info["filters"]:
-                    self._register(f, tr, name, priors)
-            elif "each" in info:
-                name, tr = self.get_name_and_times(key, info)
-                for f in info["each"]:
-                    self._register(f, tr, name.replace(key, f), priors)
-            else:
-                cleared = True
-                name, tr = self.get_name_and_times(key, info)
-                for f in sorted(self.missing_filters, key=self.filters.index):
-                    self._register(f, tr, name, priors, clean=False)
-        assert cleared or len(self.missing_filters) == 0, \
-            f"Some filters are missing systematic uncertainty definitions: {self.missing_filters}"
-        if not self.interpolate_map:
-            self.mode = "param" if len(set(self.direct_sys_map.values())) == 1 else "single"
-            if self.mode == "param":
-                self.base_prior_name = next(iter(self.direct_sys_map.values()))
-        elif not self.direct_sys_map:
-            self.mode = "interp"
+            self.table = {f: Entry((self.base_prior_name,), None) for f in self.filters}
         else:
-            self.mode = "mixed"
+            self.table = None
 
-    def _register(self, filt, time_range, prior_name, priors, clean=True):
-        if clean:
-            self.direct_sys_map.pop(filt, None)
-            self.interpolate_map.pop(filt, None)
-            self.missing_filters.discard(filt)
-        if time_range is None:
-            assert prior_name in priors, "Required systematics prior missing"
-            self.direct_sys_map[filt] = prior_name
-        else:
-            names = [f"{prior_name}_{i}" for i, _ in enumerate(time_range)]
-            for p in names:
-                assert p in priors, f"Required systematics prior missing: {p}"
-            self.interpolate_map[filt] = (names, np.asarray(time_range, float))
+    # the reference's two maps, for callers and tests that look at them
+    @property
+    def direct_sys_map(self):
+        return {f: e.names[0] for f, e in (self.table or {}).items() if e.nodes is None}
 
-    # systematics.py:298-336
-    def legacy_systematics_setup(self, sysdict):
-        cfg = sysdict["config"]
-        with_time, without = cfg["withTime"], cfg.get("withoutTime", {"value": False})
-        if bool(with_time["value"]) == bool(without["value"]):
-            raise ValueError("Only one of withTime / withoutTime may be true")
-        if not with_time["value"]:
-            self.direct_sys_map = {f: self.base_prior_name for f in self.filters}
-            self.missing_filters = set()
-            return
-        groups = {}
-        for grp in list(with_time["filters"]):
-            if grp is None:
-                groups = {f: "all" for f in self.filters}
-                self.missing_filters = set()
-                break
-            if isinstance(grp, list):
-                for f in grp:
-                    self.missing_filters.discard(f)
-                    groups[f] = "___".join(grp)
-            else:
-                groups[grp] = grp
-                self.missing_filters.discard(grp)
-        nodes = np.round(np.linspace(*self.time_range, with_time["time_nodes"]), decimals=2)
-        self.interpolate_map = {f: ([f"{self.base_prior_name}_{name}_{i}" for i, _ in enumerate(nodes)], nodes)
-                                for f, name in groups.items()}
+    @property
+    def interpolate_map(self):
+        return {f: (list(e.names), e.nodes) for f, e in (self.table or {}).items() if e.nodes is not None}
 
-    # ---- what the HIP kernel consumes (engine.EMEngine._systematics_arrays)
     def kernel_spec(self):
-        if self.mode == "budget":
+        """Flat description for ``EMEngine(systematics=...)``."""
+        if self.table is None:
             return {"mode": "budget", "values": dict(self.error_budget_values)}
-        if self.mode == "param":
-            return {"mode": "param", "name": self.base_prior_name}
-        return {"mode": "mixed", "names": dict(self.direct_sys_map),
-                "nodes": {f: (list(n), np.asarray(t, float)) for f, (n, t) in self.interpolate_map.items()}}
+        direct = self.direct_sys_map
+        if len(direct) == len(self.table) and len(set(direct.values())) == 1:
+            return {"mode": "param", "name": next(iter(direct.values()))}
+        return {"mode": "mixed", "names": direct, "nodes": self.interpolate_map}
 
-    # ---- reference per-sample API (diagnostics only; systematics.py:51-55, :279-296)
     def __call__(self, parameters):
+        """sigma_sys per filter at the data epochs for ONE sample (diagnostics only)."""
         t = self.light_curve_times
-        if self.mode == "budget":
+        if self.table is None:
             return {f: np.full_like(t[f], self.error_budget_values[f]) for f in self.filters}
-        if self.mode == "param":
-            return {f: np.full_like(t[f], parameters[self.base_prior_name]) for f in self.filters}
-        out = {f: np.full_like(t[f], parameters[n]) for f, n in self.direct_sys_map.items()}
-        for f, (names, nodes) in self.interpolate_map.items():
-            out[f] = _interp_constant(t[f], nodes, np.array([parameters[p] for p in names]))
+        out = {}
+        for f, entry in self.table.items():
+            vals = np.array([parameters[n] for n in entry.names], dtype=float)
+            out[f] = (np.full_like(t[f], vals[0]) if entry.nodes is None
+                      else np.interp(t[f], entry.nodes, vals, left=vals[0], right=vals[-1]))
         return out

@@ -71,6 +71,75 @@ def setup_filtered_lc_data(light_curve_data, trigger_time):
     return (lc_times, lc_mags, lc_unc, trigger_time)
 
 
+def _prior_bounds(priors, key, default=None):
+    """(minimum, maximum) of a prior; a plain number or delta function counts as both."""
+    if key not in priors:
+        return default
+    prior = priors[key]
+    if isinstance(prior, (int, float, np.integer, np.floating)):
+        return float(prior), float(prior)
+    if hasattr(prior, "minimum") and hasattr(prior, "maximum") and prior.minimum is not None:
+        return float(prior.minimum), float(prior.maximum)
+    peak = getattr(prior, "peak", None)
+    if peak is None:
+        raise ValueError(f"prior on {key!r} has neither bounds nor a fixed value")
+    return float(peak), float(peak)
+
+
+def observer_frame_window(model_times, priors):
+    """The observer-frame interval every prior draw's model covers: the model grid [t_lo, t_hi] (source
+    frame, days) stretched by (1 + z) and shifted by ``timeshift``; taking the latest possible start
+    and the earliest possible end (utils.py:301-329)."""
+    from ..core import conversion
+    if "redshift" in priors:
+        z_lo, z_hi = _prior_bounds(priors, "redshift")
+    elif "luminosity_distance" in priors:
+        d_lo, d_hi = _prior_bounds(priors, "luminosity_distance")
+        if "Hubble_constant" in priors:
+            # the reference evaluates every prior at its minimum, then at its maximum
+            ends = []
+            for pick in (0, 1):
+                corner = {k: _prior_bounds(priors, k)[pick] for k in ("luminosity_distance", "Hubble_constant",
+                                                                      "Omega_matter") if k in priors}
+                ends.append(conversion.cosmology_to_distance(corner)["redshift"])
+            z_lo, z_hi = ends
+        else:
+            z_lo = conversion.luminosity_distance_to_redshift(d_lo)
+            z_hi = conversion.luminosity_distance_to_redshift(d_hi)
+    else:
+        z_lo = z_hi = 0.0
+    shift_lo, shift_hi = _prior_bounds(priors, "timeshift", (0.0, 0.0))
+    t_lo, t_hi = float(model_times[0]), float(model_times[-1])
+    return (1.0 + z_hi) * t_lo + shift_hi, (1.0 + z_lo) * t_hi + shift_lo
+
+
+def check_model_time_consistency(light_curve_data, light_curve_model, priors, injection=None):
+    """Refuse (or, for an injection, trim) photometry that falls outside the window the model covers for
+    every prior draw (utils.py:289-353).  Detections only: non-finite magnitudes / uncertainties do not
+    count towards the data's time span.  Returns the (possibly trimmed) data tuple."""
+    lc_times, lc_mags, lc_unc, trigger_time = light_curve_data
+    window_start, window_end = observer_frame_window(light_curve_model.model_times, priors)
+    if injection is not None:
+        for filt in list(lc_times):
+            keep = (lc_times[filt] >= window_start) & (lc_times[filt] <= window_end)
+            lc_times[filt] = lc_times[filt][keep]
+            lc_mags[filt] = lc_mags[filt][keep]
+            lc_unc[filt] = lc_unc[filt][keep]
+        return (lc_times, lc_mags, lc_unc, trigger_time)
+    first, last = np.inf, -np.inf
+    for filt, t in lc_times.items():
+        detected = np.isfinite(lc_mags[filt]) & np.isfinite(lc_unc[filt])
+        if np.any(detected):
+            first, last = min(first, t[detected].min()), max(last, t[detected].max())
+    if first < window_start:
+        raise ValueError(f"First data point is at {first} days, but with your timeshift and redshift settings, "
+                         f"the model time in detector frame can start as late as {window_start}.")
+    if window_end < last:
+        raise ValueError(f"Last data point is at {last} days, but with your timeshift and redshift settings, "
+                         f"the model time in detector frame can end as early as {window_end}.")
+    return (lc_times, lc_mags, lc_unc, trigger_time)
+
+
 def resolve_sources(observed_filters, model_filters, known_filters=()):
     """Model bands feeding each observed band (em_likelihood.py:313-335).
 

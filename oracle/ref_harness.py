@@ -104,7 +104,8 @@ class _Uniform(_Prior):
 
 class _Constraint(_Prior):
     def prob(self, val):
-        return float((val > self.minimum) & (val < self.maximum))
+        # bilby.core.prior.Constraint.prob: elementwise, works on arrays
+        return (val > self.minimum) & (val < self.maximum)
 
 
 class _PriorDict(dict):

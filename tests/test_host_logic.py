@@ -127,6 +127,83 @@ def test_systematics_selection_matches_reference_handler():
         np.testing.assert_allclose(a[f], b[f], rtol=1e-15)
 
 
+class _AnyPrior(dict):
+    """A prior set that contains every name (the documents below only need membership)."""
+    def __contains__(self, key):
+        return True
+
+
+SYS_DOCS = {
+    "global_scalar": {"prior": "Uniform(0, 2)"},
+    "global_nodes": {"time_nodes": 4, "time_range": "lin 2 12", "prior": "Uniform(0, 2)"},
+    "global_range_log": {"time_range": "log 0.5 20 5"},
+    "global_range_start_end": {"time_range": "1.0 15.0 3"},
+    "global_range_spacing_end": {"time_range": "geom 15.0 3"},
+    "per_filter_and_rest": {"g": {"time_range": "1 9 3"}, "rest": {"prior": "x"}},
+    "group_each_rest": {"opt": {"filters": ["g", "r"], "time_range": "lin 1 10 4"},
+                        "nir": {"each": ["i"], "time_nodes": 2, "time_range": "log 19"}, "other": {}},
+    "two_gap_fillers": {"a": {"time_range": "0.2 8 3"}, "b": {}},
+    "legacy_all": {"config": {"withTime": {"value": True, "filters": [None], "time_nodes": 4},
+                              "withoutTime": {"value": False}}},
+    "legacy_flat": {"config": {"withTime": {"value": False, "filters": [None], "time_nodes": 4},
+                               "withoutTime": {"value": True}}},
+}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nmma"), reason="reference tree not available")
+@pytest.mark.parametrize("doc", sorted(SYS_DOCS))
+def test_systematics_documents_match_reference_handler(doc):
+    """Every document form the reference accepts gives the same prior names, node grids and
+    per-sample sigma_sys as the reference's own handler."""
+    from oracle import ref_harness
+    ref = ref_harness.reference_modules()
+    filters = ["g", "r", "i", "z"]
+    times = {f: np.linspace(0.3 + k, 18.0, 7 + k) for k, f in enumerate(filters)}
+    priors = _AnyPrior()
+    span = np.array([0.1, 20.0])
+    r = ref.systematics.FilterSystematicsHandler(list(filters), systematics_file=SYS_DOCS[doc], light_curve_times=times)
+    r.reset(span, priors)
+    h = FilterSystematicsHandler(filters, systematics_file=SYS_DOCS[doc], light_curve_times=times)
+    h.reset(span, priors)
+    rng = np.random.default_rng(5)
+    used = set()
+    for f, e in h.table.items():
+        used.update(e.names)
+    for f, n in r.direct_sys_map.items():
+        used.add(n)
+    for f, (names, _) in r.interpolate_map.items():
+        used.update(names)
+    used.add(r.base_prior_name)
+    p = {n: float(rng.uniform(0.1, 2.0)) for n in sorted(used)}
+    a, b = h(p), r(p)
+    assert set(a) == set(b) == set(filters)
+    for f in filters:
+        np.testing.assert_allclose(a[f], b[f], rtol=1e-15, err_msg=f"{doc}/{f}")
+    # and the kernel table describes the same thing
+    spec = h.kernel_spec()
+    if spec["mode"] == "param":
+        for f in filters:
+            np.testing.assert_array_equal(a[f], np.full_like(times[f], p[spec["name"]]))
+
+
+def test_bare_time_nodes_span_the_model_range():
+    """``time_nodes: n`` without a ``time_range``: the reference's get_time_range leaves the
+    spacing unset for this form (UnboundLocalError, systematics.py:141-146); here it means n
+    linear nodes over the model's time range, which is what its branch sets up."""
+    h = FilterSystematicsHandler(["g", "r"], systematics_file={"time_nodes": 4})
+    h.reset(np.array([0.5, 12.5]), _AnyPrior())
+    names, nodes = h.interpolate_map["r"]
+    assert names == [f"em_syserr_{i}" for i in range(4)]
+    np.testing.assert_array_equal(nodes, np.linspace(0.5, 12.5, 4))
+
+
+def test_filter_addressed_twice_is_rejected():
+    doc = {"all": {"filters": ["g", "r"]}, "r": {"time_range": "0.2 8 3"}}
+    h = FilterSystematicsHandler(["g", "r"], systematics_file=doc)
+    with pytest.raises(KeyError):                       # the reference: set.remove KeyError (:269)
+        h.reset(np.array([0.5, 12.5]), _AnyPrior())
+
+
 def test_legacy_yaml_systematics(tmp_path):
     cfg = {"config": {"withTime": {"value": True, "filters": [["g", "r"], "i"], "time_nodes": 3,
                                    "type": "Uniform", "minimum": 0, "maximum": 2},
@@ -188,3 +265,124 @@ def test_native_cosmology_is_monotone_and_close_to_hubble_law():
     assert len(dg) == 50 and np.all(np.diff(dg) > 0) and np.all(np.diff(zg) > 0)
     assert dg[0] == pytest.approx(1.0, rel=1e-9) and dg[-1] == pytest.approx(200.0, rel=1e-9)
     np.testing.assert_allclose(zg, dg * 67.66 / 299792.458, rtol=0.04)
+
+
+# ---------------------------------------------------------------------------------------------------
+# model-window check, AnBa2022 conversion, posterior conversion, batched constraints
+# ---------------------------------------------------------------------------------------------------
+class _Bounds:
+    def __init__(self, lo, hi):
+        self.minimum, self.maximum = lo, hi
+
+
+class _Grid:
+    model_times = np.linspace(0.1, 14.0, 50)
+
+
+def _window_data(t_first=0.5, t_last=10.0):
+    t = {"g": np.array([t_first, 2.0, t_last]), "r": np.array([0.05, 3.0, 30.0])}
+    m = {"g": np.array([18.0, 19.0, 20.0]), "r": np.array([21.0, 19.5, 22.0])}
+    # the r-band points outside the model are non-detections: they do not count towards the span
+    e = {"g": np.array([0.1, 0.1, 0.1]), "r": np.array([np.inf, 0.1, np.inf])}
+    return (t, m, e, 57982.5)
+
+
+@pytest.mark.parametrize("use_reference", [False, True])
+def test_check_model_time_consistency(use_reference):
+    if use_reference:
+        if not os.path.isdir("/root/reference/nmma"):
+            pytest.skip("reference tree not available")
+        from oracle import ref_harness
+        check = ref_harness.reference_modules().utils.check_model_time_consistency
+    else:
+        check = utils.check_model_time_consistency
+    priors = {"redshift": _Bounds(0.0, 0.1), "timeshift": _Bounds(-0.2, 0.3)}
+    # window: start (1+0.1)*0.1+0.3 = 0.41, end (1+0)*14-0.2 = 13.8
+    out = check(_window_data(), _Grid(), priors)
+    np.testing.assert_array_equal(out[0]["g"], [0.5, 2.0, 10.0])
+    with pytest.raises(ValueError, match="First data point"):
+        check(_window_data(t_first=0.4), _Grid(), priors)
+    with pytest.raises(ValueError, match="Last data point"):
+        check(_window_data(t_last=13.9), _Grid(), priors)
+    # an injection is trimmed to the window instead
+    cut = check(_window_data(t_first=0.4, t_last=13.9), _Grid(), priors, injection={"x": 1})
+    np.testing.assert_array_equal(cut[0]["g"], [2.0])
+    np.testing.assert_array_equal(cut[0]["r"], [3.0])
+    np.testing.assert_array_equal(cut[1]["r"], [19.5])
+    assert cut[3] == 57982.5
+
+
+def test_observer_frame_window_from_distance_priors():
+    from nmma_amd.core import conversion
+    priors = {"luminosity_distance": _Bounds(20.0, 400.0)}
+    lo, hi = utils.observer_frame_window(_Grid.model_times, priors)
+    z_lo, z_hi = (conversion.luminosity_distance_to_redshift(d) for d in (20.0, 400.0))
+    assert lo == pytest.approx((1 + z_hi) * 0.1) and hi == pytest.approx((1 + z_lo) * 14.0)
+    # a sampled Hubble constant moves both ends (utils.py:304-311: all minima, then all maxima)
+    priors["Hubble_constant"] = _Bounds(60.0, 80.0)
+    lo2, hi2 = utils.observer_frame_window(_Grid.model_times, priors)
+    z_a = conversion.cosmology_to_distance({"luminosity_distance": 20.0, "Hubble_constant": 60.0})["redshift"]
+    z_b = conversion.cosmology_to_distance({"luminosity_distance": 400.0, "Hubble_constant": 80.0})["redshift"]
+    assert lo2 == pytest.approx((1 + z_b) * 0.1) and hi2 == pytest.approx((1 + z_a) * 14.0)
+    assert z_b > z_hi                                   # larger H0 -> larger z at the same distance
+
+
+def test_convert_mtot_mni_matches_reference():
+    from nmma_amd.core.conversion import convert_mtot_mni
+    rng = np.random.default_rng(2)
+    cols = {"log10_mtot": rng.uniform(-0.5, 1.0, 9), "log10_mni": rng.uniform(-2.0, -0.5, 9),
+            "log10_mrp": rng.uniform(-2, 0, 9), "xmix": rng.uniform(0, 1, 9), "vej": rng.uniform(3, 9, 9)}
+    got = convert_mtot_mni({k: v.copy() for k, v in cols.items()})
+    np.testing.assert_array_equal(got["mni_c"], 10 ** cols["log10_mni"] / 10 ** cols["log10_mtot"])
+    np.testing.assert_array_equal(
+        got["mrp_c"], cols["xmix"] * (10 ** cols["log10_mtot"] - 10 ** cols["log10_mni"]) - 10 ** cols["log10_mrp"])
+    if os.path.isdir("/root/reference/nmma"):
+        from oracle import ref_harness
+        ref = ref_harness.reference_modules().conversion.convert_mtot_mni({k: v.copy() for k, v in cols.items()})
+        for key in ("mni", "mtot", "mrp", "mni_c", "mrp_c"):
+            np.testing.assert_array_equal(got[key], ref[key])
+
+
+def test_constraint_set_rows_and_scalars():
+    from nmma_amd.core.base import LOGL_FLOOR, Constraint, ConstraintSet, floor_rows
+    priors = {"mni_c": Constraint(minimum=0.0, maximum=1.0, name="mni_c"), "mrp_c": Constraint(minimum=0.0, maximum=np.inf, name="mrp_c"),
+              "vej": _Bounds(1, 2)}
+    cons = ConstraintSet.of(priors)
+    assert sorted(cons) == ["mni_c", "mrp_c"]
+    assert bool(cons.mask({"mni_c": 0.5, "mrp_c": 2.0})) and not bool(cons.mask({"mni_c": 1.5, "mrp_c": 2.0}))
+    keep = cons.mask({"mni_c": np.array([0.5, 1.5, 0.2]), "mrp_c": np.array([1.0, 1.0, -1.0])})
+    np.testing.assert_array_equal(keep, [True, False, False])
+    np.testing.assert_array_equal(floor_rows(np.array([-1.0, -2.0, -3.0]), keep), [-1.0, LOGL_FLOOR, LOGL_FLOOR])
+    assert LOGL_FLOOR == float(np.nan_to_num(-np.inf))
+    assert not ConstraintSet.of({})                     # empty: nothing to evaluate
+
+
+def test_anba2022_likelihood_adds_mass_conversion_and_wing_posterior():
+    """em_likelihood.py:91-100 and :122-131 on the host side (no engine is built)."""
+    from nmma_amd.core.conversion import convert_mtot_mni
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+
+    class _Model:
+        def __init__(self, name):
+            self.model = name
+
+        def parameter_conversion(self, p):
+            return p
+
+    class _Sub:
+        def __init__(self, name):
+            self.light_curve_model = _Model(name)
+
+    for name, expect in (("AnBa2022_log", True), (["Bu2019lm", "AnBa2022_linear"], True), ("Bu2019lm", False)):
+        lik = EMTransientLikelihood.__new__(EMTransientLikelihood)
+        lik.sub_model, lik.conv_functions = _Sub(name), []
+        lik.setup_submodel_conversion()
+        assert (convert_mtot_mni in lik.conv_functions) is expect
+        assert lik.conv_functions[-1] == lik.sub_model.light_curve_model.parameter_conversion
+    post = {"thetaWing": np.array([0.2, 0.3]), "thetaCore": np.array([0.1, 0.1]),
+            "log10_mej_dyn": np.array([-2.0, -2.0]), "log10_mej_wind": np.array([-2.0, -1.0])}
+    out = lik.posterior_conversion(dict(post))
+    np.testing.assert_allclose(out["alphaWing"], [2.0, 3.0])
+    np.testing.assert_allclose(out["log10_mej"], np.log10([0.02, 0.11]))
+    out = lik.posterior_conversion({"alphaWing": np.array([2.0]), "thetaCore": np.array([0.1])})
+    np.testing.assert_allclose(out["thetaWing"], [0.2])
