@@ -153,6 +153,24 @@ class NMMALikelihoodMixin:
     def sanity_checks(self):
         return True
 
+    def final_diagnostics(self, bestfit_params, args, result=None):
+        """Best-fit diagnostics of the wrapped model, if it offers any (reference :88-104)."""
+        hook = getattr(getattr(self, "sub_model", None), "final_diagnostics", None)
+        return hook(bestfit_params, args, result) if callable(hook) else None
+
+    def post_process_bestfit(self, args, result=None, bestfit_params=None):
+        """Convert the best-fit sample and hand it to ``final_diagnostics`` (reference :106-110).  The
+        reference reads the sample from the posterior file named by ``args``; that reader belongs to its
+        result-file layer, so here the caller passes the sample (or a ``result`` with a ``posterior``
+        table holding ``log_likelihood``)."""
+        if bestfit_params is None:
+            posterior = getattr(result, "posterior", None)
+            if posterior is None:
+                raise ValueError("post_process_bestfit needs bestfit_params or a result with a posterior table")
+            row = posterior.loc[posterior["log_likelihood"].idxmax()]
+            bestfit_params = dict(row.to_dict(), best_fit_index=int(row.name))
+        return self.final_diagnostics(self.parameter_conversion(dict(bestfit_params)), args, result)
+
     def log_likelihood(self, parameters):
         """One sample: convert, then the sub-likelihood if constraints and sanity checks pass,
         else the floor (reference :77-82)."""
@@ -187,6 +205,13 @@ class NMMALikelihood(NMMALikelihoodMixin, Likelihood):
 
     def __repr__(self):
         return f"{type(self).__name__} with {self.sub_model!r}"
+
+    def setup_parameter_conversion(self):
+        """Standard conversions implied by the priors (reference :161-164): a sampled Hubble constant
+        turns (d_L, H0) into a redshift -- or (z, H0) into a distance -- per sample."""
+        from .conversion import cosmology_to_distance
+        if "Hubble_constant" in self.priors and cosmology_to_distance not in self.conv_functions:
+            self.conv_functions.append(cosmology_to_distance)
 
     def setup_submodel_conversion(self):
         """Hook: append to ``self.conv_functions``.  They run last-appended first (reference :163-167)."""

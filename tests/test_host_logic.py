@@ -386,3 +386,30 @@ def test_anba2022_likelihood_adds_mass_conversion_and_wing_posterior():
     np.testing.assert_allclose(out["log10_mej"], np.log10([0.02, 0.11]))
     out = lik.posterior_conversion({"alphaWing": np.array([2.0]), "thetaCore": np.array([0.1])})
     np.testing.assert_allclose(out["thetaWing"], [0.2])
+
+
+def test_hubble_constant_conversion_and_device_refusal():
+    """core/base.py:161-164: a sampled H0 adds cosmology_to_distance to the conversions; the device path,
+    which tabulates ONE cosmology, refuses it loudly instead of silently using Planck18."""
+    from nmma_amd import _lib as L
+    from nmma_amd.core.base import NMMALikelihood
+    from nmma_amd.core.conversion import cosmology_to_distance
+    from nmma_amd.em.em_likelihood import MultiFilterTransient
+
+    class _Sub:
+        def log_likelihood(self, p):
+            return -0.5 * p["redshift"]
+
+    priors = {"luminosity_distance": _Bounds(10, 100), "Hubble_constant": _Bounds(60, 80)}
+    lik = NMMALikelihood(_Sub(), priors)
+    lik.setup_parameter_conversion()
+    lik.setup_parameter_conversion()                    # idempotent
+    assert lik.conv_functions == [cosmology_to_distance]
+    a = lik.log_likelihood({"luminosity_distance": 40.0, "Hubble_constant": 60.0})
+    b = lik.log_likelihood({"luminosity_distance": 40.0, "Hubble_constant": 80.0})
+    assert b < a < 0                                    # larger H0 -> larger z at fixed distance
+    assert lik.post_process_bestfit(None, bestfit_params={"luminosity_distance": 40.0, "Hubble_constant": 70.0}) is None
+    mft = MultiFilterTransient.__new__(MultiFilterTransient)
+    mft._engine = mft._names = None
+    with pytest.raises(L.NMMAHipError, match="Hubble_constant"):
+        mft.engine(["luminosity_distance", "Hubble_constant", "log10_mej"])
