@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 1
+#define NMMA_ABI_VERSION 2
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -55,6 +55,11 @@ enum nmma_redshift_mode {
     NMMA_Z_ZERO = 0,      /* no distance information: z = 0 (conversion.py:62-64)            */
     NMMA_Z_SLOT = 1,      /* sampled "redshift" (conversion.py:58-59)                         */
     NMMA_Z_GRID = 2       /* z = interp(d_L; dist_grid, z_grid)  (model.py:262-265)           */
+};
+
+enum nmma_extinction_law {
+    NMMA_EXT_LINEAR = 0,
+    NMMA_EXT_P92_SMC_HOST = 1
 };
 
 enum nmma_model_kind {
@@ -119,9 +124,14 @@ typedef struct nmma_em_config {
     nmma_slot timeshift;                    /* default 0 (model.py:297)                    */
     nmma_slot ebv;                          /* default 0 (model.py:290)                    */
 
-    /* ---- extinction: ext_mag[m] = ebv_coeff[m] * Ebv when Ebv != 0 (model.py:323-350);
-     *      NULL => Ebv ignored.  Coefficients are an input (dust law is third-party). ---- */
+    /* ---- extinction, applied when Ebv != 0 (get_extinction_mags, model.py:323-350):
+     *      NMMA_EXT_LINEAR      ext_mag[m] = ebv_coeff[m] * Ebv; coefficients are an input (any law that
+     *                           does not depend on the sample, e.g. the Milky-Way foreground G23_MW whose
+     *                           curve lives in third-party dust_extinction); ebv_coeff NULL => Ebv ignored
+     *      NMMA_EXT_P92_SMC_HOST  Pei (1992) SMC curve at the host-frame wavelength of every sample
+     *                           (utils.py:373-428); needs filter_nu0, ebv_coeff is ignored ---- */
     const double* ebv_coeff;      /* [M] or NULL */
+    int32_t extinction_law;       /* enum nmma_extinction_law */
 
     /* ---- photometry in the detector frame: utils.py:255-286 (days since trigger) ---- */
     int32_t n_obs_filters;        /* O  */

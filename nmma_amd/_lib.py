@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMMA_HIP_LIB") or os.path.join(_HERE, "libnmma_hip.so")   # env: experiment builds
 SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -24,6 +24,7 @@ OP_IDENT, OP_RAD2DEG, OP_DEG2RAD, OP_LOG10, OP_POW10, OP_THETAJN2DEG, OP_COSTHET
 Z_ZERO, Z_SLOT, Z_GRID = range(3)
 SYS_CONST, SYS_PARAM, SYS_NODES = range(3)
 MODEL_SVD, MODEL_ME2017, MODEL_EXTERNAL = range(3)
+EXT_LINEAR, EXT_P92_SMC_HOST = range(2)
 
 
 class NMMAHipError(RuntimeError):
@@ -62,7 +63,7 @@ class EmConfig(C.Structure):
         ("n_dim", C.c_int32),
         ("model_param", Slot * MAX_PARAMS),
         ("luminosity_distance", Slot), ("redshift", Slot), ("timeshift", Slot), ("ebv", Slot),
-        ("ebv_coeff", _pd),
+        ("ebv_coeff", _pd), ("extinction_law", C.c_int32),
         ("n_obs_filters", C.c_int32), ("data_offsets", _pi),
         ("data_times", _pd), ("data_mags", _pd), ("data_sigmas", _pd),
         ("detection_limit", _pd), ("n_sources", _pi), ("sources", _pi),

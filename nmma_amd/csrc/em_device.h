@@ -33,6 +33,7 @@ struct EmDev {
     // dims
     int32_t M, NP, KP, NH_pad, HB, NC, NT, NS, D, O;
     int32_t n_cosmo, redshift_mode, has_ebv, kmax;
+    int32_t ext_law, pad_ext;   // enum nmma_extinction_law; for P92 the ebv_coeff array / ItemDesc::ebvc hold filter_nu0
     int32_t st_uniform, pad0;     // sample_times equally spaced: bracket guess by division
     double st0, st_inv_dt;
     // surrogate

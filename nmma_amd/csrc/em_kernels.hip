@@ -828,7 +828,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
             const double dmod = scal[s * 8 + S_DMOD], rc = scal[s * 8 + S_RC];
             const double ebv = scal[s * 8 + S_EBV], izp1 = scal[s * 8 + S_IZP1];
-            const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
+            const double ext = extinction_mag(P.ext_law, ebvc, zp1, ebv);
             const double t_lo = stl[jlo] * zp1 + tsh, t_hi = stl[jhi] * zp1 + tsh;
             long brow = tile0 + s;
             if (brow >= B) brow = B - 1;
@@ -1585,7 +1585,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
             if (b >= B) continue;
             const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
             const double ebv = scal[s * 8 + S_EBV];
-            const double ext = (ebv != 0.0) ? ebvc * ebv : 0.0;
+            const double ext = extinction_mag(P.ext_law, ebvc, zp1, ebv);
             double v = dinf();
             if (j >= jlo && j <= jhi && jhi > jlo) {
                 const double* magrow = magb + sl * NT;
@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         const ItemDesc& it = P.item_desc[k];
         const int o = it.o, ks = it.ks, m = it.m, nsrc = it.nsrc, d0 = it.d0, nf = it.nf, kind = it.kind;
         const double lim = it.lim, e_const = it.e_const;
-        const double ext = (ebv != 0.0) ? it.ebvc * ebv : 0.0;
+        const double ext = extinction_mag(P.ext_law, it.ebvc, zp1, ebv);
         // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
         const double* cur = lc + ((size_t)b * M + m) * NS;
         __builtin_amdgcn_wave_barrier();
@@ -1951,7 +1951,7 @@ __global__ void lc_to_detector(const EmDev* __restrict__ Pp, const double* __res
         for (int j = threadIdx.x; j < NS; j += blockDim.x) { const double v = cur[j]; n += (v - v == 0.0) ? 1 : 0; }
         atomicAdd(&nfin_s, n);
         __syncthreads();
-        const double ext = (ebv != 0.0 && P.has_ebv) ? P.ebv_coeff[m] * ebv : 0.0;
+        const double ext = P.has_ebv ? extinction_mag(P.ext_law, P.ebv_coeff[m], scal[S_ZP1], ebv) : 0.0;
         for (int j = threadIdx.x; j < NS; j += blockDim.x) {
             double v = cur[j];
             if (ext != 0.0) v = v + ext;

@@ -177,4 +177,46 @@ NM_HD double upper_limit_term_inline(double m, double est, double sigma_sys) {
 NM_HD double distance_modulus(double d_lum) { return 5.0 * (5 + log10(d_lum)); }
 NM_HD double redshift_correction(double z) { return -2.5 * log10(1 + z); }
 
+// ---------------------------------------------------------------------------
+// Host-galaxy extinction, Pei (1992) SMC curve: extinctionFactorP92SMC (nmma/em/utils.py:373-428) followed by
+// get_extinction_mags' -2.5 log10 (em/model.py:323-342).  The curve itself is third-party there
+// (dust_extinction.shapes.P92, v1.x): A(lam)/A(V) = sum_i a_i / ((lam/lam_i)^n_i + (lam/lam_i)^-n_i + b_i) over
+// the six terms BKG, FUV, NUV, SIL1, SIL2, FIR in this order, amplitudes converted from the B to the V reference
+// with AbAv = 1/3.08 + 1, valid for 1e-3 <= 1/lam[um] <= 1e3.  nu: observer-frame filter frequency [Hz];
+// the curve is read at the HOST-frame wavelength c / (nu (1+z)); R_V = 2.93.  Outside the curve's range (or
+// above the reference's 2e16 Hz cut-off) the factor is 1.  Parity vs dust_extinction is unpinned (absent here).
+// ---------------------------------------------------------------------------
+NM_HD double p92_term(double lam, double amp, double cen, double b, double n) {
+    const double l_norm = lam / cen;
+    return amp / (pow(l_norm, n) + pow(l_norm, -1 * n) + b);
+}
+NM_HD double p92_smc_ext_mag(double nu, double zp1, double ebv) {
+    const double c_cgs = 29979245800.0;
+    const double nu_lo = (1.0 / 1e3) * 1e4 * c_cgs;
+    double nu_hi = (1.0 / 1e-3) * 1e4 * c_cgs;
+    if (2e16 < nu_hi) nu_hi = 2e16;
+    const double nu_host = nu * zp1;
+    double ext = 1.0;
+    if (nu_host >= nu_lo && nu_host <= nu_hi) {
+        const double x = 1.0 / ((c_cgs / nu_host) * 1e4);      // wavenumber in 1/um
+        const double lam = 1.0 / x;
+        const double abav = 1.0 / 3.08 + 1.0;
+        double axav = p92_term(lam, 185.0 * abav, 0.042, 90.0, 2.0);
+        axav = axav + p92_term(lam, 27 * abav, 0.08, 5.5, 4.0);
+        axav = axav + p92_term(lam, 0.005 * abav, 0.22, -1.95, 2.0);
+        axav = axav + p92_term(lam, 0.010 * abav, 9.7, -1.95, 2.0);
+        axav = axav + p92_term(lam, 0.012 * abav, 18.0, -1.80, 2.0);
+        axav = axav + p92_term(lam, 0.030 * abav, 25.0, 0.0, 2.0);
+        const double av = 2.93 * ebv;
+        ext = pow(10.0, -0.4 * axav * av);
+    }
+    return -2.5 * log10(ext);
+}
+// extinction magnitude of one (sample, model filter): `coeff` is ebv_coeff[m] for the linear law and the filter
+// frequency for P92 (law: enum nmma_extinction_law); nothing is applied at Ebv == 0 (model.py:328-330)
+NM_HD double extinction_mag(int law, double coeff, double zp1, double ebv) {
+    if (ebv == 0.0) return 0.0;
+    return law == 1 ? p92_smc_ext_mag(coeff, zp1, ebv) : coeff * ebv;
+}
+
 }  // namespace nmma

@@ -106,7 +106,7 @@ class SVDLightCurveModel(LightCurveModelContainer):
     def __init__(self, model, svd_path=None, svd_mag_ncoeff=None, svd_lbol_ncoeff=None,
                  interpolation_type="keras", model_parameters=None, filters=None, sample_times=None,
                  local_only=True, svd_mag_model=None, cosmo_grid=None, ebv_coeff=None, device=0,
-                 **em_model_kwargs):
+                 extinction_law=None, filter_lambdas=None, **em_model_kwargs):
         comps = model.split("_")
         if "tf" in comps:
             comps.remove("tf")
@@ -135,6 +135,13 @@ class SVDLightCurveModel(LightCurveModelContainer):
                   "(nmma/em/lightcurve_generation.py:168-169)")
         self.cosmo_grid = cosmo_grid
         self.ebv_coeff = ebv_coeff
+        if extinction_law is not None:
+            self.extinction_law = extinction_law          # class default: "P92_SMC_host" (model.py:198-201)
+        # effective wavelengths [m] -> filter frequencies (model.py:223-224); sncosmo bandpass names have none
+        # built in and need filter_lambdas
+        lam = dict(BUILTIN_FILTER_LAMBDAS)
+        lam.update(filter_lambdas or {})
+        self.filter_nu0 = ({f: C_SI / lam[f] for f in self.filters} if all(f in lam for f in self.filters) else None)
         self.device = device
         self._lc_engine, self._lc_names = None, None
 
@@ -165,11 +172,16 @@ class SVDLightCurveModel(LightCurveModelContainer):
         return [f for f in self.filters if f in self.svd_mag_model]
 
     def engine_kwargs(self):
-        return dict(svd_model=self.svd_mag_model, model_filters=self.gpu_filters,
-                    model_parameters=self.model_parameters,
-                    sample_times=None if self._default_times() else self.model_times,
-                    cosmo_grid=self.cosmo_grid, ebv_coeff=self.ebv_coeff, device=self.device,
-                    n_coeff=self.mag_ncoeff)
+        kw = dict(svd_model=self.svd_mag_model, model_filters=self.gpu_filters,
+                  model_parameters=self.model_parameters,
+                  sample_times=None if self._default_times() else self.model_times,
+                  cosmo_grid=self.cosmo_grid, ebv_coeff=self.ebv_coeff, device=self.device,
+                  n_coeff=self.mag_ncoeff)
+        # extinction (get_extinction_mags, model.py:323-342): caller-supplied linear coefficients win; else the
+        # default host-frame SMC law is evaluated natively when the filter frequencies are known
+        if self.ebv_coeff is None and self.extinction_law == "P92_SMC_host" and self.filter_nu0 is not None:
+            kw.update(extinction_law="P92_SMC_host", filter_nu0=self.filter_nu0)
+        return kw
 
     def lightcurves_abs(self, theta, names):
         """Source-frame absolute magnitudes [B, M, NS] (calc_svd_lc for every row of theta)."""

@@ -96,13 +96,15 @@ class EMEngine:
     sources : dict observed filter -> list of model filters (1, or 2-3 to average)
     detection_limit : dict observed filter -> float
     systematics : dict, see ``nmma_amd.em.systematics.FilterSystematicsHandler.kernel_spec``
-    ebv_coeff : dict model filter -> A_filter / E(B-V), or None
+    ebv_coeff : dict model filter -> A_filter / E(B-V), or None (linear law: ext_mag = coeff * Ebv)
+    extinction_law : None / "linear" (``ebv_coeff``) or "P92_SMC_host" (Pei 1992 SMC curve at every sample's
+        host-frame wavelength, utils.py:373-428; needs ``filter_nu0``: dict model filter -> Hz)
     """
 
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
-                 model_kind="svd", filter_nu0=None):
+                 model_kind="svd", filter_nu0=None, extinction_law=None):
         self._handle = None
         lib = L.load_library()
         fixed = dict(fixed or {})
@@ -157,10 +159,10 @@ class EMEngine:
             n_p, n_h, n_c, n_t = len(model_parameters), 0, 0, 0
             tt = None
             cfg.n_params = n_p
-            if filter_nu0 is not None:
-                nu0 = _f64([filter_nu0[f] for f in model_filters])
-                keep.append(nu0)
-                cfg.filter_nu0 = _ptr(nu0, C.c_double)
+        if filter_nu0 is not None:
+            nu0 = _f64([filter_nu0[f] for f in model_filters])
+            keep.append(nu0)
+            cfg.filter_nu0 = _ptr(nu0, C.c_double)
         self.n_params, self.n_hidden, self.n_coeff, self.n_tt = n_p, n_h, n_c, n_t
 
         if sample_times is not None:
@@ -202,10 +204,21 @@ class EMEngine:
         cfg.luminosity_distance = _plain_slot("luminosity_distance", names, fixed, _AVG_DEFAULT_LD)
         cfg.timeshift = _plain_slot("timeshift", names, fixed, 0.0)
         cfg.ebv = _plain_slot("Ebv", names, fixed, 0.0)
+        laws = {None: L.EXT_LINEAR, "linear": L.EXT_LINEAR, "P92_SMC_host": L.EXT_P92_SMC_HOST}
+        if extinction_law not in laws:
+            # G23_MW (and anything else z-independent) enters as ebv_coeff: its curve is third-party data
+            raise L.NMMAHipError(f"extinction_law {extinction_law!r} is not evaluated natively; pass its "
+                                 "A_filter / E(B-V) as ebv_coeff (known: 'P92_SMC_host')")
+        cfg.extinction_law = laws[extinction_law]
+        if cfg.extinction_law == L.EXT_P92_SMC_HOST and filter_nu0 is None:
+            raise L.NMMAHipError("extinction_law 'P92_SMC_host' needs filter_nu0 (observer-frame filter frequencies, Hz)")
         if ebv_coeff is not None:
             ec = _f64([ebv_coeff[f] for f in model_filters])
             keep.append(ec)
             cfg.ebv_coeff = _ptr(ec, C.c_double)
+        elif cfg.extinction_law == L.EXT_LINEAR and ("Ebv" in names or fixed.get("Ebv", 0.0) != 0.0):
+            raise L.NMMAHipError("Ebv is sampled (or fixed non-zero) but no extinction law can be evaluated: pass "
+                                 "ebv_coeff, or extinction_law='P92_SMC_host' with filter_nu0 / filter_lambdas")
 
         # photometry + systematics
         obs = self.observed_filters

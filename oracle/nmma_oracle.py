@@ -180,6 +180,65 @@ def calc_svd_lc(sample_times, param_list, svd_model, mag_ncoeff=None, filters=No
 
 
 # ---------------------------------------------------------------------------
+# f3: host-galaxy extinction, Pei (1992) SMC curve
+# ---------------------------------------------------------------------------
+#: constants of nmma/core/constants.py used by extinctionFactorP92SMC
+C_CGS = 29979245800.0
+#: dust_extinction.shapes.P92: x_range in 1/micron and the B -> V amplitude conversion
+P92_X_RANGE = (1.0 / 1e3, 1.0 / 1e-3)
+P92_ABAV = 1.0 / 3.08 + 1.0
+#: (amplitude / AbAv, lambda [um], b, n) of the six terms with the SMC values of nmma/em/utils.py:398-421
+P92_SMC_TERMS = (
+    (185.0, 0.042, 90.0, 2.0),      # BKG
+    (27, 0.08, 5.5, 4.0),           # FUV
+    (0.005, 0.22, -1.95, 2.0),      # NUV
+    (0.010, 9.7, -1.95, 2.0),       # SIL1
+    (0.012, 18.0, -1.80, 2.0),      # SIL2
+    (0.030, 25.0, 0.0, 2.0),        # FIR
+)
+
+
+def p92_axav(lam_um):
+    """A(lambda)/A(V) of dust_extinction.shapes.P92.evaluate with the SMC parameters (the
+    third-party package is absent from this image: its published formula -- Pei 1992, eq. 20 -- is
+    ``sum_i a_i / ((lam/lam_i)^n_i + (lam/lam_i)^-n_i + b_i)`` summed in the order BKG, FUV, NUV,
+    SIL1, SIL2, FIR; PARITY UNPINNED against the package itself)."""
+    lam_um = np.asarray(lam_um, dtype=float)
+    total = None
+    for amp, cen, b, n in P92_SMC_TERMS:
+        l_norm = lam_um / cen
+        term = (amp * P92_ABAV) / (np.power(l_norm, n) + np.power(l_norm, -1 * n) + b)
+        total = term if total is None else total + term
+    return total
+
+
+def extinction_factor_p92_smc(nu, Ebv, z, cutoff_hi=2e16):
+    """nmma/em/utils.py:373-428: multiplicative flux factor per observer-frame frequency."""
+    nu = np.asarray(nu, dtype=float)
+    nu_lo = P92_X_RANGE[0] * 1e4 * C_CGS
+    nu_hi = min(cutoff_hi, P92_X_RANGE[1] * 1e4 * C_CGS)
+    nu_host = nu * (1 + z)
+    opt = (nu_host >= nu_lo) & (nu_host <= nu_hi)
+    lam_host_cm = C_CGS / nu_host[opt]
+    # the package converts the wavelength to wavenumbers in 1/um and back
+    x = 1.0 / (lam_host_cm * 1e4)
+    ax_o_av = p92_axav(1.0 / x)
+    av = 2.93 * Ebv
+    ext = np.ones(nu.shape)
+    ext[opt] = np.power(10.0, -0.4 * ax_o_av * av)
+    return ext
+
+
+def extinction_mags_p92_smc(nu_0s, redshift, Ebv):
+    """get_extinction_mags (nmma/em/model.py:323-342) for extinction_law = "P92_SMC_host"."""
+    nu_0s = np.asarray(nu_0s, dtype=float)
+    if Ebv == 0.0:
+        return np.zeros_like(nu_0s)
+    with np.errstate(divide="ignore"):
+        return -2.5 * np.log10(extinction_factor_p92_smc(nu_0s, Ebv, redshift))
+
+
+# ---------------------------------------------------------------------------
 # a4 + a8: SVD light-curve model in the detector frame
 # ---------------------------------------------------------------------------
 class OracleSVDModel:

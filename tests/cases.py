@@ -281,6 +281,21 @@ def case_extinction_limit():
     return c
 
 
+def case_extinction_p92():
+    """Sampled E(B-V) under the reference's DEFAULT law: the Pei (1992) SMC curve read at every sample's
+    host-frame wavelength (utils.py:373-428, model.py:323-342) -- the extinction magnitude of a filter
+    depends on the sample's redshift.  Filter frequencies from UV to the K band; two far outside the curve's
+    applicability (> 2e16 Hz cut-off, and a radio band below 3e11 Hz) where the factor is 1."""
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind", "Ebv"]
+    c = _base(seed=9744, batch=48, names=names)
+    lam_um = [0.155, 0.36, 0.62, 1.25, 2.2]
+    nu = [2.99792458e14 / x for x in lam_um] + [3.0e16]
+    assert len(nu) >= len(c["model_filters"]) - 1
+    c["filter_nu0"] = dict(zip(c["model_filters"], nu))
+    c["theta"][:5, names.index("Ebv")] = 0.0             # model.py:328-330: nothing applied at Ebv == 0
+    return c
+
+
 def case_log_grid():
     """The CLI's default grid when --em-tmin/--em-tmax are given (150 log-spaced sample times,
     em/utils.py:87-88): two-stage interpolation on a non-uniform grid (bisection instead of an index guess)."""
@@ -288,7 +303,7 @@ def case_log_grid():
     return c
 
 
-#: geometry cases: the reference runs all of them unchanged except `extinction_limit` (its dust law is third-party),
+#: geometry cases: the reference runs all of them unchanged except the two extinction cases (its dust law is third-party),
 #: so they are golden cases too (tools/make_golden.py writes tests/golden/<name>.npz for every entry of CASES)
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
@@ -297,6 +312,8 @@ SHAPE_CASES = {
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,
     "extinction_limit": case_extinction_limit,
+    "extinction_p92": case_extinction_p92,
     "log_grid": case_log_grid,
 }
-CASES.update({k: v for k, v in SHAPE_CASES.items() if k != "extinction_limit"})
+ORACLE_ONLY_CASES = ("extinction_limit", "extinction_p92")
+CASES.update({k: v for k, v in SHAPE_CASES.items() if k not in ORACLE_ONLY_CASES})

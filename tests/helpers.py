@@ -15,6 +15,8 @@ def engine_from_case(case, device=0):
                     sources=resolve_sources(obs, case["model_filters"],
                                             known_filters=[f for f in obs if f not in FILTER_AVERAGES]),
                     detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
+                    filter_nu0=case.get("filter_nu0"),
+                    extinction_law="P92_SMC_host" if case.get("filter_nu0") is not None else None,
                     device=device)
 
 

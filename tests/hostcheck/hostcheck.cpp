@@ -21,4 +21,5 @@ double hc_apply_slot(int col, int op, double value, const double* row) {
 }
 double hc_distance_modulus(double d) { return nmma::distance_modulus(d); }
 double hc_redshift_correction(double z) { return nmma::redshift_correction(z); }
+double hc_extinction_mag(int law, double coeff, double zp1, double ebv) { return nmma::extinction_mag(law, coeff, zp1, ebv); }
 }

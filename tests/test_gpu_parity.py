@@ -110,6 +110,41 @@ def test_coefficients_and_lightcurves(name, torch_cuda):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["extinction_limit", "extinction_p92"])
+def test_extinction_lightcurves_match_oracle(name, torch_cuda):
+    """Detector-frame light curves with extinction (gen_detector_lc, model.py:352-404 with get_extinction_mags :323-342):
+    the linear law and the native Pei-1992 SMC law, whose magnitude per filter depends on each sample's redshift;
+    the extinction term alone (difference to an Ebv = 0 run) is compared at 1e-12."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    case = cases.SHAPE_CASES[name]()
+    eng = engine_from_case(case)
+    theta = case["theta"][:12].copy()
+    j_ebv = case["names"].index("Ebv")
+    theta0 = theta.copy()
+    theta0[:, j_ebv] = 0.0
+    _, mag = (x.cpu().numpy() for x in eng.lightcurves(torch.as_tensor(theta, device="cuda:0")))
+    _, mag0 = (x.cpu().numpy() for x in eng.lightcurves(torch.as_tensor(theta0, device="cuda:0")))
+    olik = oracle_from_case(case)
+    for i in range(len(theta)):
+        p = olik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in theta[i]))))
+        _, lc = olik.model.gen_detector_lc(p)
+        z, ebv = olik.model.redshift, theta[i, j_ebv]
+        for k, f in enumerate(case["model_filters"]):
+            fin = np.isfinite(lc[f])
+            assert np.array_equal(np.isfinite(mag[i, k]), fin)
+            np.testing.assert_allclose(mag[i, k][fin], lc[f][fin], rtol=0, atol=2e-5)
+            # the extinction magnitude itself, free of the surrogate's fp32 noise
+            if name == "extinction_p92":
+                want = orc.extinction_mags_p92_smc([case["filter_nu0"][f]], z, ebv)[0]
+            else:
+                want = case["ebv_coeff"][f] * ebv if ebv != 0 else 0.0
+            got = (mag[i, k][fin] - mag0[i, k][fin])
+            if np.isfinite(want) and fin.any():
+                np.testing.assert_allclose(got, want, rtol=0, atol=5e-13 * max(1.0, abs(want)) + 1e-11)
+    eng.close()
+
+
 def test_parts_match_oracle(torch_cuda):
     torch = torch_cuda
     case = cases.case_c2_dt05_limit()

@@ -95,3 +95,37 @@ def test_sharded_evaluator_single_rank():
 def test_legacy_alias():
     from nmma_amd.em.em_likelihood import EMTransientLikelihood, OpticalLightCurve
     assert OpticalLightCurve is EMTransientLikelihood
+
+
+def test_default_extinction_law_through_the_plugin():
+    """A sampled ``Ebv`` with the model's default ``extinction_law`` ("P92_SMC_host", model.py:198-201): the plugin
+    passes the filter frequencies (from ``filter_lambdas``) and the law to the engine; results match the oracle's
+    restatement of get_extinction_mags.  Without wavelengths for its filters the engine refuses a sampled Ebv."""
+    from nmma_amd import _lib as L
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    from oracle import nmma_oracle as orc
+    from tests.helpers import SimplePrior, oracle_from_case
+    case = cases.SHAPE_CASES["extinction_p92"]()
+    lam_m = {f: 2.99792458e8 / nu for f, nu in case["filter_nu0"].items()}
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    times, mags, sigmas = case["data"]
+
+    def build(filter_lambdas):
+        model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"],
+                                   model_parameters=case["model_parameters"], sample_times=case["sample_times"],
+                                   cosmo_grid=case["cosmo_grid"], filter_lambdas=filter_lambdas)
+        handler = FilterSystematicsHandler(case["observed_filters"], error_budget=1.0, light_curve_times=times)
+        return EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, priors,
+                                     filters=case["observed_filters"], detection_limit=case["detection_limit"])
+
+    lik = build(lam_m)
+    assert lik.sub_model.light_curve_model.extinction_law == "P92_SMC_host"
+    got = lik.log_likelihood_batch(case["theta"], case["names"])
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and (~floor).sum() > 20
+    assert rel_err(got[~floor], want[~floor]).max() <= 1e-6
+    with pytest.raises(L.NMMAHipError, match="Ebv"):
+        build(None).log_likelihood_batch(case["theta"], case["names"])

@@ -15,7 +15,8 @@ def hc():
     d, i, pd = C.c_double, C.c_int, C.POINTER(C.c_double)
     sig = {"hc_interp_np": [d, pd, pd, i, d, d], "hc_lerp_np": [d] * 5, "hc_ndtr": [d], "hc_log_ndtr": [d],
            "hc_log_gauss_mass_neginf": [d], "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
-           "hc_apply_slot": [i, i, d, pd], "hc_distance_modulus": [d], "hc_redshift_correction": [d]}
+           "hc_apply_slot": [i, i, d, pd], "hc_distance_modulus": [d], "hc_redshift_correction": [d],
+           "hc_extinction_mag": [i, d, d, d]}
     for name, args in sig.items():
         getattr(lib, name).restype = d
         getattr(lib, name).argtypes = args
@@ -96,3 +97,25 @@ def test_slots_and_distance(hc):
     assert hc.hc_apply_slot(3, 6, 0.0, _p(row)) == pytest.approx(np.arccos(0.3) * 180 / np.pi, rel=1e-15)
     assert hc.hc_distance_modulus(40.0) == pytest.approx(5.0 * (5 + np.log10(40.0)), rel=1e-15)
     assert hc.hc_redshift_correction(0.01) == pytest.approx(-2.5 * np.log10(1.01), rel=1e-14)
+
+
+def test_p92_smc_extinction_matches_oracle(hc):
+    """em_math.h:p92_smc_ext_mag against the oracle's restatement of extinctionFactorP92SMC + get_extinction_mags
+    (utils.py:373-428, model.py:323-342): inside the curve's range, at both edges, beyond the 2e16 Hz cut-off,
+    below the far-infrared end, and at Ebv = 0."""
+    from oracle import nmma_oracle as orc
+    lam_um = np.concatenate([np.geomspace(0.016, 900.0, 60), [0.0149, 0.0151, 999.0, 1001.0, 0.01, 5e3]])
+    nu = 2.99792458e14 / lam_um
+    for z in (0.0, 0.0098, 0.21):
+        for ebv in (0.05, 0.4, 1.7):
+            want = orc.extinction_mags_p92_smc(nu, z, ebv)
+            got = np.array([hc.hc_extinction_mag(1, x, 1 + z, ebv) for x in nu])
+            inside = np.isfinite(want) & (want != 0)
+            assert inside.sum() >= 55
+            np.testing.assert_allclose(got, want, rtol=2e-14, atol=2e-15)   # (10^x then log10: absolute, not relative)
+        assert all(hc.hc_extinction_mag(1, x, 1 + z, 0.0) == 0.0 for x in nu[:5])
+    # known shape of the SMC curve: ~1 near 0.55 um (the fit is normalised in B, converted with the MW A_B/A_V), steep UV rise
+    assert orc.p92_axav(0.55) == pytest.approx(1.0, abs=0.06)
+    assert 4.0 < orc.p92_axav(0.15) < 7.0
+    # the linear law is coeff * Ebv
+    assert hc.hc_extinction_mag(0, 3.1, 1.3, 0.25) == 3.1 * 0.25
