@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""The rows of README's "Measured on MI355X" table in one run (HIP events on the launch stream, 30 launches after 5 of warm-up).
+Usage: python tools/perf_table.py > gpurun_out/<tag>/perf_table.log"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmma_amd import synthetic as syn  # noqa: E402
+from tests import cases  # noqa: E402
+from tests.helpers import engine_from_case, plugin_from_case  # noqa: E402
+
+
+def timed(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+rows = [("c2_default", 4096), ("c2_default", 65536), ("syserr_param", 4096), ("syserr_time_nodes", 4096),
+        ("c2_dt05_limit", 4096), ("extinction_limit", 4096), ("extinction_p92", 4096), ("log_grid", 4096),
+        ("averaging", 4096), ("c4_shape", 8192), ("c4_shape", 65536)]
+for name, B in rows:
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    eng = engine_from_case(case)
+    th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
+    out = torch.empty(B, dtype=torch.float64, device="cuda:0")
+    us = timed(lambda: eng.loglike(th, out=out))
+    eng.check()
+    geo = eng.last_launch_geometry()
+    print(f"{name:20s} B={B:6d}: {us:8.1f} us/launch  {B / us:8.2f} Mevals/s  {eng.flops_per_eval * B / us / 1e6:6.1f} TF/s  "
+          f"block {geo['block']} tile {geo['tile_samples']}")
+    eng.close()
+
+# host-buffer entry point and the per-sample plugin call
+case = cases.case_c2_default()
+eng = engine_from_case(case)
+th = syn.draw_theta(7, 4096, case["names"])[1]
+for B in (4096, 1):
+    sub = np.ascontiguousarray(th[:B])
+    eng.loglike(sub)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.loglike(sub)
+    print(f"host numpy in/out    B={B:6d}: {(time.perf_counter() - t0) / 200 * 1e6:8.1f} us/call")
+eng.close()
+_, _, lik = plugin_from_case(case)
+p = dict(zip(case["names"], (float(v) for v in case["theta"][0])))
+lik.log_likelihood(p)
+t0 = time.perf_counter()
+for _ in range(500):
+    lik.log_likelihood(p)
+print(f"plugin log_likelihood(dict)      : {(time.perf_counter() - t0) / 500 * 1e6:8.1f} us/call")
