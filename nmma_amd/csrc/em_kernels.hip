@@ -66,6 +66,53 @@ __device__ __forceinline__ float relu1(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// ---------------------------------------------------------------------------------------
+// Layer 2 on bf16 MFMAs (em_logl): an fp32 value is the exact sum of three bf16 terms (8 + 8 + 8 significant bits,
+// round-to-nearest splits of exact residuals), so h*w = sum of bf16 x bf16 products, each exact in the MFMA's fp32
+// accumulation; the three smallest cross terms (<= 2^-25 relative) are dropped.  v_mfma_f32_16x16x32_bf16 runs at 16x
+// the rate of the fp32 MFMA and -- unlike it -- leaves the vector ALU to the other waves of the SIMD
+// (tools/ubench/valu_mix3.hip, bf16_split.hip).
+// EXPERIMENT, off by default (-DNMMA_MLP_BF16=1 builds it; all GPU parity tests pass with it): measured 34.1 us against
+// 30.5 us for the fp32 chain at B = 4096.  The split costs 18 VALU per record plus 8 register copies for the operand
+// tuples, and with two MFMA-role waves per SIMD one wave's split does not overlap the other's MFMAs.
+// ---------------------------------------------------------------------------------------
+#ifndef NMMA_MLP_BF16
+#define NMMA_MLP_BF16 0
+#endif
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// v_cvt_pk_bf16_f32 (round to nearest even): low half = a, high half = b
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// x - float(one bf16 half of pk) in one v_dot2c_f32_bf16: sel = (-1, 0) picks the low half, (0, -1) the high half.  The
+// selectors come from opaque s_mov's: as compile-time constants hipcc 7.2 folds (-1, 0) into the inline constant -1.0,
+// which the hardware reads as the fp32 pattern 0xBF800000 = (0, -1).  The residual is exactly representable.
+__device__ __forceinline__ float sub_bf16(float x, unsigned pk, unsigned sel) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, sel), x, false);
+}
+using u32x6 = __attribute__((ext_vector_type(6))) unsigned;
+using u32x8 = __attribute__((ext_vector_type(8))) unsigned;
+struct Bf16Split { unsigned p1a, p1b, p1c, p1d, p2a, p2b, p3a, p3b; };     // (p1c, p1d): second copy of (p1a, p1b)
+__device__ __forceinline__ Bf16Split split3_bf16(const f32x4 h, const unsigned sel_lo, const unsigned sel_hi) {
+    Bf16Split o;
+    o.p1a = cvt_pk_bf16(h[0], h[1]); o.p1b = cvt_pk_bf16(h[2], h[3]);
+    o.p1c = o.p1a; o.p1d = o.p1b;
+    const float r0 = sub_bf16(h[0], o.p1a, sel_lo), r1 = sub_bf16(h[1], o.p1a, sel_hi);
+    const float r2 = sub_bf16(h[2], o.p1b, sel_lo), r3 = sub_bf16(h[3], o.p1b, sel_hi);
+    o.p2a = cvt_pk_bf16(r0, r1); o.p2b = cvt_pk_bf16(r2, r3);
+    const float s0 = sub_bf16(r0, o.p2a, sel_lo), s1 = sub_bf16(r1, o.p2a, sel_hi);
+    const float s2 = sub_bf16(r2, o.p2b, sel_lo), s3 = sub_bf16(r3, o.p2b, sel_hi);
+    o.p3a = cvt_pk_bf16(s0, s1); o.p3b = cvt_pk_bf16(s2, s3);
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // Opaque identity: stops InstCombine from folding phi(load, load) into load(phi(addr)),
 // which would move every prefetched weight load back to its use (no latency hiding).
 __device__ __forceinline__ void opaque(f32x4& v) { asm volatile("" : "+v"(v)); }
@@ -266,8 +313,12 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                                           float* __restrict__ part, const int NBUF, int* sync,
                                           long long* __restrict__ dbg_generic) {
     g_llp dbg = (g_llp)(uintptr_t)dbg_generic;
+#if NMMA_MLP_BF16
+    constexpr int RECB = rec2_words(KP) * 4;
+#else
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
+#endif
     constexpr int NSL = NSLICE / NMW;
     constexpr int TS = 16 * R;
     const int W = P.n_items, NP = P.NP;
@@ -276,11 +327,26 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     gci32p items = as_global(P.items);
     gci32p idesc = as_global(reinterpret_cast<const int*>(P.item_desc));   // words 22, 23 of a descriptor = ntask[R - 1]
     gcf64p pmin = as_global(P.pmin), pinv = as_global(P.pinv);
+#if NMMA_MLP_BF16
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(uintptr_t)P.wrec2, 0, P.wrec2_bytes, 0x00020000);
+    const int off_a2 = lane * 16;
+    const int off_a3 = 1024 + lane * 8;
+    const int off_a1 = (384 + lane) * 4;
+    const int off_b = (384 + 64 * KP + (lane >> 4) * 4) * 4;
+    unsigned sel_lo, sel_hi;
+    asm volatile("s_mov_b32 %0, 0xbf80" : "=s"(sel_lo));
+    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(sel_hi));
+    auto ld2 = [&](int voff, int soff) -> u32x2 {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+    };
+#else
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(uintptr_t)P.wrec, 0, P.wrec_bytes, 0x00020000);
     const int off_a2 = lane * 16;
     const int off_a1 = (256 + lane) * 4;
     const int off_b = (256 + 64 * KP + (lane >> 4) * 4) * 4;
+#endif
     auto ld4 = [&](int voff, int soff) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
     };
@@ -311,16 +377,25 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     int base = item_base(0);
     f32x4 ra2[PF], rbias[PF];
     float ra1[PF][KP];
+#if NMMA_MLP_BF16
+    u32x2 ra3[PF];
+#endif
     // The ring holds records g .. g+PF-2 when record g is consumed; the step that consumes slot g % PF
     // refills the slot consumed ONE STEP EARLIER with record g+PF-1.  Every reader of that slot has been
     // issued before the load, so the load writes the slot's own registers (loading into the slot being
     // consumed makes hipcc double-buffer the whole ring: 16 v_mov_b64 and an s_waitcnt vmcnt(0) per chunk).
     ra2[PF - 1] = f32x4{0, 0, 0, 0}; rbias[PF - 1] = f32x4{0, 0, 0, 0};
+#if NMMA_MLP_BF16
+    ra3[PF - 1] = u32x2{0, 0};
+#endif
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) ra1[PF - 1][kp] = 0.f;
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u) {
         ra2[u] = ld4(off_a2, base + u * RECB);
+#if NMMA_MLP_BF16
+        ra3[u] = ld2(off_a3, base + u * RECB);
+#endif
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, base + u * RECB);
         rbias[u] = ld4(off_b, base + u * RECB);
@@ -390,17 +465,53 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                         }
                     }
                     const f32x4 a2 = ra2[u];
+#if NMMA_MLP_BF16
+                    const u32x2 a3 = ra3[u];
+#endif
                     // refill the slot consumed one step earlier; in the last chunk of an item step 0 still
                     // fetches the item's last record, steps 1.. fetch the first PF-1 records of the next item
                     const int pu = (u + PF - 1) % PF;
                     if (u == 1 && last_chunk) soff = nbase;
 #ifndef NMMA_DBG_NOLOAD
                     ra2[pu] = ld4(off_a2, soff);
+#if NMMA_MLP_BF16
+                    ra3[pu] = ld2(off_a3, soff);
+#endif
 #pragma unroll
                     for (int kp = 0; kp < KP; ++kp) ra1[pu][kp] = ld1(off_a1 + kp * 256, soff);
                     rbias[pu] = ld4(off_b, soff);
 #endif
                     soff += RECB;
+#if NMMA_MLP_BF16
+                    {
+                        // Operand tuples are 4-register windows of ONE register sequence each, so that no copies are needed:
+                        //   weights  [w3 | w1 | w2]        -> (w3, w1), (w1, w2)
+                        //   hidden   [h1' | h2 | h1 | h3]  -> (h1', h2), (h2, h1), (h1, h3)      (h1' = h1 packed a second time)
+                        // products: (h1', h2).(w1, w2) + (h2, h1).(w1, w2) + (h1, h3).(w3, w1)
+                        const u32x4 w12 = __builtin_bit_cast(u32x4, a2);
+                        const u32x6 wseq = u32x6{a3[0], a3[1], w12[0], w12[1], w12[2], w12[3]};
+                        const u32x4 w31 = __builtin_shufflevector(wseq, wseq, 0, 1, 2, 3);
+                        const u32x4 w12b = __builtin_shufflevector(wseq, wseq, 2, 3, 4, 5);
+#pragma unroll
+                        for (int rb = 0; rb < R; ++rb) {
+#ifdef NMMA_BF16_PRIO
+                            __builtin_amdgcn_s_setprio(NMMA_BF16_PRIO);
+#endif
+                            const Bf16Split q = split3_bf16(h[rb], sel_lo, sel_hi);
+#ifdef NMMA_BF16_PRIO
+                            __builtin_amdgcn_s_setprio(0);
+#endif
+                            const u32x8 hseq = u32x8{q.p1c, q.p1d, q.p2a, q.p2b, q.p1a, q.p1b, q.p3a, q.p3b};
+                            acc[rb][0] = mfma_bf16(w12b, __builtin_shufflevector(hseq, hseq, 0, 1, 2, 3), acc[rb][0]);   // h1 w1 + h2 w2
+                            acc[rb][1] = mfma_bf16(w12b, __builtin_shufflevector(hseq, hseq, 2, 3, 4, 5), acc[rb][1]);   // h2 w1 + h1 w2
+                            acc[rb][0] = mfma_bf16(w31, __builtin_shufflevector(hseq, hseq, 4, 5, 6, 7), acc[rb][0]);    // h1 w3 + h3 w1
+                        }
+                    }
+#ifndef NMMA_BF16_SB
+#define NMMA_BF16_SB 1
+#endif
+                    if (NMMA_BF16_SB > 0 && (u % NMMA_BF16_SB) == NMMA_BF16_SB - 1) __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -415,6 +526,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
                     __builtin_amdgcn_sched_group_barrier(0x020, 2 + KP, 0);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
             const int slice = wave * NSL + sl;
