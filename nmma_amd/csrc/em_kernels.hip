@@ -1260,6 +1260,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         else isig = 0.0;             // infinite data error: upper limit
                         if (sig != sig) sig_bad = true;
                     }
+                    // (two explicit accumulations: written as "chi += v" in one branch and "gp += ..." in the other, hipcc merges
+                    //  them into ONE add on a two-element private array indexed by the branch -- scratch memory and an
+                    //  s_waitcnt vmcnt(0) per datum)
+                    double add_chi = 0.0, add_gp = 0.0;
                     if (isig != 0.0 || sig_bad) {
                         double v;
                         if (EXT && lim_finite) {         // uniform: truncated Gaussian with a finite detection limit
@@ -1269,10 +1273,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                             v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
                             if (!(est < dinf()) || sig_bad) v = dnan();
                         }
-                        chi += v;
+                        add_chi = v;
                     } else {
-                        gp += upper_limit_term(c_m[u], est, e_sys);
+                        add_gp = upper_limit_term(c_m[u], est, e_sys);
                     }
+                    opaque(add_chi); opaque(add_gp);
+                    chi += add_chi; gp += add_gp;
                 }
             }
         };
