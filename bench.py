@@ -133,11 +133,33 @@ def main():
     send = torch.zeros(slot, dtype=torch.float64, device=dev) if use_dist else None
     gathered = torch.empty(world * slot, dtype=torch.float64, device=dev) if use_dist else None
 
+    # N > 1: the all-gather of step i runs on a second stream while the kernel of step i + 1 runs on the first (two logL
+    # buffers; events order "kernel i -> gather i" and "gather i -> kernel i + 2").  Host cost per step is the same as the
+    # blocking form (~38 us, tools/overlap_probe.py), but the GPU no longer serialises kernel + collective.
+    # NMMA_BENCH_BLOCKING=1 keeps everything on one stream.
+    pipelined = use_dist and not share_gpu and slot == B and os.environ.get("NMMA_BENCH_BLOCKING") != "1"
+    if pipelined:
+        s_eval, s_coll = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = [out, torch.empty_like(out)]
+        gathers = [gathered, torch.empty_like(gathered)]
+        ev_eval = [torch.cuda.Event() for _ in range(2)]
+        ev_coll = [torch.cuda.Event() for _ in range(2)]
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(s_coll)            # torch.distributed enqueues on the current stream
+
     def step(i):
+        if pipelined:
+            b = i & 1
+            if i >= 2:
+                s_eval.wait_event(ev_coll[b])    # the gather that read outs[b] two steps ago
+            eng.loglike(thetas[i % N_THETA_SETS], out=outs[b], stream=s_eval)
+            ev_eval[b].record(s_eval)
+            s_coll.wait_event(ev_eval[b])
+            dist.all_gather_into_tensor(gathers[b], outs[b])
+            ev_coll[b].record(s_coll)
+            return
         eng.loglike(thetas[i % N_THETA_SETS], out=out)
         if use_dist:
-            # blocking form on purpose: an overlapped variant (second stream + events, or async_op) costs ~60 us of
-            # host work per step in torch.distributed -- more than the 32 us kernel it would hide the collective behind
             if share_gpu:
                 send[:B] = out
                 parts = [torch.empty(slot, dtype=torch.float64) for _ in range(world)]
@@ -148,6 +170,11 @@ def main():
                 send[:B] = out
                 dist.all_gather_into_tensor(gathered, send)
 
+    # A full collection of Python's garbage collector takes ~75 ms with torch imported (2 400 launches' worth) and fires
+    # whenever enough container objects have been allocated: none inside the timed region
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -169,6 +196,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_end()
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,7 +222,8 @@ def main():
                                    f"batch={B} live points per GPU, sigma_sys=1, detection_limit=inf",
                        "batch_per_gpu": B, "global_batch": global_batch,
                        "exchange": ("gloo all_gather (TEST MODE: ranks share one GPU)" if share_gpu else
-                                    "RCCL all_gather of logL per step") if world > 1 else "none",
+                                    ("RCCL all_gather of logL per step, pipelined with the next evaluation" if pipelined else
+                                     "RCCL all_gather of logL per step")) if world > 1 else "none",
                        "launch": geom},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
@@ -219,8 +248,10 @@ def main():
 def host_call_ms(eng, case, syn):
     """PCIe-inclusive cost of the reference-shaped call: numpy theta in host memory -> logL in host memory
     (nmma_em_loglike_host), for the full batch and for the single point an unmodified sampler sends.  Never `value`."""
+    import gc
     import numpy as np
     res = {}
+    gc.collect()
     for b in (4096, 1):
         th = np.ascontiguousarray(syn.draw_theta(4321, b, case["names"])[1])
         for _ in range(5):

@@ -311,9 +311,14 @@ class EMEngine:
             raise L.NMMAHipError(f"theta must be [B, >={len(self.parameter_names)}], got {tuple(t.shape)}")
         return t.contiguous()
 
-    def _stream(self):
-        """torch's current stream OF THE HANDLE'S DEVICE (the C side launches there)."""
+    def _stream(self, stream=None):
+        """The launch stream: an explicit torch stream of the handle's device, else torch's current stream OF THAT
+        DEVICE (the C side launches there)."""
         import torch
+        if stream is not None:
+            if stream.device.index != self.device:
+                raise L.NMMAHipError(f"stream belongs to {stream.device}, the handle to cuda:{self.device}")
+            return C.c_void_p(stream.cuda_stream)
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _check_out(self, out, n):
@@ -322,9 +327,9 @@ class EMEngine:
                 or out.device.index != self.device or out.numel() < n or not out.is_contiguous()):
             raise L.NMMAHipError(f"out must be a contiguous float64 tensor on cuda:{self.device} with >= {n} elements")
 
-    def loglike(self, theta, out=None):
+    def loglike(self, theta, out=None, stream=None):
         """logL for every row of ``theta[B, D]``.  torch CUDA tensor in -> torch tensor out
-        (asynchronous on the current stream); numpy in -> numpy out (synchronous)."""
+        (asynchronous on ``stream``, default torch's current stream); numpy in -> numpy out (synchronous)."""
         import torch
         if not isinstance(theta, torch.Tensor):
             th = _f64(theta)
@@ -341,7 +346,7 @@ class EMEngine:
         else:
             self._check_out(out, t.shape[0])
         L.check(self._lib.nmma_em_loglike(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
-                                          C.c_void_p(out.data_ptr()), self._stream()), "nmma_em_loglike")
+                                          C.c_void_p(out.data_ptr()), self._stream(stream)), "nmma_em_loglike")
         return out
 
     def loglike_parts(self, theta):
