@@ -218,6 +218,17 @@ int32_t nmma_lc_regrid(nmma_em_handle* h, const double* lc_src_dev, int32_t n_sr
                        const double* src_times_host, const int32_t* src_index_host, const int32_t* n_sources_host,
                        int64_t B, double* out_dev, void* stream);
 
+/* GW term of the joint likelihood for strain already projected onto each detector: replaces B calls of
+ * bilby.gw.likelihood.GravitationalWaveTransient.log_likelihood_ratio (no marginalisation) as wrapped by
+ * nmma/gw/gw_likelihood.py:97-247 and summed by MultiMessengerLikelihood (joint/joint_likelihood.py:62-67):
+ *   out_dev[b] = sum_ifo ( Re<d|h_b> - <h_b|h_b>/2 ),   <a|b> = 4/duration * sum_f conj(a_f) b_f * weight_f
+ * strain_dev[B][n_ifo][n_freq] and data_dev[n_ifo][n_freq] are complex128 (re, im interleaved);
+ * weight_dev[n_ifo][n_freq] = 1/S_n(f) inside the detector's frequency mask, 0 outside.
+ * Stateless and asynchronous on `stream` of `device`.  Waveform generation and the detector response (lalsimulation,
+ * bilby.gw.detector) stay with the caller; parity against bilby is unpinned (absent from the build image). */
+int32_t nmma_gw_loglike_ratio(const double* strain_dev, const double* data_dev, const double* weight_dev, int64_t B,
+                              int32_t n_ifo, int64_t n_freq, double duration, double* out_dev, int32_t device, void* stream);
+
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                              float* coeff_dev, void* stream);

@@ -91,6 +91,8 @@ PROTOTYPES = {
     "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_lc_regrid": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _pd, _pi, _pi, C.c_int64, C.c_void_p,
                                    C.c_void_p]),
+    "nmma_gw_loglike_ratio": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double,
+                                         C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_em_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "nmma_em_check": (C.c_int32, [C.c_void_p]),

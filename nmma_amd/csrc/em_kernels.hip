@@ -2084,4 +2084,5 @@ __global__ void lc_to_detector(const EmDev* __restrict__ Pp, const double* __res
 }  // namespace nmma
 
 #include "em_logl_iw.inc"
+#include "gw_kernels.inc"
 #include "em_api.inc"

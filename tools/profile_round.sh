@@ -4,7 +4,7 @@
 #   bench line (with cpu baselines)          -> <tag>/bench_line.json
 #   rocprofv3 --kernel-trace --stats         -> <tag>/stats_<what>/   for: bench (config 2, lean task), c2_dt05_limit @ 4096
 #                                               (extended task), c4_shape @ 8192 (config 4 shape), models (Me2017, combined,
-#                                               em_fused outputs), bench with the opt-in in-wave kernel
+#                                               em_fused outputs), bench with the opt-in in-wave kernel, gw (inner products)
 #   rocprofv3 --pmc (separate passes)        -> <tag>/pmc_<set>/      for the bench command
 # Under rocprofv3 the program goes directly after `--` (no env / bash -c hops).
 tag=${1:-r02}
@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05 -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 tools/perf_gw.py 2048 > $o/stats_gw.log 2>&1
 export NMMA_EM_IW=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_iw -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_iw.log 2>&1
 unset NMMA_EM_IW
