@@ -611,6 +611,10 @@ struct LdsW {
 };
 
 // One candidate layout: `nbuf` ring slots, photometry staged or not.
+// Dynamic LDS a launch may ask for: the 160 KiB of a CU minus the kernel's static words (g_wd_trip), rounded down to the
+// 1-KiB granule the layouts use -- a layout of exactly 160 KiB is refused by hipFuncSetAttribute.
+constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
+
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
                                          int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat) {
     const int TS = 16 * R;
@@ -646,7 +650,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // slots; the generic path keeps 3 partial-sum buffers next to its double-buffered tables.
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
                                      int all_fast, int n_data, int n_sys_slots) {
-    constexpr int LDS_MAX = 160 * 1024;
+    constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     const int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     LdsW L{};
     for (int pass = 0; pass < 2; ++pass)
@@ -1316,8 +1320,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // re-check of the extended task: the guess can differ from np.interp's bracket only when the epoch lies within
     // ~1e-13 of a grid node, where both brackets give the same value to rounding (linear interpolation is continuous).
     // ---------------------------------------------------------------------------------
-    auto lean_task = [&](auto typeb_tag, const int k, const int c) {
+    auto lean_task = [&](auto typeb_tag, auto two_tag, const int k, const int c) {
         constexpr bool TYPEB = decltype(typeb_tag)::value;
+        // TWO: sample_times differ from the SVD grid -- each of a datum's two sample nodes is a stage-1 lerp between two
+        // SVD rows (lightcurve_generation.py:177), evaluated in two passes of the same four FMA chains
+        constexpr bool TWO = decltype(two_tag)::value;
         const ItemDesc& it = itab[k];
         const int o = it.o;
         if (c == 0) {      // this wave stages the item's basis rows (see fast_task)
@@ -1400,44 +1407,74 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             cc_[q] = (lds_c2p)cslot;
         }
         // the two basis rows of every slot, read as 16-byte pairs [VA[2j], VA[2j+1]] (pair 5 = [span, mins]); the four FMA
-        // chains (2 slots x 2 rows) advance together, one pair per step, so that no instruction waits for its predecessor
-        lds_c2p row_[NSL];
+        // chains (2 slots x 2 rows) advance together, one pair per step, so that no instruction waits for its predecessor.
+        // TWO: pass 0 reconstructs the SVD rows around sample node lo, pass 1 those around node lo + 1.
+        const lds_c2p rows2 = (lds_c2p)(tbl);
+        const lds_cdp s1of_l = (lds_cdp)(tbl + P.tab_off_s1of), s1inv_l = (lds_cdp)(tbl + P.tab_off_s1inv);
+        typedef const __attribute__((address_space(3))) int* lds_cip;
+        const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
+        double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
 #pragma unroll
-        for (int u = 0; u < NSL; ++u) row_[u] = (lds_c2p)(tbl) + lo_[u] * 6;
-        double a0_[NSL], a1_[NSL];
-        f64x2 p0_[NSL], p1_[NSL];
+        for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
+            lds_c2p ra_[NSL], rb_[NSL];
 #pragma unroll
-        for (int u = 0; u < NSL; ++u) { p0_[u] = row_[u][0]; p1_[u] = row_[u][6]; }
-        f64x2 cq_[NCC];
+            for (int u = 0; u < NSL; ++u) {
+                if constexpr (TWO) {
+                    const int j = lo_[u] + pass;
+                    int i1 = s1i_l[j];
+                    i1 = i1 < 0 ? 0 : i1;                         // (nodes outside the SVD grid lie outside [jlo, jhi]: never bracketed)
+                    const int i2 = i1 + 1 < NT ? i1 + 1 : NT - 1;
+                    ra_[u] = rows2 + i1 * 6; rb_[u] = rows2 + i2 * 6;
+                } else {
+                    ra_[u] = rows2 + lo_[u] * 6; rb_[u] = ra_[u] + 6;
+                }
+            }
+            double a0_[NSL], a1_[NSL];
+            f64x2 p0_[NSL], p1_[NSL];
 #pragma unroll
-        for (int q = 0; q < NCC; ++q) cq_[q] = cc_[q][0];
+            for (int u = 0; u < NSL; ++u) { p0_[u] = ra_[u][0]; p1_[u] = rb_[u][0]; }
+            f64x2 cq_[NCC];
 #pragma unroll
-        for (int jp = 0; jp < 5; ++jp) {
-            f64x2 n0_[NSL], n1_[NSL], nq_[NCC];
+            for (int q = 0; q < NCC; ++q) cq_[q] = cc_[q][0];
 #pragma unroll
-            for (int u = 0; u < NSL; ++u) { n0_[u] = row_[u][jp + 1]; n1_[u] = row_[u][6 + jp + 1]; }
-            if (jp < 4) {
+            for (int jp = 0; jp < 5; ++jp) {
+                f64x2 n0_[NSL], n1_[NSL], nq_[NCC];
 #pragma unroll
-                for (int q = 0; q < NCC; ++q) nq_[q] = cc_[q][jp + 1];
+                for (int u = 0; u < NSL; ++u) { n0_[u] = ra_[u][jp + 1]; n1_[u] = rb_[u][jp + 1]; }
+                if (jp < 4) {
+#pragma unroll
+                    for (int q = 0; q < NCC; ++q) nq_[q] = cc_[q][jp + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) {
+                    const f64x2 cq = cq_[TYPEB ? u : 0];
+                    if (jp == 0) { a0_[u] = p0_[u][0] * cq[0]; a1_[u] = p1_[u][0] * cq[0]; }
+                    else { a0_[u] = fma(p0_[u][0], cq[0], a0_[u]); a1_[u] = fma(p1_[u][0], cq[0], a1_[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) {
+                    const f64x2 cq = cq_[TYPEB ? u : 0];
+                    a0_[u] = fma(p0_[u][1], cq[1], a0_[u]); a1_[u] = fma(p1_[u][1], cq[1], a1_[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) { p0_[u] = n0_[u]; p1_[u] = n1_[u]; }
+                if (jp < 4) {
+#pragma unroll
+                    for (int q = 0; q < NCC; ++q) cq_[q] = nq_[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int u = 0; u < NSL; ++u) {
-                const f64x2 cq = cq_[TYPEB ? u : 0];
-                if (jp == 0) { a0_[u] = p0_[u][0] * cq[0]; a1_[u] = p1_[u][0] * cq[0]; }
-                else { a0_[u] = fma(p0_[u][0], cq[0], a0_[u]); a1_[u] = fma(p1_[u][0], cq[0], a1_[u]); }
+                const double ya = a0_[u] * p0_[u][0] + p0_[u][1], yb = a1_[u] * p1_[u][0] + p1_[u][1];   // (VA[i,:].c) span[i] + mins[i]
+                if constexpr (TWO) {
+                    const int j = lo_[u] + pass;
+                    // stage 1: ((yb - ya) / dx) * off + ya with the reciprocal of dx from the table
+                    ynode_[pass][u] = ((yb - ya) * s1inv_l[j]) * s1of_l[j] + ya;
+                } else {
+                    ynode_[0][u] = ya; ynode_[1][u] = yb;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) {
-                const f64x2 cq = cq_[TYPEB ? u : 0];
-                a0_[u] = fma(p0_[u][1], cq[1], a0_[u]); a1_[u] = fma(p1_[u][1], cq[1], a1_[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) { p0_[u] = n0_[u]; p1_[u] = n1_[u]; }
-            if (jp < 4) {
-#pragma unroll
-                for (int q = 0; q < NCC; ++q) cq_[q] = nq_[q];
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         double v_[NSL], est_[NSL], m_[NSL];
         bool ul_[NSL];
@@ -1446,7 +1483,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
             const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * inv_dt;
-            double y0 = a0_[u] * p0_[u][0] + p0_[u][1], y1 = a1_[u] * p1_[u][0] + p1_[u][1];
+            double y0 = ynode_[0][u], y1 = ynode_[1][u];
             y0 = y0 + dmrc; y1 = y1 + dmrc;
             const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
             const double x = (tm[1] - est) * sl[0];
@@ -1546,8 +1583,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 else if (kind == NMMA_SYS_NODES) fast_task(std::integral_constant<int, 2>{}, k, t);
                 else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
-                if (itab[k].nf <= 16) lean_task(std::true_type{}, k, t);
-                else lean_task(std::false_type{}, k, t);
+                const bool two = !(itab[k].identity != 0 && itab[k].same_grid != 0);       // uniform per item
+                if (itab[k].nf <= 16) { if (two) lean_task(std::true_type{}, std::true_type{}, k, t); else lean_task(std::true_type{}, std::false_type{}, k, t); }
+                else { if (two) lean_task(std::false_type{}, std::true_type{}, k, t); else lean_task(std::false_type{}, std::false_type{}, k, t); }
             }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);

@@ -53,6 +53,23 @@ def case_c2_dt05_limit():
     return c
 
 
+def case_c2_dt05():
+    """The documented CLI call ``--em-tmin .1 --em-tmax 20 --em-tstep .5`` with the default error budget and no
+    detection limit: two-stage interpolation (sample nodes between SVD nodes) on the lean task."""
+    c = _base(seed=2236)
+    c["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    return c
+
+
+def case_grid_subset():
+    """sample_times = every second node of the SVD training grid: every sample node coincides with an SVD node
+    (stage-1 offsets are all zero) but the grids differ."""
+    c = _base(seed=2237, batch=48)
+    tt = next(iter(c["svd"].values()))["tt"]
+    c["sample_times"] = np.asarray(tt)[::2].copy()
+    return c
+
+
 def case_limit_violated():
     """One datum fainter than the detection limit -> -inf -> floor for every sample."""
     c = _base(seed=2235, batch=8)
@@ -200,6 +217,8 @@ def case_small_hidden():
 CASES = {
     "c2_default": case_c2_default,
     "c2_dt05_limit": case_c2_dt05_limit,
+    "c2_dt05": case_c2_dt05,
+    "grid_subset": case_grid_subset,
     "limit_violated": case_limit_violated,
     "syserr_param": case_syserr_param,
     "syserr_time_nodes": case_syserr_time_nodes,
