@@ -306,7 +306,13 @@ constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 // fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
 constexpr int TMAP_MAX = 512;
 // fast mode: most photometry points (all filters) staged in LDS as [t | m | 1/sigma | log sigma]
-constexpr int DAT_MAX = 512;
+constexpr int DAT_MAX = 2560;
+// most points of one filter the lean task takes (passes of 32 per group of 16 lanes; beyond this the extended task's wider
+// groups win)
+#ifndef NMMA_LEAN_NF_MAX
+#define NMMA_LEAN_NF_MAX 2560
+#endif
+constexpr int LEAN_NF_MAX = NMMA_LEAN_NF_MAX;
 
 template <int R, int KP, int PF, int NMW, int NVW, bool FAST>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
@@ -1363,9 +1369,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         bool inside_[NSL], valid_[NSL];
         int lo_[NSL];
         lds_c2p D_[NSL];
+        // (filters with 17 .. 32 points take one pass over the lane's two slots; more points further passes of 32: `pp`)
+        auto stage_p = [&](const int pp) {
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
-            const int dd = TYPEB ? gi : gi + 16 * u;
+            const int dd = TYPEB ? gi : gi + 16 * u + 32 * pp;
             valid_[u] = dd < nf;
             D_[u] = dat4 + 2 * (d0 + (valid_[u] ? dd : 0));
             const double t = D_[u][0][0];
@@ -1380,6 +1388,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             lo_[u] = lo;
             asm volatile("" : "+v"(dtx_[u]), "+v"(lo_[u]));   // (evaluated here, before the wait for the MLP)
         }
+        };
+        stage_p(0);
         // ---- stage Q (needs the coefficients of item k)
         if (c == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1413,6 +1423,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cdp s1of_l = (lds_cdp)(tbl + P.tab_off_s1of), s1inv_l = (lds_cdp)(tbl + P.tab_off_s1inv);
         typedef const __attribute__((address_space(3))) int* lds_cip;
         const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
+        double v_[NSL], gp_[NSL];
+        auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
 #pragma unroll
         for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
@@ -1476,7 +1488,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 }
             }
         }
-        double v_[NSL], est_[NSL], m_[NSL];
+        double est_[NSL], m_[NSL];
         bool ul_[NSL];
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
@@ -1495,12 +1507,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
             est_[u] = est; m_[u] = tm[1];
         }
-        double gp_[NSL] = {0.0, 0.0};
+        gp_[0] = 0.0; gp_[1] = 0.0;
         if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
 #pragma unroll
             for (int u = 0; u < NSL; ++u)
                 if (ul_[u]) gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), it.e_const);
         }
+        };
+        stage_q();
         lds_dp chi_l = (lds_dp)chi_tot;
         lds_dp gp_l = (lds_dp)gp_tot;
         if constexpr (TYPEB) {
@@ -1521,9 +1535,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 }
             }
         } else {
-            const double chi = group_sum(v_[0] + v_[1], 16);
+            double vacc = v_[0] + v_[1], gacc = gp_[0] + gp_[1];
+            for (int pp = 1; pp * 32 < nf; ++pp) {          // uniform: only filters with more than 32 points
+                stage_p(pp);
+                stage_q();
+                vacc += v_[0] + v_[1]; gacc += gp_[0] + gp_[1];
+            }
+            const double chi = group_sum(vacc, 16);
             double gp = 0.0;
-            if (it.has_ul) gp = group_sum(gp_[0] + gp_[1], 16);
+            if (it.has_ul) gp = group_sum(gacc, 16);
             if (gi == 0) {
                 const int s = s_[0];
                 chi_l[o * TS + s] = chi;

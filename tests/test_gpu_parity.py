@@ -246,6 +246,25 @@ def test_shape_cases_match_oracle(name, tile, torch_cuda, monkeypatch):
     eng.close()
 
 
+def test_lean_task_photometry_limits(torch_cuda):
+    """The lean task keeps the photometry in LDS: up to ~2 400 points (BASELINE config 4's shape) it fits next to the ring,
+    beyond that the handle falls back to the extended task -- same numbers either way (oracle spot check)."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    filters = [f"q{i:02d}" for i in range(8)]
+    for counts in (120, 400):                        # 960 points: lean; 3 200 points: extended (does not fit)
+        case = cases._base(seed=4242 + counts, filters=filters, counts=counts, batch=40, upper_limit_filter="q03")
+        eng = engine_from_case(case)
+        got = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+        eng.check()
+        rows = np.arange(0, 40, 5)
+        want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"][rows])
+        floor = want == FLOOR
+        assert np.array_equal(got[rows] == FLOOR, floor)
+        assert rel_err(got[rows][~floor], want[~floor]).max() <= LOGL_RTOL
+        eng.close()
+
+
 def test_check_reports_clean_handle(torch_cuda):
     """nmma_em_check synchronises and finds no watchdog trip after ordinary launches."""
     torch = torch_cuda
