@@ -638,7 +638,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
     if (L.dat >= 0) off = align16(off + 4 * n_data * 8);
-    L.epar = off;  off = align16(off + (all_fast == 2 ? n_sys_slots * TS * 8 : 0));   // extended fast mode: sysv[slot][sample]
+    L.epar = off;  off = align16(off + (all_fast ? n_sys_slots * TS * 8 : 0));        // fast modes: sysv[slot][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
     L.cdl = off;  off = align16(off + 16 * 2 * 4 * 16 * 8);          // per wave (any role): 2 x 4 slots x 16 coefficients
@@ -681,6 +681,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr int TS = 16 * R;
     constexpr int PF = (R == 1) ? 8 : 4;
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
+    // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
+    // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
+    constexpr bool LEANX = FASTM == 3;
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     const EmDev& P = *Pp;
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     for (int q = 0; q < P.n_sys_slots; ++q) {
                         const double v = apply_slot(P.sys_slots[q], row);
                         chk += v;
-                        if constexpr (EXT) reinterpret_cast<double*>(smem + L.epar)[q * TS + lane] = v;   // sysv[slot][sample]
+                        if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + lane] = v;   // sysv[slot][sample]
                     }
                     bad[lane] = 0;
 
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             for (int q = 0; q < P.n_sys_slots; ++q) {
                 const double v = apply_slot(P.sys_slots[q], row);
                 chk += v;
-                if constexpr (EXT) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
+                if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
             }
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
@@ -1326,8 +1329,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // re-check of the extended task: the guess can differ from np.interp's bracket only when the epoch lies within
     // ~1e-13 of a grid node, where both brackets give the same value to rounding (linear interpolation is continuous).
     // ---------------------------------------------------------------------------------
-    auto lean_task = [&](auto typeb_tag, auto two_tag, const int k, const int c) {
+    auto lean_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, const int k, const int c) {
         constexpr bool TYPEB = decltype(typeb_tag)::value;
+        // SYS: one sampled systematic per filter or shared (em_syserr): sigma_tot = sqrt(sigma_data^2 + e^2) per datum and sample,
+        // with the extended task's expressions (the photometry record then carries sigma_data instead of 1 / sigma_tot)
+        constexpr bool SYS = decltype(sys_tag)::value;
         // TWO: sample_times differ from the SVD grid -- each of a datum's two sample nodes is a stage-1 lerp between two
         // SVD rows (lightcurve_generation.py:177), evaluated in two passes of the same four FMA chains
         constexpr bool TWO = decltype(two_tag)::value;
@@ -1423,7 +1429,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cdp s1of_l = (lds_cdp)(tbl + P.tab_off_s1of), s1inv_l = (lds_cdp)(tbl + P.tab_off_s1inv);
         typedef const __attribute__((address_space(3))) int* lds_cip;
         const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
-        double v_[NSL], gp_[NSL];
+        double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
+        const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
 #pragma unroll
@@ -1498,12 +1505,24 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             double y0 = ynode_[0][u], y1 = ynode_[1][u];
             y0 = y0 + dmrc; y1 = y1 + dmrc;
             const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
-            const double x = (tm[1] - est) * sl[0];
-            double v = (-(x * x) / 2.0 - kNormPdfLogC) - sl[1];
+            double isig = sl[0], lsig = sl[1];
+            bool sig_bad = false;
+            if constexpr (SYS) {
+                const double sd = sl[0];                      // sigma_data
+                const double e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
+                esys_[u] = e_sys;
+                const double sig = sqrt(sd * sd + e_sys * e_sys);
+                const bool fin = (sig - sig == 0.0);
+                isig = fin ? 1.0 / sig : 0.0;                 // infinite data error: upper limit
+                lsig = log(sig);
+                sig_bad = (fin & !(sig > 0)) | (sig != sig);
+            }
+            const double x = (tm[1] - est) * isig;
+            double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
             opaque(v);                                        // (computed on every lane: no exec-masked region around the chain)
             // outside the model window est = +inf: truncnorm.logpdf(loc = inf) = NaN (em_likelihood.py:252-256)
-            v = inside_[u] ? v : dnan();
-            ul_[u] = valid_[u] & (sl[0] == 0.0);              // infinite data error: an upper limit
+            v = (inside_[u] & !sig_bad) ? v : dnan();
+            ul_[u] = valid_[u] & (isig == 0.0) & !sig_bad;    // infinite data error: an upper limit
             v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
             est_[u] = est; m_[u] = tm[1];
         }
@@ -1511,7 +1530,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
 #pragma unroll
             for (int u = 0; u < NSL; ++u)
-                if (ul_[u]) gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), it.e_const);
+                if (ul_[u]) gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const);
         }
         };
         stage_q();
@@ -1536,10 +1555,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
         } else {
             double vacc = v_[0] + v_[1], gacc = gp_[0] + gp_[1];
-            for (int pp = 1; pp * 32 < nf; ++pp) {          // uniform: only filters with more than 32 points
-                stage_p(pp);
-                stage_q();
-                vacc += v_[0] + v_[1]; gacc += gp_[0] + gp_[1];
+            if constexpr (LEANX) {
+                for (int pp = 1; pp * 32 < nf; ++pp) {      // uniform: only filters with more than 32 points
+                    stage_p(pp);
+                    stage_q();
+                    vacc += v_[0] + v_[1]; gacc += gp_[0] + gp_[1];
+                }
             }
             const double chi = group_sum(vacc, 16);
             double gp = 0.0;
@@ -1604,8 +1625,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
                 const bool two = !(itab[k].identity != 0 && itab[k].same_grid != 0);       // uniform per item
-                if (itab[k].nf <= 16) { if (two) lean_task(std::true_type{}, std::true_type{}, k, t); else lean_task(std::true_type{}, std::false_type{}, k, t); }
-                else { if (two) lean_task(std::false_type{}, std::true_type{}, k, t); else lean_task(std::false_type{}, std::false_type{}, k, t); }
+                const bool sysp = LEANX && itab[k].kind == NMMA_SYS_PARAM;
+                auto run = [&](auto tb) {
+                    if constexpr (LEANX) {
+                        if (sysp) {
+                            if (two) lean_task(tb, std::true_type{}, std::true_type{}, k, t); else lean_task(tb, std::false_type{}, std::true_type{}, k, t);
+                            return;
+                        }
+                    }
+                    if (two) lean_task(tb, std::true_type{}, std::false_type{}, k, t); else lean_task(tb, std::false_type{}, std::false_type{}, k, t);
+                };
+                if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
             }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
