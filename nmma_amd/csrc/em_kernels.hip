@@ -629,7 +629,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.nbuf = nbuf;
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
-    L.stl = off;  off = align16(off + NS * 8);
+    L.stl = off;  off = align16(off + 2 * NS * 8);                   // sample times | 1 / (t[j+1] - t[j])
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             bad[vt] = 0;
         }
         for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
-        for (int j = vt; j < NS; j += NV) stl[j] = P.st[j];
+        for (int j = vt; j < NS; j += NV) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? 1.0 / (P.st[j + 1] - P.st[j]) : 0.0; }
         if constexpr (FAST) {
             int* tmap = reinterpret_cast<int*>(smem + L.tmap);
             gci32p src = as_global(P.task_map[R - 1]);
@@ -1329,7 +1329,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // re-check of the extended task: the guess can differ from np.interp's bracket only when the epoch lies within
     // ~1e-13 of a grid node, where both brackets give the same value to rounding (linear interpolation is continuous).
     // ---------------------------------------------------------------------------------
-    auto lean_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, const int k, const int c) {
+    auto lean_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, auto nonuni_tag, const int k, const int c) {
+        // NONUNI: sample_times not equally spaced (the CLI's default log-spaced grid): branch-free bisection instead of the
+        // index guess, and the node spacing from a table
+        constexpr bool NONUNI = decltype(nonuni_tag)::value;
         constexpr bool TYPEB = decltype(typeb_tag)::value;
         // SYS: one sampled systematic per filter or shared (em_syserr): sigma_tot = sqrt(sigma_data^2 + e^2) per datum and sample,
         // with the extended task's expressions (the photometry record then carries sigma_data instead of 1 / sigma_tot)
@@ -1362,6 +1365,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
         const lds_c2p dat4 = (lds_c2p)(smem + L.dat);
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
+        const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
         const bool range_ok = jhi > jlo;
         constexpr int NSL = 2;
         int s_[NSL];
@@ -1387,9 +1391,23 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
             const double t_lo = st_lo * zp1 + tsh, t_hi = st_hi * zp1 + tsh;
             inside_[u] = range_ok & (t >= t_lo) & (t <= t_hi);
-            int lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
-            lo = lo > jhi - 1 ? jhi - 1 : lo;
-            lo = lo < jlo ? jlo : lo;
+            int lo;
+            if constexpr (NONUNI) {
+                // largest node index in [jlo, jhi - 1] whose observer-frame time is <= t (np.interp's bracket)
+                lo = jlo;
+                int hi = jhi;
+                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count: ceil(log2(NS))
+                    const int mid = (lo + hi) >> 1;
+                    const bool le = (stl_l[mid] * zp1 + tsh) <= t;
+                    lo = le ? mid : lo;
+                    hi = le ? hi : mid;
+                }
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+            } else {
+                lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+                lo = lo < jlo ? jlo : lo;
+            }
             dtx_[u] = t - (stl_l[lo] * zp1 + tsh);            // t - x0
             lo_[u] = lo;
             asm volatile("" : "+v"(dtx_[u]), "+v"(lo_[u]));   // (evaluated here, before the wait for the MLP)
@@ -1501,7 +1519,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int u = 0; u < NSL; ++u) {
             const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
-            const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * inv_dt;
+            const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
             double y0 = ynode_[0][u], y1 = ynode_[1][u];
             y0 = y0 + dmrc; y1 = y1 + dmrc;
             const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
@@ -1627,13 +1645,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const bool two = !(itab[k].identity != 0 && itab[k].same_grid != 0);       // uniform per item
                 const bool sysp = LEANX && itab[k].kind == NMMA_SYS_PARAM;
                 auto run = [&](auto tb) {
+                    using T = std::true_type; using F = std::false_type;
                     if constexpr (LEANX) {
+                        if (!uniform) {            // (an unequally spaced grid never coincides with the SVD grid: always two-stage)
+                            if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
+                            return;
+                        }
                         if (sysp) {
-                            if (two) lean_task(tb, std::true_type{}, std::true_type{}, k, t); else lean_task(tb, std::false_type{}, std::true_type{}, k, t);
+                            if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t);
                             return;
                         }
                     }
-                    if (two) lean_task(tb, std::true_type{}, std::false_type{}, k, t); else lean_task(tb, std::false_type{}, std::false_type{}, k, t);
+                    if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                 };
                 if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
             }
