@@ -1449,6 +1449,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
         double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
         const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
+        const double ebvc_item = LEANX ? it.ebvc : 0.0;
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
 #pragma unroll
@@ -1521,6 +1522,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
             const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
             double y0 = ynode_[0][u], y1 = ynode_[1][u];
+            if constexpr (LEANX) {       // linear extinction law: ext_mag = coeff * Ebv when Ebv != 0 (model.py:328-342)
+                const double ext = ebvc_item * sc[S_EBV];       // (coeff * 0 = 0 for Ebv = 0; coefficients are finite)
+                y0 = y0 + ext; y1 = y1 + ext;
+            }
             y0 = y0 + dmrc; y1 = y1 + dmrc;
             const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
             double isig = sl[0], lsig = sl[1];

@@ -300,6 +300,15 @@ def case_extinction_limit():
     return c
 
 
+def case_extinction_linear():
+    """Sampled E(B-V) with per-filter linear coefficients and no detection limit: handled by the lean task."""
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind", "Ebv"]
+    c = _base(seed=9735, batch=48, names=names)
+    c["ebv_coeff"] = {f: 2.9 - 0.4 * i for i, f in enumerate(c["model_filters"])}
+    c["theta"][:4, names.index("Ebv")] = 0.0
+    return c
+
+
 def case_extinction_p92():
     """Sampled E(B-V) under the reference's DEFAULT law: the Pei (1992) SMC curve read at every sample's
     host-frame wavelength (utils.py:373-428, model.py:323-342) -- the extinction magnitude of a filter
@@ -331,8 +340,9 @@ SHAPE_CASES = {
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,
     "extinction_limit": case_extinction_limit,
+    "extinction_linear": case_extinction_linear,
     "extinction_p92": case_extinction_p92,
     "log_grid": case_log_grid,
 }
-ORACLE_ONLY_CASES = ("extinction_limit", "extinction_p92")
+ORACLE_ONLY_CASES = ("extinction_limit", "extinction_linear", "extinction_p92")
 CASES.update({k: v for k, v in SHAPE_CASES.items() if k not in ORACLE_ONLY_CASES})

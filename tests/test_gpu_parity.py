@@ -110,7 +110,7 @@ def test_coefficients_and_lightcurves(name, torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["extinction_limit", "extinction_p92"])
+@pytest.mark.parametrize("name", ["extinction_limit", "extinction_linear", "extinction_p92"])
 def test_extinction_lightcurves_match_oracle(name, torch_cuda):
     """Detector-frame light curves with extinction (gen_detector_lc, model.py:352-404 with get_extinction_mags :323-342):
     the linear law and the native Pei-1992 SMC law, whose magnitude per filter depends on each sample's redshift;

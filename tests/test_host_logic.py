@@ -413,3 +413,42 @@ def test_hubble_constant_conversion_and_device_refusal():
     mft._engine = mft._names = None
     with pytest.raises(L.NMMAHipError, match="Hubble_constant"):
         mft.engine(["luminosity_distance", "Hubble_constant", "log10_mej"])
+
+
+def test_kernel_register_budget():
+    """Code-object metadata of the built library: the lean kernels (em_logl<.., 1> and <.., 3>) must not spill -- a change
+    that made hipcc spill 2 600 registers in one of them went unnoticed by the parity tests and cost 50 % of its speed --
+    and no kernel may use more than a few words of scratch."""
+    import re
+    import subprocess
+    from nmma_amd import _lib
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(readelf) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-readelf or the built library not available")
+    data = open(_lib.LIB_PATH, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+    assert len(starts) >= 2, "no embedded device code object found"
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
+        tmp.write(data[starts[1]:])
+        tmp.flush()
+        notes = subprocess.run([readelf, "--notes", tmp.name], capture_output=True, text=True).stdout
+    kernels = {}
+    name = None
+    for line in notes.splitlines():
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+        for key in ("private_segment_fixed_size", "vgpr_spill_count", "vgpr_count"):
+            m = re.search(r"\." + key + r":\s+(\d+)", line)
+            if m and name:
+                kernels[name][key] = int(m.group(1))
+    logl = {k: v for k, v in kernels.items() if "7em_loglI" in k}
+    assert len(logl) >= 12, sorted(kernels)
+    for k, v in logl.items():
+        fastm = int(re.search(r"Li8ELi(\d)EE", k).group(1)) if re.search(r"Li8ELi(\d)EE", k) else 0
+        if fastm in (1, 3):
+            assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+        assert v["private_segment_fixed_size"] <= 64, (k, v)
+        assert v["vgpr_count"] <= (128 if fastm else 160), (k, v)
