@@ -246,6 +246,30 @@ def test_shape_cases_match_oracle(name, tile, torch_cuda, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("combo", ["log_grid+em_syserr", "cli_grid+em_syserr", "log_grid+extinction", "log_grid+many_points"])
+def test_lean_task_combinations_match_oracle(combo, torch_cuda):
+    """The combinations real runs use (the CLI's grids with the sampled em_syserr of current priors, extinction, dense
+    photometry) go through ONE lean kernel: every pairing of its compile-time variants against the oracle."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    grid, extra = combo.split("+")
+    if extra == "em_syserr":
+        case = cases.case_syserr_param()
+    elif extra == "extinction":
+        case = cases.case_extinction_linear()
+    else:
+        case = cases._base(seed=5150, filters=["a", "b", "d"], counts=dict(a=40, b=75, d=9), batch=40, upper_limit_filter="b")
+    case["sample_times"] = np.geomspace(0.2, 20.0, 150) if grid == "log_grid" else np.arange(0.1, 20.5, 0.5)
+    eng = engine_from_case(case)
+    got = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+    eng.check()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and (~floor).sum() > 10
+    assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    eng.close()
+
+
 def test_lean_task_photometry_limits(torch_cuda):
     """The lean task keeps the photometry in LDS: up to ~2 400 points (BASELINE config 4's shape) it fits next to the ring,
     beyond that the handle falls back to the extended task -- same numbers either way (oracle spot check)."""
