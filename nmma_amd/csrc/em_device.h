@@ -62,6 +62,7 @@ struct EmDev {
     const double* pspan;      // [M][NP]   param_maxs - param_mins
     const double* pinv;       // [M][NP]   1 / pspan (em_logl normalises with one multiply)
     const double* ebv_coeff;  // [M]
+    const double* ext_tab;    // [B][M] extinction magnitudes of the current batch (p92_tab; written by ext_prepass_kernel)
     // stage-1 interpolation tables (sample_times <- tt), static per model filter
     const double* st;         // [NS] sample times
     const int32_t* s1_idx;    // [M][NS]  left node in tt (-1: outside the SVD grid -> +inf)
@@ -96,7 +97,7 @@ struct EmDev {
     int32_t n_data;           // total number of photometry points (all observed filters)
     int32_t tab_fast_bytes;   // 1-KiB-rounded prefix [rows | b2] staged per item by em_logl's fast mode
     int32_t tab_bytes, tab_row_stride, tab_off_s1dx, tab_off_s1of, tab_off_s1i, tab_off_b2;
-    int32_t lean_x, pad_lx;           // lean task extras needed (a filter with more than 32 points, a sampled em_syserr): em_logl<.., 3>
+    int32_t lean_x, p92_tab;          // p92_tab: the P92 extinction magnitudes come from ext_tab (pre-pass kernel) -- lean task           // lean task extras needed (a filter with more than 32 points, a sampled em_syserr): em_logl<.., 3>
     int32_t tab_off_s1inv, any_two;   // 1 / s1dx (lean two-stage task); some item's sample_times differ from the SVD grid
     const ItemDesc* item_desc;   // [n_items]
     const int32_t* iw_items;     // [n_items][8] compact copy for em_logl_iw: d0, nf, jlo, jhi, o, has_ul, m, record byte base

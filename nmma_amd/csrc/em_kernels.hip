@@ -611,7 +611,7 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
 constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
-    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, epar, total;
+    int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, epar, exttab, total;
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
@@ -622,7 +622,7 @@ struct LdsW {
 constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
 
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
-                                         int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat) {
+                                         int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -639,6 +639,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
     if (L.dat >= 0) off = align16(off + 4 * n_data * 8);
     L.epar = off;  off = align16(off + (all_fast ? n_sys_slots * TS * 8 : 0));        // fast modes: sysv[slot][sample]
+    L.exttab = off; off = align16(off + ext_rows * TS * 8);          // lean task with extinction: ext_mag[item][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
     L.cdl = off;  off = align16(off + 16 * 2 * 4 * 16 * 8);          // per wave (any role): 2 x 4 slots x 16 coefficients
@@ -655,14 +656,14 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // takes as many slots (at most 4) as fit the 160 KiB of LDS, giving up the photometry staging before the last
 // slots; the generic path keeps 3 partial-sum buffers next to its double-buffered tables.
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data, int n_sys_slots) {
+                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     const int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     LdsW L{};
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
             // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
-    constexpr bool LEANX = FASTM == 3;
+    constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     const EmDev& P = *Pp;
@@ -752,6 +753,19 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const bool helper = wave < NMW;              // an MFMA-role wave that finished its stream
     const int vt = tid - 64 * NMW;               // negative for helpers (they skip the prologue)
     const int vwave = wave - NMW;
+    // Lean task with extinction: ext_mag[item][sample] of this tile in LDS, filled by the prologue lane that owns the sample's
+    // E(B-V) -- coefficient x E(B-V) for the linear law, the pre-pass kernel's value for the Pei-1992 law -- so that a task reads
+    // ONE LDS word per slot (anything more inside the task tips hipcc into spilling: see the register-budget test)
+    auto fill_ext = [&](const int s_l, const double ebv) {
+        double* et = reinterpret_cast<double*>(smem + L.exttab);
+        if (!P.has_ebv) { et[s_l] = 0.0; return; }        // one row of zeros that every item reads
+        long bb = tile0 + s_l;
+        if (bb >= B) bb = B - 1;
+        for (int kk = 0; kk < W; ++kk) {
+            const int m_k = P.item_desc[kk].m;
+            et[kk * TS + s_l] = P.p92_tab ? P.ext_tab[bb * P.M + m_k] : ((ebv != 0.0) ? P.item_desc[kk].ebvc * ebv : 0.0);
+        }
+    };
     if (!helper) {
         if (dbg && blockIdx.x == 0 && vt == 0) dbg[64] = clock64();
         // ---- prologue: per-sample scalars, accumulators, sample-time grid.
@@ -802,6 +816,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     sc[S_TS] = apply_slot(P.timeshift, row);
                     sc[S_EBV] = P.has_ebv ? apply_slot(P.ebv, row) : 0.0;
                     chk = sc[S_TS] + sc[S_EBV];
+                    if constexpr (LEANX) fill_ext(lane, sc[S_EBV]);
                 } else if (vwave == 2) {
                     for (int p = 0; p < P.NP; ++p) chk += apply_slot(P.model_param[p], row);
                 } else {
@@ -826,6 +841,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 chk += v;
                 if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
             }
+            if constexpr (LEANX) fill_ext(vt, scal[vt * 8 + S_EBV]);
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
@@ -1449,7 +1465,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
         double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
         const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
-        const double ebvc_item = LEANX ? it.ebvc : 0.0;
+        const lds_cdp ext_l = (lds_cdp)(smem + L.exttab) + (P.has_ebv ? k : 0) * TS;
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
 #pragma unroll
@@ -1522,8 +1538,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
             const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
             double y0 = ynode_[0][u], y1 = ynode_[1][u];
-            if constexpr (LEANX) {       // linear extinction law: ext_mag = coeff * Ebv when Ebv != 0 (model.py:328-342)
-                const double ext = ebvc_item * sc[S_EBV];       // (coeff * 0 = 0 for Ebv = 0; coefficients are finite)
+            if constexpr (LEANX) {       // extinction magnitude of this sample and item (filled by the prologue, model.py:323-342)
+                const double ext = ext_l[s_[u]];       // (no branch here: 0 when there is no extinction)
                 y0 = y0 + ext; y1 = y1 + ext;
             }
             y0 = y0 + dmrc; y1 = y1 + dmrc;
@@ -1651,17 +1667,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const bool sysp = LEANX && itab[k].kind == NMMA_SYS_PARAM;
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
-                    if constexpr (LEANX) {
-                        if (!uniform) {            // (an unequally spaced grid never coincides with the SVD grid: always two-stage)
-                            if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
-                            return;
-                        }
-                        if (sysp) {
-                            if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t);
-                            return;
-                        }
+                    if constexpr (FASTM == 4) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
+                        if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
+                    } else if constexpr (FASTM == 3) {
+                        if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
+                        else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
+                    } else {
+                        if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     }
-                    if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                 };
                 if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
             }
@@ -2195,6 +2208,23 @@ __global__ void lc_to_detector(const EmDev* __restrict__ Pp, const double* __res
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pre-pass of the lean task for the Pei-1992 extinction law: ext_mag[b][m] for the whole batch, one thread per parameter
+// vector (the law costs ~800 instructions per sample and filter -- six terms with three divisions each, 10^x, log10 -- which
+// inside the likelihood kernel would be paid per datum slot).  Same sample_scalars as the kernel's prologue => same z.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ext_prepass_kernel(const EmDev* __restrict__ Pp, const double* __restrict__ theta,
+                                                          const long B, const long ld, double* __restrict__ ext_tab) {
+    const EmDev& P = *Pp;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (parameter vector, model filter)
+    const long b = idx / P.M;
+    const int m = (int)(idx - b * P.M);
+    if (b >= B) return;
+    double praw[NMMA_MAX_PARAMS], scal[8], chk;
+    sample_scalars(P, theta + b * ld, praw, scal, chk);
+    ext_tab[idx] = P.has_ebv ? extinction_mag(P.ext_law, P.ebv_coeff[m], scal[S_ZP1], scal[S_EBV]) : 0.0;
 }
 
 }  // namespace nmma
