@@ -1620,6 +1620,297 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
     };
 
+    // ---------------------------------------------------------------------------------
+    // lean_avg_task (FASTM = 5): the lean task for configurations with averaged bands -- an observed filter whose magnitude
+    // is the mean of several model filters (utils.py:566-584).  k is the LAST source item of the band (items k - nsrc + 1 .. k,
+    // one surrogate each; nsrc = 1 for an ordinary band); stage Q walks the sources -- wait for the source's coefficients,
+    // node magnitudes with its basis rows, + extinction of its filter + distance modulus -- sums them in source order and
+    // divides the interpolated sum by nsrc (the generic item phase's order).  The other source items own no tasks; every
+    // task of the band signals each of them, which releases their ring slots.  A copy of lean_task rather than a variant
+    // of it: any change to that lambda, even a semantically neutral one, moves hipcc's register allocation off its optimum.
+    // ---------------------------------------------------------------------------------
+    auto lean_avg_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, const int k, const int c) {
+        // NONUNI: sample_times not equally spaced (the CLI's default log-spaced grid): branch-free bisection instead of the
+        // index guess, and the node spacing from a table
+        constexpr bool NONUNI = false;
+        constexpr bool TYPEB = decltype(typeb_tag)::value;
+        // SYS: one sampled systematic per filter or shared (em_syserr): sigma_tot = sqrt(sigma_data^2 + e^2) per datum and sample,
+        // with the extended task's expressions (the photometry record then carries sigma_data instead of 1 / sigma_tot)
+        constexpr bool SYS = decltype(sys_tag)::value;
+        // TWO: sample_times differ from the SVD grid -- each of a datum's two sample nodes is a stage-1 lerp between two
+        // SVD rows (lightcurve_generation.py:177), evaluated in two passes of the same four FMA chains
+        constexpr bool TWO = decltype(two_tag)::value;
+        const ItemDesc& it = itab[k];
+        const int o = it.o;
+        const int nsrc = __builtin_amdgcn_readfirstlane(it.nsrc);
+        const int k0 = k - (nsrc - 1);
+        if (c == 0) {      // this wave stages the basis rows of every source (the host guarantees NBUF >= nsrc)
+            typedef __attribute__((address_space(3))) unsigned char* lds_bp;
+            typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+            for (int kk = k0; kk <= k; ++kk) {
+                if (kk >= NBUF) sync_wait(sync + W + 1 + (kk - NBUF + 1), itab[kk - NBUF].ntask[R - 1], P.watchdog, 800 + kk);
+                gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)itab[kk].m * P.tab_bytes);
+                lds_bp dst = (lds_bp)(tabl + (kk % NBUF) * P.tab_fast_bytes);
+                for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
+                    __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
+            }
+        }
+        typedef const __attribute__((address_space(3))) double* lds_cdp;
+        typedef const __attribute__((address_space(3))) float* lds_cfp;
+        typedef __attribute__((address_space(3))) double* lds_dp;
+        // (uniform descriptor words as scalars: comparisons on them are SALU work)
+        const int jlo = __builtin_amdgcn_readfirstlane(it.jlo), jhi = __builtin_amdgcn_readfirstlane(it.jhi);
+        const int d0 = __builtin_amdgcn_readfirstlane(it.d0), nf = __builtin_amdgcn_readfirstlane(it.nf);
+        const int g = lane >> 4, gi = lane & 15;
+        const double st0 = P.st0, inv_dt = P.st_inv_dt;
+        const lds_cdp stl_l = (lds_cdp)stl;
+        typedef __attribute__((ext_vector_type(2))) double f64x2;
+        typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
+        const lds_c2p dat4 = (lds_c2p)(smem + L.dat);
+        const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
+        const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
+        const bool range_ok = jhi > jlo;
+        constexpr int NSL = 2;
+        int s_[NSL];
+        s_[0] = TYPEB ? 8 * c + g : 4 * c + g;
+        s_[1] = TYPEB ? s_[0] + 4 : s_[0];
+        // ---- stage P (needs only the prologue)
+        // (only what depends on the bracket stays in registers across the wait for the MLP: the photometry record and
+        //  the sample scalars are read again from LDS in stage Q -- LDS reads cost the MFMA stream nothing, registers
+        //  are what limits the workgroup to 16 waves)
+        double dtx_[NSL];
+        bool inside_[NSL], valid_[NSL];
+        int lo_[NSL];
+        lds_c2p D_[NSL];
+        // (filters with 17 .. 32 points take one pass over the lane's two slots; more points further passes of 32: `pp`)
+        auto stage_p = [&](const int pp) {
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int dd = TYPEB ? gi : gi + 16 * u + 32 * pp;
+            valid_[u] = dd < nf;
+            D_[u] = dat4 + 2 * (d0 + (valid_[u] ? dd : 0));
+            const double t = D_[u][0][0];
+            const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
+            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
+            const double t_lo = st_lo * zp1 + tsh, t_hi = st_hi * zp1 + tsh;
+            inside_[u] = range_ok & (t >= t_lo) & (t <= t_hi);
+            int lo;
+            if constexpr (NONUNI) {
+                // largest node index in [jlo, jhi - 1] whose observer-frame time is <= t (np.interp's bracket)
+                lo = jlo;
+                int hi = jhi;
+                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count: ceil(log2(NS))
+                    const int mid = (lo + hi) >> 1;
+                    const bool le = (stl_l[mid] * zp1 + tsh) <= t;
+                    lo = le ? mid : lo;
+                    hi = le ? hi : mid;
+                }
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+            } else {
+                lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+                lo = lo < jlo ? jlo : lo;
+            }
+            dtx_[u] = t - (stl_l[lo] * zp1 + tsh);            // t - x0
+            lo_[u] = lo;
+            asm volatile("" : "+v"(dtx_[u]), "+v"(lo_[u]));   // (evaluated here, before the wait for the MLP)
+        }
+        };
+        stage_p(0);
+        // ---- stage Q (needs the coefficients of item k)
+        if (c == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int kk = k0; kk <= k; ++kk) sync_signal(sync + 2 * W + 4 + kk, lane);     // rows of the band's sources staged
+        }
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        constexpr int NCC = TYPEB ? 2 : 1;
+        // the two basis rows of every slot, read as 16-byte pairs [VA[2j], VA[2j+1]] (pair 5 = [span, mins]); the four FMA
+        // chains (2 slots x 2 rows) advance together, one pair per step, so that no instruction waits for its predecessor.
+        // TWO: pass 0 reconstructs the SVD rows around sample node lo, pass 1 those around node lo + 1.
+        typedef const __attribute__((address_space(3))) int* lds_cip;
+        double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
+        const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
+        auto stage_q = [&]() {
+        double ys_[2][NSL] = {{0.0, 0.0}, {0.0, 0.0}};     // sums over the sources of the node magnitudes
+        for (int kk = k0; kk <= k; ++kk) {               // uniform trip count
+        sync_wait(sync + 2 * W + 4 + kk, 1, P.watchdog, 350 + kk);
+        sync_wait(sync + kk, NMW, P.watchdog, 300 + kk);   // coefficients of source item kk published
+        const unsigned char* tbl = tabl + (kk % NBUF) * P.tab_fast_bytes;
+        const lds_cfp b2l = (lds_cfp)(tbl + P.tab_off_b2);
+        const float b2v = b2l[gi];
+        lds_c2p cc_[NCC];          // the sample's 10 coefficients (fp64) in this wave's LDS slots: [wave][q][g][16]
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) {
+            // slice reduction (fixed order) + bias of the second Dense: lane gi owns coefficient gi of its sample
+            const int s = s_[q];
+            const lds_cfp pp = (lds_cfp)(part + (kk % NBUF) * (NSLICE * TS * PSTR)) + ((s >> 4) * 16 + (s & 15)) * PSTR + gi;
+            float cmine = pp[0];
+#pragma unroll
+            for (int w = 1; w < NSLICE; ++w) cmine += pp[w * (R * 16 * PSTR)];
+            cmine += b2v;
+            const lds_dp cslot = (lds_dp)(cdl + ((wave * 2 + q) * 4 + g) * 16);
+            cslot[gi] = (double)cmine;
+            cc_[q] = (lds_c2p)cslot;
+        }
+        const lds_c2p rows2 = (lds_c2p)(tbl);
+        const lds_cdp s1of_l = (lds_cdp)(tbl + P.tab_off_s1of), s1inv_l = (lds_cdp)(tbl + P.tab_off_s1inv);
+        const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
+        const lds_cdp ext_l = (lds_cdp)(smem + L.exttab) + (P.has_ebv ? kk : 0) * TS;
+        double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
+#pragma unroll
+        for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
+            lds_c2p ra_[NSL], rb_[NSL];
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                if constexpr (TWO) {
+                    const int j = lo_[u] + pass;
+                    int i1 = s1i_l[j];
+                    i1 = i1 < 0 ? 0 : i1;                         // (nodes outside the SVD grid lie outside [jlo, jhi]: never bracketed)
+                    const int i2 = i1 + 1 < NT ? i1 + 1 : NT - 1;
+                    ra_[u] = rows2 + i1 * 6; rb_[u] = rows2 + i2 * 6;
+                } else {
+                    ra_[u] = rows2 + lo_[u] * 6; rb_[u] = ra_[u] + 6;
+                }
+            }
+            double a0_[NSL], a1_[NSL];
+            f64x2 p0_[NSL], p1_[NSL];
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) { p0_[u] = ra_[u][0]; p1_[u] = rb_[u][0]; }
+            f64x2 cq_[NCC];
+#pragma unroll
+            for (int q = 0; q < NCC; ++q) cq_[q] = cc_[q][0];
+#pragma unroll
+            for (int jp = 0; jp < 5; ++jp) {
+                f64x2 n0_[NSL], n1_[NSL], nq_[NCC];
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) { n0_[u] = ra_[u][jp + 1]; n1_[u] = rb_[u][jp + 1]; }
+                if (jp < 4) {
+#pragma unroll
+                    for (int q = 0; q < NCC; ++q) nq_[q] = cc_[q][jp + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) {
+                    const f64x2 cq = cq_[TYPEB ? u : 0];
+                    if (jp == 0) { a0_[u] = p0_[u][0] * cq[0]; a1_[u] = p1_[u][0] * cq[0]; }
+                    else { a0_[u] = fma(p0_[u][0], cq[0], a0_[u]); a1_[u] = fma(p1_[u][0], cq[0], a1_[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) {
+                    const f64x2 cq = cq_[TYPEB ? u : 0];
+                    a0_[u] = fma(p0_[u][1], cq[1], a0_[u]); a1_[u] = fma(p1_[u][1], cq[1], a1_[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NSL; ++u) { p0_[u] = n0_[u]; p1_[u] = n1_[u]; }
+                if (jp < 4) {
+#pragma unroll
+                    for (int q = 0; q < NCC; ++q) cq_[q] = nq_[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const double ya = a0_[u] * p0_[u][0] + p0_[u][1], yb = a1_[u] * p1_[u][0] + p1_[u][1];   // (VA[i,:].c) span[i] + mins[i]
+                if constexpr (TWO) {
+                    const int j = lo_[u] + pass;
+                    // stage 1: ((yb - ya) / dx) * off + ya with the reciprocal of dx from the table
+                    ynode_[pass][u] = ((yb - ya) * s1inv_l[j]) * s1of_l[j] + ya;
+                } else {
+                    ynode_[0][u] = ya; ynode_[1][u] = yb;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {    // + extinction of this source's filter (0 without) + distance modulus (model.py:323-342)
+            const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
+            const double dmrc = sc[S_DMOD] + sc[S_RC], ext = ext_l[s_[u]];
+            ys_[0][u] += (ynode_[0][u] + ext) + dmrc; ys_[1][u] += (ynode_[1][u] + ext) + dmrc;
+        }
+        }
+        double est_[NSL], m_[NSL];
+        bool ul_[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
+            const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
+            const double izdt = sc[S_IZP1] * inv_dt;
+            const double y0 = ys_[0][u], y1 = ys_[1][u];
+            const double est = (((y1 - y0) * izdt) * dtx_[u] + y0) / (double)nsrc;     // (a + b [+ c]) / n  (utils.py:566-584)
+            double isig = sl[0], lsig = sl[1];
+            bool sig_bad = false;
+            if constexpr (SYS) {
+                const double sd = sl[0];                      // sigma_data
+                const double e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
+                esys_[u] = e_sys;
+                const double sig = sqrt(sd * sd + e_sys * e_sys);
+                const bool fin = (sig - sig == 0.0);
+                isig = fin ? 1.0 / sig : 0.0;                 // infinite data error: upper limit
+                lsig = log(sig);
+                sig_bad = (fin & !(sig > 0)) | (sig != sig);
+            }
+            const double x = (tm[1] - est) * isig;
+            double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
+            opaque(v);                                        // (computed on every lane: no exec-masked region around the chain)
+            // outside the model window est = +inf: truncnorm.logpdf(loc = inf) = NaN (em_likelihood.py:252-256)
+            v = (inside_[u] & !sig_bad) ? v : dnan();
+            ul_[u] = valid_[u] & (isig == 0.0) & !sig_bad;    // infinite data error: an upper limit
+            v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
+            est_[u] = est; m_[u] = tm[1];
+        }
+        gp_[0] = 0.0; gp_[1] = 0.0;
+        if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
+#pragma unroll
+            for (int u = 0; u < NSL; ++u)
+                if (ul_[u]) gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const);
+        }
+        };
+        stage_q();
+        lds_dp chi_l = (lds_dp)chi_tot;
+        lds_dp gp_l = (lds_dp)gp_tot;
+        if constexpr (TYPEB) {
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const double chi = group_sum(v_[u], 16);
+                double gp = 0.0;
+                if (it.has_ul) gp = group_sum(gp_[u], 16);
+                if (gi == 0) {
+                    const int s = s_[u];
+                    chi_l[k * TS + s] = chi;
+                    gp_l[k * TS + s] = gp;
+                    if (chi != chi) bad[s] = 1;
+                    if (chi_parts != nullptr && tile0 + s < B) {
+                        chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
+                        gp_parts[(long)o * B + tile0 + s] = gp;
+                    }
+                }
+            }
+        } else {
+            double vacc = v_[0] + v_[1], gacc = gp_[0] + gp_[1];
+            if constexpr (LEANX) {
+                for (int pp = 1; pp * 32 < nf; ++pp) {      // uniform: only filters with more than 32 points
+                    stage_p(pp);
+                    stage_q();
+                    vacc += v_[0] + v_[1]; gacc += gp_[0] + gp_[1];
+                }
+            }
+            const double chi = group_sum(vacc, 16);
+            double gp = 0.0;
+            if (it.has_ul) gp = group_sum(gacc, 16);
+            if (gi == 0) {
+                const int s = s_[0];
+                chi_l[k * TS + s] = chi;
+                gp_l[k * TS + s] = gp;
+                if (chi != chi) bad[s] = 1;
+                if (chi_parts != nullptr && tile0 + s < B) {
+                    chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
+                    gp_parts[(long)o * B + tile0 + s] = gp;
+                }
+            }
+        }
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
+        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
+        for (int kk = k0; kk <= k; ++kk) sync_signal(sync + W + 2 + kk, lane);     // one signal per task and source item
+    };
+
     if constexpr (FAST) {
         sync_wait(sync + W + 1, NVW, P.watchdog, 400);   // prologue data of every likelihood wave in LDS
         // Tasks (item-major) are claimed from one LDS counter: likelihood waves from the start, MFMA-role
@@ -1669,6 +1960,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     using T = std::true_type; using F = std::false_type;
                     if constexpr (FASTM == 4) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
                         if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
+                    } else if constexpr (FASTM == 5) {
+                        if (sysp) { if (two) lean_avg_task(tb, T{}, T{}, k, t); else lean_avg_task(tb, F{}, T{}, k, t); }
+                        else { if (two) lean_avg_task(tb, T{}, F{}, k, t); else lean_avg_task(tb, F{}, F{}, k, t); }
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }

@@ -114,17 +114,18 @@ def case_syserr_time_nodes():
     return c
 
 
-def case_averaging():
+def case_averaging(names=None, counts=12, n_new=9):
     """Observed filters the model does not provide (``w``, ``o``, ``I``): arithmetic mean
-    of mapped model bands (em_likelihood.py:326-333), plus renamed ``B -> g``."""
+    of mapped model bands (em_likelihood.py:326-333), plus renamed ``B -> g``.
+    (The keyword arguments make variants for the lean-task tests; the defaults are the golden case.)"""
     model_filters = ["g", "r", "i", "z", "y"]
-    c = _base(seed=5234, filters=model_filters, counts=12, batch=32, upper_limit_filter="i")
+    c = _base(seed=5234, filters=model_filters, counts=counts, batch=32, upper_limit_filter="i", names=names)
     times, mags, sigmas = c["data"]
     rng = np.random.default_rng(99)
     for new, src in (("w", ["g", "r", "i"]), ("o", ["r", "i"]), ("I", ["z", "y"]), ("B", ["g"])):
-        t = np.sort(rng.uniform(0.6, 13.0, 9))
+        t = np.sort(rng.uniform(0.6, 13.0, n_new))
         m = np.mean([np.interp(t, times[s], mags[s]) for s in src], axis=0)
-        times[new], mags[new], sigmas[new] = t, m + 0.05 * rng.standard_normal(9), rng.uniform(0.02, 0.1, 9)
+        times[new], mags[new], sigmas[new] = t, m + 0.05 * rng.standard_normal(n_new), rng.uniform(0.02, 0.1, n_new)
     observed = ["g", "r", "i", "z", "y", "w", "o", "I", "B"]
     for k in list(times):
         if k not in observed:

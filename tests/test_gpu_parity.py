@@ -270,6 +270,68 @@ def test_lean_task_combinations_match_oracle(combo, torch_cuda):
     eng.close()
 
 
+AVG_NAMES = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"]
+
+
+def _averaging_variant(variant):
+    if variant == "em_syserr":
+        case = cases.case_averaging(names=AVG_NAMES + ["em_syserr"])
+        case["systematics"] = dict(mode="param", name="em_syserr")
+    elif variant in ("extinction", "p92"):
+        case = cases.case_averaging(names=AVG_NAMES + ["Ebv"])
+        if variant == "extinction":
+            case["ebv_coeff"] = {f: 3.1 - 0.5 * i for i, f in enumerate(case["model_filters"])}
+        else:
+            case["filter_nu0"] = dict(zip(case["model_filters"], [2.99792458e14 / x for x in (0.48, 0.62, 0.75, 0.87, 0.96)]))
+        case["theta"][:3, -1] = 0.0
+    elif variant == "many_points":
+        case = cases.case_averaging(counts=40, n_new=45)
+    else:
+        case = cases.case_averaging()
+    if variant == "cli_grid":
+        case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    if variant == "log_grid":
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150)
+    return case
+
+
+@pytest.mark.parametrize("variant", ["plain", "cli_grid", "em_syserr", "extinction", "p92", "many_points", "log_grid"])
+def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
+    """Averaged bands (ATLAS c / o, PS1 w, Johnson V / I: the mean of two or three model filters, utils.py:566-584) on the lean
+    task (em_logl<.., 5>: 16-wave workgroups) with each of its extras, against the oracle and against the generic item
+    phase (12-wave workgroups) that had them before; an unequally spaced grid keeps the generic phase."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    case = _averaging_variant(variant)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    assert eng.last_launch_geometry()["block"] == (768 if variant == "log_grid" else 1024)
+    got32 = None
+    eng.close()
+    monkeypatch.setenv("NMMA_EM_TILE", "2")
+    eng = engine_from_case(case)
+    got32 = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    # (forced 32-sample tiles: the ring is then too shallow for three sources and the handle keeps the generic phase)
+    fin = got != FLOOR
+    assert np.array_equal(got32 != FLOOR, fin) and rel_err(got[fin], got32[fin]).max() <= 1e-9
+    monkeypatch.delenv("NMMA_EM_TILE")
+    monkeypatch.setenv("NMMA_EM_NO_LEAN_AVG", "1")
+    eng = engine_from_case(case)
+    gen = eng.loglike(th).cpu().numpy()
+    eng.check()
+    assert eng.last_launch_geometry()["block"] == 768
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and np.array_equal(gen == FLOOR, floor) and (~floor).sum() > 10
+    assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    assert rel_err(got[~floor], gen[~floor]).max() <= 1e-9
+
+
 def test_lean_task_photometry_limits(torch_cuda):
     """The lean task keeps the photometry in LDS: up to ~2 400 points (BASELINE config 4's shape) it fits next to the ring,
     beyond that the handle falls back to the extended task -- same numbers either way (oracle spot check)."""

@@ -416,7 +416,7 @@ def test_hubble_constant_conversion_and_device_refusal():
 
 
 def test_kernel_register_budget():
-    """Code-object metadata of the built library: the lean kernels (em_logl<.., 1> and <.., 3>) must not spill -- a change
+    """Code-object metadata of the built library: the lean kernels (em_logl<.., 1>, <.., 3>, <.., 4>, <.., 5>) must not spill -- a change
     that made hipcc spill 2 600 registers in one of them went unnoticed by the parity tests and cost 50 % of its speed --
     and no kernel may use more than a few words of scratch."""
     import re
@@ -445,10 +445,10 @@ def test_kernel_register_budget():
             if m and name:
                 kernels[name][key] = int(m.group(1))
     logl = {k: v for k, v in kernels.items() if "7em_loglI" in k}
-    assert len(logl) >= 12, sorted(kernels)
+    assert len(logl) >= 24, sorted(kernels)
     for k, v in logl.items():
         fastm = int(re.search(r"Li8ELi(\d)EE", k).group(1)) if re.search(r"Li8ELi(\d)EE", k) else 0
-        if fastm in (1, 3):
+        if fastm in (1, 3, 4, 5):
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
         assert v["private_segment_fixed_size"] <= 64, (k, v)
         assert v["vgpr_count"] <= (128 if fastm else 160), (k, v)
