@@ -1629,13 +1629,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // task of the band signals each of them, which releases their ring slots.  A copy of lean_task rather than a variant
     // of it: any change to that lambda, even a semantically neutral one, moves hipcc's register allocation off its optimum.
     // ---------------------------------------------------------------------------------
-    auto lean_avg_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, const int k, const int c) {
+    auto lean_avg_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, auto nonuni_tag, const int k, const int c) {
         // NONUNI: sample_times not equally spaced (the CLI's default log-spaced grid): branch-free bisection instead of the
         // index guess, and the node spacing from a table
-        constexpr bool NONUNI = false;
+        constexpr bool NONUNI = decltype(nonuni_tag)::value;
         constexpr bool TYPEB = decltype(typeb_tag)::value;
-        // SYS: one sampled systematic per filter or shared (em_syserr): sigma_tot = sqrt(sigma_data^2 + e^2) per datum and sample,
-        // with the extended task's expressions (the photometry record then carries sigma_data instead of 1 / sigma_tot)
+        // SYS: sampled systematics -- one parameter per filter or shared (em_syserr), or parameters at time nodes, constant
+        // outside and linear in between (systematics.py:288-291): sigma_tot = sqrt(sigma_data^2 + e^2) per datum and sample.
+        // The photometry record then carries [t | m | sigma_data | q], q = node index + fraction of the datum's node interval
+        // (0 for a single parameter; written by nmma_em_create), and e = v[i] + (v[i + 1] - v[i]) * fraction
         constexpr bool SYS = decltype(sys_tag)::value;
         // TWO: sample_times differ from the SVD grid -- each of a datum's two sample nodes is a stage-1 lerp between two
         // SVD rows (lightcurve_generation.py:177), evaluated in two passes of the same four FMA chains
@@ -1729,7 +1731,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // TWO: pass 0 reconstructs the SVD rows around sample node lo, pass 1 those around node lo + 1.
         typedef const __attribute__((address_space(3))) int* lds_cip;
         double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
-        const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
+        const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter(s)
+        const int svl = SYS ? __builtin_amdgcn_readfirstlane(P.sys_nn[o]) - 1 : 0;   // last node
         auto stage_q = [&]() {
         double ys_[2][NSL] = {{0.0, 0.0}, {0.0, 0.0}};     // sums over the sources of the node magnitudes
         for (int kk = k0; kk <= k; ++kk) {               // uniform trip count
@@ -1832,14 +1835,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int u = 0; u < NSL; ++u) {
             const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
-            const double izdt = sc[S_IZP1] * inv_dt;
+            const double izdt = sc[S_IZP1] * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
             const double y0 = ys_[0][u], y1 = ys_[1][u];
             const double est = (((y1 - y0) * izdt) * dtx_[u] + y0) / (double)nsrc;     // (a + b [+ c]) / n  (utils.py:566-584)
             double isig = sl[0], lsig = sl[1];
             bool sig_bad = false;
             if constexpr (SYS) {
                 const double sd = sl[0];                      // sigma_data
-                const double e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
+                const double qf = floor(sl[1]), fr = sl[1] - qf;
+                const int i0 = (int)qf, i1 = i0 < svl ? i0 + 1 : svl;
+                const lds_cdp ep = (lds_cdp)(smem + L.epar) + sv0 * TS + s_[u];
+                const double e0 = ep[i0 * TS], e1 = ep[i1 * TS];
+                const double e_sys = (e1 - e0) * fr + e0;     // (a single parameter: i0 = i1 = 0, fr = 0 -- exactly e0)
                 esys_[u] = e_sys;
                 const double sig = sqrt(sd * sd + e_sys * e_sys);
                 const bool fin = (sig - sig == 0.0);
@@ -1955,14 +1962,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
                 const bool two = !(itab[k].identity != 0 && itab[k].same_grid != 0);       // uniform per item
-                const bool sysp = LEANX && itab[k].kind == NMMA_SYS_PARAM;
+                const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || (FASTM == 5 && itab[k].kind == NMMA_SYS_NODES));
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
                     if constexpr (FASTM == 4) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
                         if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
                     } else if constexpr (FASTM == 5) {
-                        if (sysp) { if (two) lean_avg_task(tb, T{}, T{}, k, t); else lean_avg_task(tb, F{}, T{}, k, t); }
-                        else { if (two) lean_avg_task(tb, T{}, F{}, k, t); else lean_avg_task(tb, F{}, F{}, k, t); }
+                        if (!P.st_uniform) { if (sysp) lean_avg_task(tb, T{}, T{}, T{}, k, t); else lean_avg_task(tb, T{}, F{}, T{}, k, t); }
+                        else if (sysp) { if (two) lean_avg_task(tb, T{}, T{}, F{}, k, t); else lean_avg_task(tb, F{}, T{}, F{}, k, t); }
+                        else { if (two) lean_avg_task(tb, T{}, F{}, F{}, k, t); else lean_avg_task(tb, F{}, F{}, F{}, k, t); }
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }

@@ -246,8 +246,9 @@ def test_shape_cases_match_oracle(name, tile, torch_cuda, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("combo", ["log_grid+em_syserr", "cli_grid+em_syserr", "log_grid+extinction", "log_grid+many_points"])
-def test_lean_task_combinations_match_oracle(combo, torch_cuda):
+@pytest.mark.parametrize("combo", ["log_grid+em_syserr", "cli_grid+em_syserr", "log_grid+extinction", "log_grid+many_points",
+                                   "svd_grid+time_nodes", "cli_grid+time_nodes", "log_grid+time_nodes"])
+def test_lean_task_combinations_match_oracle(combo, torch_cuda, monkeypatch):
     """The combinations real runs use (the CLI's grids with the sampled em_syserr of current priors, extinction, dense
     photometry) go through ONE lean kernel: every pairing of its compile-time variants against the oracle."""
     torch = torch_cuda
@@ -257,12 +258,23 @@ def test_lean_task_combinations_match_oracle(combo, torch_cuda):
         case = cases.case_syserr_param()
     elif extra == "extinction":
         case = cases.case_extinction_linear()
+    elif extra == "time_nodes":
+        case = cases.case_syserr_time_nodes()
     else:
         case = cases._base(seed=5150, filters=["a", "b", "d"], counts=dict(a=40, b=75, d=9), batch=40, upper_limit_filter="b")
-    case["sample_times"] = np.geomspace(0.2, 20.0, 150) if grid == "log_grid" else np.arange(0.1, 20.5, 0.5)
+    if grid != "svd_grid":
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150) if grid == "log_grid" else np.arange(0.1, 20.5, 0.5)
     eng = engine_from_case(case)
     got = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
     eng.check()
+    if extra == "time_nodes":          # the extended task, which had the time nodes before, gives the same numbers
+        eng.close()
+        monkeypatch.setenv("NMMA_EM_NO_LEAN_NODES", "1")
+        eng = engine_from_case(case)
+        ext = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+        eng.check()
+        fin = got != FLOOR
+        assert np.array_equal(ext != FLOOR, fin) and rel_err(got[fin], ext[fin]).max() <= 1e-9
     want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
     floor = want == FLOOR
     assert np.array_equal(got == FLOOR, floor) and (~floor).sum() > 10
@@ -286,6 +298,13 @@ def _averaging_variant(variant):
         case["theta"][:3, -1] = 0.0
     elif variant == "many_points":
         case = cases.case_averaging(counts=40, n_new=45)
+    elif variant == "time_nodes":
+        n_a, n_b = [f"em_syserr_avg_{i}" for i in range(3)], [f"em_syserr_red_{i}" for i in range(5)]
+        case = cases.case_averaging(names=AVG_NAMES + ["em_syserr_rest"] + n_a + n_b)
+        obs = case["observed_filters"]
+        nodes = {f: (n_a, np.linspace(1.0, 12.0, 3)) for f in ("w", "o", "g")}
+        nodes.update({f: (n_b, np.linspace(0.0, 20.0, 5)) for f in ("I", "z")})
+        case["systematics"] = dict(mode="mixed", names={f: "em_syserr_rest" for f in obs if f not in nodes}, nodes=nodes)
     else:
         case = cases.case_averaging()
     if variant == "cli_grid":
@@ -295,11 +314,11 @@ def _averaging_variant(variant):
     return case
 
 
-@pytest.mark.parametrize("variant", ["plain", "cli_grid", "em_syserr", "extinction", "p92", "many_points", "log_grid"])
+@pytest.mark.parametrize("variant", ["plain", "cli_grid", "em_syserr", "time_nodes", "extinction", "p92", "many_points", "log_grid"])
 def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     """Averaged bands (ATLAS c / o, PS1 w, Johnson V / I: the mean of two or three model filters, utils.py:566-584) on the lean
     task (em_logl<.., 5>: 16-wave workgroups) with each of its extras, against the oracle and against the generic item
-    phase (12-wave workgroups) that had them before; an unequally spaced grid keeps the generic phase."""
+    phase (12-wave workgroups) that had them before."""
     torch = torch_cuda
     from oracle import nmma_oracle as orc
     case = _averaging_variant(variant)
@@ -307,8 +326,7 @@ def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     eng = engine_from_case(case)
     got = eng.loglike(th).cpu().numpy()
     eng.check()
-    assert eng.last_launch_geometry()["block"] == (768 if variant == "log_grid" else 1024)
-    got32 = None
+    assert eng.last_launch_geometry()["block"] == 1024
     eng.close()
     monkeypatch.setenv("NMMA_EM_TILE", "2")
     eng = engine_from_case(case)

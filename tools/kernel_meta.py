@@ -35,7 +35,8 @@ def kernel_table(lib):
 
     def flush():
         if cur in out:
-            text = "\n".join(re.sub(r"<[^>]*>", "", ln).split("//")[0].rstrip() for ln in body)
+            # (branch targets are printed as absolute offsets: drop them, they move with the position in the code object)
+            text = "\n".join(re.sub(r"^(s_c?branch\S*)\s+\S+", r"\1", re.sub(r"<[^>]*>", "", ln).split("//")[0].rstrip()) for ln in body)
             out[cur]["insts"] = len(body)
             out[cur]["sha"] = hashlib.sha1(text.encode()).hexdigest()[:12]
     for line in dis.splitlines():

@@ -13,7 +13,7 @@ from tests.test_gpu_parity import _averaging_variant  # noqa: E402
 from tools.perf_table import timed  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for variant in ("plain", "cli_grid", "em_syserr", "extinction", "p92", "many_points"):
+for variant in ("plain", "cli_grid", "log_grid", "em_syserr", "time_nodes", "extinction", "p92", "many_points"):
     case = _averaging_variant(variant)
     th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
     out = torch.empty(B, dtype=torch.float64, device="cuda:0")
