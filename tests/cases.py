@@ -136,6 +136,32 @@ def case_averaging(names=None, counts=12, n_new=9):
     return c
 
 
+def case_averaging_nodes_grid():
+    """Averaged bands + time-node systematics (shared by the averaged ATLAS / PS1 bands, a group of its own for ``I``, one
+    parameter for the rest) + the documented CLI grid: everything the general lean task adds, through the reference's own
+    FilterSystematicsHandler and averaging code."""
+    nodes = np.linspace(0.0, 21.0, 4)
+    n_a = [f"em_syserr_wide_{i}" for i in range(4)]
+    n_b = [f"em_syserr_I_{i}" for i in range(4)]
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift",
+             "log10_mej_dyn", "log10_mej_wind", "em_syserr_rest"] + n_a + n_b
+    c = case_averaging(names=names)
+    c["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    wide = ["w", "o", "r"]
+    spec_nodes = {f: (n_a, nodes) for f in wide}
+    spec_nodes["I"] = (n_b, nodes)
+    spec_names = {f: "em_syserr_rest" for f in c["observed_filters"] if f not in spec_nodes}
+    c["systematics"] = dict(mode="mixed", names=spec_names, nodes=spec_nodes)
+    c["systematics_ref"] = dict(
+        error_budget=None,
+        systematics_file={
+            "wide": {"filters": wide, "time_nodes": 4, "time_range": "lin 0.0 21.0"},
+            "I": {"time_nodes": 4, "time_range": "lin 0.0 21.0"},
+            "rest": {"prior": "unused"},
+        })
+    return c
+
+
 def case_edges():
     """timeshift / redshift pushing data out of the model window (m_est = +inf ->
     NaN -> floor), an upper-limit-only filter and a one-point filter."""
@@ -224,6 +250,7 @@ CASES = {
     "syserr_param": case_syserr_param,
     "syserr_time_nodes": case_syserr_time_nodes,
     "averaging": case_averaging,
+    "averaging_nodes_grid": case_averaging_nodes_grid,
     "edges": case_edges,
     "c4_shape": case_c4_shape,
     "small_hidden": case_small_hidden,
