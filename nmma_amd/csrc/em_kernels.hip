@@ -1328,7 +1328,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
-        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
     };
 
@@ -1358,6 +1357,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         constexpr bool TWO = decltype(two_tag)::value;
         const ItemDesc& it = itab[k];
         const int o = it.o;
+#ifdef NMMA_DBG_TASKSTAMPS      // diagnostic build: per-task stage stamps, dbg[128 + 8 (4 k + c) + j]
+#define NM_TS(j) do { if (dbg && blockIdx.x == 0 && lane == 0 && k < 6 && c < 4) dbg[128 + 8 * (4 * k + c) + (j)] = clock64(); } while (0)
+#else
+#define NM_TS(j) do { } while (0)
+#endif
+        NM_TS(0);
+#ifdef NMMA_DBG_TASKSTAMPS
+        if (dbg && blockIdx.x == 0 && lane == 0 && k < 6 && c < 4) dbg[128 + 8 * (4 * k + c) + 7] = wave;
+#endif
         if (c == 0) {      // this wave stages the item's basis rows (see fast_task)
             if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), itab[k - NBUF].ntask[R - 1], P.watchdog, 800 + k);
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
@@ -1367,6 +1375,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
                 __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
         }
+        NM_TS(1);
         typedef const __attribute__((address_space(3))) double* lds_cdp;
         typedef const __attribute__((address_space(3))) float* lds_cfp;
         typedef __attribute__((address_space(3))) double* lds_dp;
@@ -1430,13 +1439,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         };
         stage_p(0);
+        NM_TS(2);
         // ---- stage Q (needs the coefficients of item k)
         if (c == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NM_TS(3);
             sync_signal(sync + 2 * W + 4 + k, lane);     // rows of item k staged
         }
         sync_wait(sync + 2 * W + 4 + k, 1, P.watchdog, 350 + k);
+        NM_TS(4);
         sync_wait(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
+        NM_TS(5);
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
         const lds_cfp b2l = (lds_cfp)(tbl + P.tab_off_b2);
@@ -1616,8 +1629,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
-        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
+        NM_TS(6);
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
+#undef NM_TS
     };
 
     // ---------------------------------------------------------------------------------
@@ -1914,7 +1928,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             }
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
-        if (dbg && blockIdx.x == 0 && lane == 0) { int tt = c; for (int q = 0; q < k; ++q) tt += itab[q].ntask[R - 1]; if (tt < 24) dbg[104 + tt] = clock64(); }
         for (int kk = k0; kk <= k; ++kk) sync_signal(sync + W + 2 + kk, lane);     // one signal per task and source item
     };
 
@@ -1943,6 +1956,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 #endif
             if (dbg && blockIdx.x == 0 && lane == 0 && t < 24) { dbg[16 + t] = clock64(); dbg[40 + t] = wave; }
             if (t >= ntot) break;
+            const int t_claim = t;
             if (++claims > ntot + 64) {          // cannot happen; fail loudly instead of spinning
                 if (lane == 0) { g_ip wd = (g_ip)(uintptr_t)P.watchdog; wd[0] = 1; wd[1] = 900; wd[2] = (int)blockIdx.x * 64 + wave; wd[3] = t; }
                 break;
@@ -1983,6 +1997,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);
 #endif
+            if (dbg && blockIdx.x == 0 && lane == 0 && t_claim < 24) dbg[104 + t_claim] = clock64();     // (after the task's done-signal)
         }
     } else {
         for (int k = 0; k < W; ++k) {

@@ -30,3 +30,12 @@ print("tasks: index wave claim -> done (cycles rel. to t0)")
 for i in range(24):
     if st[16 + i] > 0:
         print(f"   task {i:2d} (item {i//4}) wave {st[40+i]:2d}  claim {st[16+i]-t0:7d}  done {st[104+i]-t0:7d}  dur {st[104+i]-st[16+i]:6d}")
+
+if any(st[128 + 8 * i] > 0 for i in range(24)):       # a -DNMMA_DBG_TASKSTAMPS build: stage stamps per (item, chunk)
+    print("stage stamps (item, chunk): wave | entry | +staging issued | +stage P | +rows landed (c = 0) | rows seen | coefficients seen | end")
+    for i in range(24):
+        b = 128 + 8 * i
+        if st[b] <= 0:
+            continue
+        rel = lambda j: (st[b + j] - t0) if st[b + j] > 0 else -1
+        print(f"   ({i // 4}, {i % 4}) wave {st[b + 7]:2d}  entry {rel(0):6d}  stg {rel(1):6d}  P {rel(2):6d}  landed {rel(3):6d}  rows {rel(4):6d}  coef {rel(5):6d}  end {rel(6):6d}")
