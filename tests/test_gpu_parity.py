@@ -275,6 +275,12 @@ def test_lean_task_combinations_match_oracle(combo, torch_cuda, monkeypatch):
         eng.check()
         fin = got != FLOOR
         assert np.array_equal(ext != FLOOR, fin) and rel_err(got[fin], ext[fin]).max() <= 1e-9
+        eng.close()
+        monkeypatch.delenv("NMMA_EM_NO_LEAN_NODES")
+        monkeypatch.setenv("NMMA_EM_TILE", "2")        # 32-sample tiles: same bits
+        eng = engine_from_case(case)
+        assert np.array_equal(eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy(), got)
+        assert eng.last_launch_geometry()["tile_samples"] == 32
     want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
     floor = want == FLOOR
     assert np.array_equal(got == FLOOR, floor) and (~floor).sum() > 10
@@ -307,6 +313,11 @@ def _averaging_variant(variant):
         case["systematics"] = dict(mode="mixed", names={f: "em_syserr_rest" for f in obs if f not in nodes}, nodes=nodes)
     else:
         case = cases.case_averaging()
+    if variant == "two_sources":       # without the three-source band the ring of 32-sample tiles is deep enough
+        keep = [f for f in case["observed_filters"] if f != "w"]
+        case["observed_filters"] = keep
+        case["data"] = tuple({f: d[f] for f in keep} for d in case["data"])
+        case["systematics"] = dict(mode="budget", values={f: 0.5 for f in keep})
     if variant == "cli_grid":
         case["sample_times"] = np.arange(0.1, 20.5, 0.5)
     if variant == "log_grid":
@@ -314,7 +325,7 @@ def _averaging_variant(variant):
     return case
 
 
-@pytest.mark.parametrize("variant", ["plain", "cli_grid", "em_syserr", "time_nodes", "extinction", "p92", "many_points", "log_grid"])
+@pytest.mark.parametrize("variant", ["plain", "two_sources", "cli_grid", "em_syserr", "time_nodes", "extinction", "p92", "many_points", "log_grid"])
 def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     """Averaged bands (ATLAS c / o, PS1 w, Johnson V / I: the mean of two or three model filters, utils.py:566-584) on the lean
     task (em_logl<.., 5>: 16-wave workgroups) with each of its extras, against the oracle and against the generic item
@@ -332,10 +343,15 @@ def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     eng = engine_from_case(case)
     got32 = eng.loglike(th).cpu().numpy()
     eng.check()
+    geo32 = eng.last_launch_geometry()
     eng.close()
-    # (forced 32-sample tiles: the ring is then too shallow for three sources and the handle keeps the generic phase)
+    # (forced 32-sample tiles: with a three-source band the ring is too shallow and the handle keeps the generic phase;
+    #  with two sources at most the lean task runs on 32-sample tiles and gives the same bits)
     fin = got != FLOOR
-    assert np.array_equal(got32 != FLOOR, fin) and rel_err(got[fin], got32[fin]).max() <= 1e-9
+    if variant == "two_sources":
+        assert geo32["block"] == 1024 and geo32["tile_samples"] == 32 and np.array_equal(got, got32)
+    else:
+        assert np.array_equal(got32 != FLOOR, fin) and rel_err(got[fin], got32[fin]).max() <= 1e-9
     monkeypatch.delenv("NMMA_EM_TILE")
     monkeypatch.setenv("NMMA_EM_NO_LEAN_AVG", "1")
     eng = engine_from_case(case)
