@@ -115,6 +115,7 @@ struct EmDev {
     const int32_t* sys_nidx;  // [N]  node bracket per datum (-1: left of first, K-1: at/after last)
     const double* sys_ndx;    // [N]  node spacing
     const double* sys_noff;   // [N]  t - node time
+    const int32_t* d_item;    // [N] first work item of each datum's observed filter (em_lc_loglike's flat pass over the photometry)
     int32_t lean_gen, pad_gen;        // general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
 };
 

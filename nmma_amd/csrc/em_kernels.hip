@@ -1635,15 +1635,19 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     };
 
     // ---------------------------------------------------------------------------------
-    // lean_avg_task (FASTM = 5): the lean task for configurations with averaged bands -- an observed filter whose magnitude
-    // is the mean of several model filters (utils.py:566-584).  k is the LAST source item of the band (items k - nsrc + 1 .. k,
-    // one surrogate each; nsrc = 1 for an ordinary band); stage Q walks the sources -- wait for the source's coefficients,
-    // node magnitudes with its basis rows, + extinction of its filter + distance modulus -- sums them in source order and
-    // divides the interpolated sum by nsrc (the generic item phase's order).  The other source items own no tasks; every
-    // task of the band signals each of them, which releases their ring slots.  A copy of lean_task rather than a variant
-    // of it: any change to that lambda, even a semantically neutral one, moves hipcc's register allocation off its optimum.
+    // lean_gen_task (FASTM = 5): the general lean task -- lean_task's extras (passes of 32 points, extinction table, sampled
+    // systematics, unequally spaced grids) plus
+    //  * averaged bands: an observed filter whose magnitude is the mean of several model filters (utils.py:566-584).  k is the
+    //    LAST source item of the band (items k - nsrc + 1 .. k, one surrogate each; nsrc = 1 for an ordinary band); stage Q
+    //    walks the sources -- wait for the source's coefficients, node magnitudes with its basis rows, + extinction of its
+    //    filter + distance modulus -- sums them in source order and divides the interpolated sum by nsrc (the generic item
+    //    phase's order).  The other source items own no tasks; every task of the band signals each of them, which releases
+    //    their ring slots.
+    //  * time-node systematics (systematics.py:288-291): see SYS below.
+    // A copy of lean_task rather than a variant of it: any change to that lambda, even a semantically neutral one, moves
+    // hipcc's register allocation off its optimum in every instantiation.
     // ---------------------------------------------------------------------------------
-    auto lean_avg_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, auto nonuni_tag, const int k, const int c) {
+    auto lean_gen_task = [&](auto typeb_tag, auto two_tag, auto sys_tag, auto nonuni_tag, const int k, const int c) {
         // NONUNI: sample_times not equally spaced (the CLI's default log-spaced grid): branch-free bisection instead of the
         // index guess, and the node spacing from a table
         constexpr bool NONUNI = decltype(nonuni_tag)::value;
@@ -1982,9 +1986,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     if constexpr (FASTM == 4) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
                         if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
                     } else if constexpr (FASTM == 5) {
-                        if (!P.st_uniform) { if (sysp) lean_avg_task(tb, T{}, T{}, T{}, k, t); else lean_avg_task(tb, T{}, F{}, T{}, k, t); }
-                        else if (sysp) { if (two) lean_avg_task(tb, T{}, T{}, F{}, k, t); else lean_avg_task(tb, F{}, T{}, F{}, k, t); }
-                        else { if (two) lean_avg_task(tb, T{}, F{}, F{}, k, t); else lean_avg_task(tb, F{}, F{}, F{}, k, t); }
+                        if (!P.st_uniform) { if (sysp) lean_gen_task(tb, T{}, T{}, T{}, k, t); else lean_gen_task(tb, T{}, F{}, T{}, k, t); }
+                        else if (sysp) { if (two) lean_gen_task(tb, T{}, T{}, F{}, k, t); else lean_gen_task(tb, F{}, T{}, F{}, k, t); }
+                        else { if (two) lean_gen_task(tb, T{}, F{}, F{}, k, t); else lean_gen_task(tb, F{}, F{}, F{}, k, t); }
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
@@ -2181,6 +2185,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
 //   combine_detector_data (model.py:381-404), sanity_check (em_likelihood.py:305-311),
 //   autocomplete_data with its finite mask (utils.py:626-645), band_log_likelihood (:337-352).
 // One wave per parameter vector; lanes stride over the data of each observed filter.
+// HBM-bound by design (the curves are read once: B x M x NS doubles): each wave first puts ALL of its sample's curves in
+// flight (coalesced, one LDS slab per wave) together with the block's copy of the sample-time and cosmology grids, so that
+// the serial parts that follow -- per-sample scalars, bracket searches, finite-node walks -- run on LDS latency
+// (`stage_all`; a configuration whose curves do not fit keeps the per-filter copy from global memory).
 // =======================================================================================
 __device__ __forceinline__ double wave_sum(double v) {
     v = group_sum(v, 64);
@@ -2192,24 +2200,41 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(256) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
-    const double* __restrict__ lc, const int lds_per_wave, const int always_floor, double* __restrict__ out,
+    const double* __restrict__ lc, const int lds_per_wave, const int stage_all, const int always_floor, double* __restrict__ out,
     double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
     const EmDev& P = *Pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long b = (long)blockIdx.x * 4 + wave;
-    if (b >= B) return;
+    const long b_raw = (long)blockIdx.x * 4 + wave;
+    const long b = b_raw < B ? b_raw : B - 1;          // (a wave beyond the batch recomputes the last row and stores nothing)
     const int NS = P.NS, M = P.M;
-    // per-wave LDS: app[NS] | estacc[nf_max] | praw[8] | scal[8]
-    double* app = reinterpret_cast<double*>(smem + (size_t)wave * lds_per_wave);
+    // block LDS: stl[NS] | dist_grid[n_cosmo] | z_grid[n_cosmo] (the cosmology grid only when it fits STAGE_COSMO nodes),
+    // then per wave: app[NS] | estacc[nf_max] | praw[8] | scal[8] | curves[M][NS] (stage_all)
+    const bool cosmo_lds = P.redshift_mode == NMMA_Z_GRID && P.n_cosmo <= STAGE_COSMO;
+    double* stl = reinterpret_cast<double*>(smem);
+    double* dgl = stl + NS;
+    double* zgl = dgl + (cosmo_lds ? P.n_cosmo : 0);
+    const int shared_bytes = ((NS + (cosmo_lds ? 2 * P.n_cosmo : 0)) * 8 + 15) & ~15;
+    double* app = reinterpret_cast<double*>(smem + shared_bytes + (size_t)wave * lds_per_wave);
     double* estacc = app + NS;
     double* praw = estacc + P.lc_nf_max;
     double* scal = praw + 8;
+    double* curves = scal + 8;
+    (void)estacc;
     const double* row = theta + b * ld;
+    if (stage_all) {                                   // every load of the sample's curves in flight before anything waits
+        const double* src = lc + (size_t)b * M * NS;
+        for (int j = lane; j < M * NS; j += 64) curves[j] = src[j];
+    }
+    for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
+    if (cosmo_lds)
+        for (int j = threadIdx.x; j < P.n_cosmo; j += 256) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
+    __syncthreads();
     if (lane == 0) {
         double chk;
-        sample_scalars(P, row, praw, scal, chk);
+        if (cosmo_lds) sample_scalars(P, row, praw, scal, chk, dgl, zgl);
+        else sample_scalars(P, row, praw, scal, chk);
         for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
         scal[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
     }
@@ -2220,99 +2245,109 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
 
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
     for (int m = 0; m < M; ++m) {
-        const double* cur = lc + ((size_t)b * M + m) * NS;
+        const double* cur = stage_all ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
         int nfin = 0;
         for (int j = lane; j < NS; j += 64) { const double v = cur[j]; nfin += (v - v == 0.0) ? 1 : 0; }
         nfin = (int)wave_sum((double)nfin);
         if (nfin < 2) bad = true;
     }
 
-    double chi_tot = 0.0, gp_tot = 0.0;
-    for (int k = 0; k < P.n_items; ++k) {
-        const ItemDesc& it = P.item_desc[k];
-        const int o = it.o, ks = it.ks, m = it.m, nsrc = it.nsrc, d0 = it.d0, nf = it.nf, kind = it.kind;
-        const double lim = it.lim, e_const = it.e_const;
-        const double ext = extinction_mag(P.ext_law, it.ebvc, zp1, ebv);
-        // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
-        const double* cur = lc + ((size_t)b * M + m) * NS;
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < NS; j += 64) {
-            double v = cur[j];
-            if (ext != 0.0) v = v + ext;
-            app[j] = (v + dmod) + rc;
+    // One datum: interpolate every source curve of the datum's band at its epoch, average, likelihood term.
+    // k0 = first work item of the band (its sources are consecutive items); the bracket depends on the epoch only.
+    auto datum_term = [&](const int di, const int k0, double& chi, double& gp) {
+        const ItemDesc& it0 = P.item_desc[k0];
+        const int o = it0.o, nsrc = it0.nsrc, kind = it0.kind;
+        const double lim = it0.lim, e_const = it0.e_const;
+        const double t = P.dt[di];
+        int lo = -1;                                   // t_obs[lo] <= t (<= t_obs[NS - 1]); -1: outside the grid
+        if (t == t && NS >= 1 && t >= stl[0] * zp1 + tsh && t <= stl[NS - 1] * zp1 + tsh) {
+            int hi = NS - 1;
+            lo = 0;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+            }
+            if (stl[hi] * zp1 + tsh <= t) lo = hi;      // t on the last node
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double chi = 0.0, gp = 0.0;
-        for (int dd = lane; dd < nf; dd += 64) {
-            const int di = d0 + dd;
-            const double t = P.dt[di];
+        double acc_e = 0.0;
+        for (int ks = 0; ks < nsrc; ++ks) {
+            const ItemDesc& it = P.item_desc[k0 + ks];
+            const double ext = extinction_mag(P.ext_law, it.ebvc, zp1, ebv);
+            // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
+            const double* cur = stage_all ? curves + it.m * NS : lc + ((size_t)b * M + it.m) * NS;
+            auto app = [&](const int j) { double v = cur[j]; if (ext != 0.0) v = v + ext; return (v + dmod) + rc; };
             // np.interp over the FINITE nodes only, left = right = +inf (utils.py:634-645)
             double est = dinf();
             if (t != t) {
                 est = t;
-            } else if (NS >= 1 && t >= P.st[0] * zp1 + tsh && t <= P.st[NS - 1] * zp1 + tsh) {
-                int lo = 0, hi = NS - 1;          // t_obs[lo] <= t <= t_obs[hi]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (P.st[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
-                }
-                if (P.st[hi] * zp1 + tsh <= t) lo = hi;      // t on the last node
+            } else if (lo >= 0) {
                 int jl = lo;                                  // nearest finite node at or left of t
-                while (jl >= 0 && !(app[jl] - app[jl] == 0.0)) --jl;
+                while (jl >= 0 && !(cur[jl] - cur[jl] == 0.0)) --jl;
                 int jr = lo + 1;                              // nearest finite node right of t
-                while (jr < NS && !(app[jr] - app[jr] == 0.0)) ++jr;
+                while (jr < NS && !(cur[jr] - cur[jr] == 0.0)) ++jr;
                 if (jl >= 0) {
-                    const double x0 = P.st[jl] * zp1 + tsh;
-                    if (x0 == t) est = app[jl];
-                    else if (jr < NS) est = lerp_np(t, x0, P.st[jr] * zp1 + tsh, app[jl], app[jr]);
+                    const double x0 = stl[jl] * zp1 + tsh;
+                    if (x0 == t) est = app(jl);
+                    else if (jr < NS) est = lerp_np(t, x0, stl[jr] * zp1 + tsh, app(jl), app(jr));
                 }
             }
-            if (nsrc > 1) {
-                double acc_e = est;
-                if (ks > 0) acc_e = estacc[dd] + est;
-                if (ks < nsrc - 1) { estacc[dd] = acc_e; continue; }
-                est = acc_e / (double)nsrc;
-            }
-            const double sd = P.dsig[di];
-            double e = e_const, sig, lsig;
-            if (kind == NMMA_SYS_CONST) {
-                sig = P.dsigtot[di]; lsig = P.dlogsig[di];
-            } else {
-                const nmma_slot* sv = P.sys_slots + P.sys_off[o];
-                if (kind == NMMA_SYS_PARAM) {
-                    e = apply_slot(sv[0], row);
-                } else {
-                    const int K = P.sys_nn[o];
-                    const int ni = P.sys_nidx[di];
-                    if (ni < 0) e = apply_slot(sv[0], row);
-                    else if (ni >= K - 1) e = apply_slot(sv[K - 1], row);
-                    else {
-                        const double v0 = apply_slot(sv[ni], row), v1 = apply_slot(sv[ni + 1], row);
-                        e = ((v1 - v0) / P.sys_ndx[di]) * P.sys_noff[di] + v0;
-                    }
-                }
-                sig = sqrt(sd * sd + e * e);
-                lsig = log(sig);
-            }
-            const double mobs = P.dm[di];
-            if (sig - sig == 0.0) chi += detection_term(mobs, est, sig, lsig, lim);
-            else gp += upper_limit_term(mobs, est, e);
+            acc_e = ks == 0 ? est : acc_e + est;     // averaged band: (a + b [+ c]) / n  (utils.py:566-584)
         }
-        if (ks < nsrc - 1) continue;
-        chi = wave_sum(chi);
-        gp = wave_sum(gp);
-        chi_tot += chi;
-        gp_tot += gp;
-        if (chi != chi) bad = true;
-        if (chi_parts != nullptr && lane == 0) {
-            chi_parts[(long)o * B + b] = chi;
-            gp_parts[(long)o * B + b] = gp;
+        const double est = nsrc > 1 ? acc_e / (double)nsrc : acc_e;
+        const double sd = P.dsig[di];
+        double e = e_const, sig, lsig;
+        if (kind == NMMA_SYS_CONST) {
+            sig = P.dsigtot[di]; lsig = P.dlogsig[di];
+        } else {
+            const nmma_slot* sv = P.sys_slots + P.sys_off[o];
+            if (kind == NMMA_SYS_PARAM) {
+                e = apply_slot(sv[0], row);
+            } else {
+                const int K = P.sys_nn[o];
+                const int ni = P.sys_nidx[di];
+                if (ni < 0) e = apply_slot(sv[0], row);
+                else if (ni >= K - 1) e = apply_slot(sv[K - 1], row);
+                else {
+                    const double v0 = apply_slot(sv[ni], row), v1 = apply_slot(sv[ni + 1], row);
+                    e = ((v1 - v0) / P.sys_ndx[di]) * P.sys_noff[di] + v0;
+                }
+            }
+            sig = sqrt(sd * sd + e * e);
+            lsig = log(sig);
+        }
+        const double mobs = P.dm[di];
+        if (sig - sig == 0.0) chi += detection_term(mobs, est, sig, lsig, lim);
+        else gp += upper_limit_term(mobs, est, e);
+    };
+
+    double chi_tot = 0.0, gp_tot = 0.0;
+    if (chi_parts == nullptr) {
+        // all photometry points of all bands in one pass over the lanes (a band with a dozen points would otherwise leave
+        // most of the wave idle for a whole pass): d_item[di] = first work item of the datum's band
+        double chi = 0.0, gp = 0.0;
+        for (int di = lane; di < P.n_data; di += 64) datum_term(di, P.d_item[di], chi, gp);
+        chi_tot = wave_sum(chi);
+        gp_tot = wave_sum(gp);
+    } else {
+        // per-filter parts requested: one pass per band
+        for (int k = 0; k < P.n_items; ++k) {
+            const ItemDesc& it = P.item_desc[k];
+            if (it.ks != 0) continue;
+            double chi = 0.0, gp = 0.0;
+            for (int dd = lane; dd < it.nf; dd += 64) datum_term(it.d0 + dd, k, chi, gp);
+            chi = wave_sum(chi);
+            gp = wave_sum(gp);
+            chi_tot += chi;
+            gp_tot += gp;
+            if (lane == 0 && b_raw < B) {
+                chi_parts[(long)it.o * B + b] = chi;
+                gp_parts[(long)it.o * B + b] = gp;
+            }
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && b_raw < B) {
         double tot = chi_tot + gp_tot;
-        if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+        if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;      // (a NaN term of any band makes the total NaN)
         out[b] = tot;
     }
 }
