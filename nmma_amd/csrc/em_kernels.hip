@@ -2085,11 +2085,22 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     const int m = blockIdx.y;  // model filter
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
 
-    if (tid < TS) {
-        long b = tile0 + tid;
-        if (b >= B) b = B - 1;
-        double chk;
-        sample_scalars(P, theta + b * ld, praw + tid * 8, scal + tid * 8, chk);
+    if constexpr (MODE == MODE_LC) {
+        if (tid < TS) {
+            long b = tile0 + tid;
+            if (b >= B) b = B - 1;
+            double chk;
+            sample_scalars(P, theta + b * ld, praw + tid * 8, scal + tid * 8, chk);
+        }
+    } else {
+        // coefficients and source-frame curves need the model parameters only: one thread per (sample, parameter) instead of the
+        // serial per-sample chain (cosmology-grid search, log10) that the detector-frame outputs go through
+        for (int idx = tid; idx < TS * 8; idx += NTHR) {
+            const int s = idx >> 3, p = idx & 7;
+            long b = tile0 + s;
+            if (b >= B) b = B - 1;
+            praw[s * 8 + p] = (p < NP) ? apply_slot(P.model_param[p], theta + b * ld) : 0.0;
+        }
     }
     for (int j = tid; j < NS; j += NTHR) stl[j] = P.st[j];
     __syncthreads();
@@ -2151,9 +2162,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
             const int s = sb0 + sl;
             const long b = tile0 + s;
             if (b >= B) continue;
-            const double zp1 = scal[s * 8 + S_ZP1], tsh = scal[s * 8 + S_TS];
-            const double ebv = scal[s * 8 + S_EBV];
-            const double ext = extinction_mag(P.ext_law, ebvc, zp1, ebv);
+            double zp1 = 1.0, tsh = 0.0, ext = 0.0;
+            if constexpr (MODE == MODE_LC) {
+                zp1 = scal[s * 8 + S_ZP1]; tsh = scal[s * 8 + S_TS];
+                ext = extinction_mag(P.ext_law, ebvc, zp1, scal[s * 8 + S_EBV]);
+            }
             double v = dinf();
             if (j >= jlo && j <= jhi && jhi > jlo) {
                 const double* magrow = magb + sl * NT;
