@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 // blockIdx.y, all WPB waves on the MLP first.
 // =======================================================================================
 struct LdsOff {
-    int32_t part, cd, praw, scal, stl, mag, total;
+    int32_t part, cd, praw, scal, stl, s1, mag, total;     // s1: the filter's stage-1 lerp tables [dx NS f64 | off NS f64 | idx NS i32]
     int32_t SB;        // MODE_LC: samples per dense reconstruction sub-batch
 };
 
@@ -2043,19 +2043,24 @@ __host__ inline LdsOff lds_layout(int mode, int R, int NC, int NT, int NS) {
     const int TS = 16 * R;
     LdsOff L{};
     int off = 0;
-    L.part = off; off = align16(off + NSLICE * TS * PSTR * 4);
+    // (the partial sums are dead once the coefficients are reduced: the dense magnitude buffer of the light-curve modes
+    //  takes their place -- the kernel is latency-bound and every block more per CU counts: 3 -> 4 for BASELINE config 2)
     L.cd = off;   off = align16(off + TS * NC * 8);
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
     L.stl = off;  off = align16(off + NS * 8);
+    L.s1 = off;   off = align16(off + ((mode == MODE_LC || mode == MODE_LC_ABS) ? NS * 20 : 0));
     L.SB = 0;
+    L.part = off;
     L.mag = off;
+    int un = NSLICE * TS * PSTR * 4;
     if (mode == MODE_LC || mode == MODE_LC_ABS) {
         int SB = TS;   // dense buffer: as many samples as fit ~32 KiB
         while (SB > 1 && SB * NT * 8 > 32 * 1024) SB >>= 1;
         L.SB = SB;
-        off = align16(off + SB * NT * 8);
+        un = un > SB * NT * 8 ? un : SB * NT * 8;
     }
+    off = align16(off + un);
     L.total = off;
     return L;
 }
@@ -2103,6 +2108,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
         }
     }
     for (int j = tid; j < NS; j += NTHR) stl[j] = P.st[j];
+    // the filter's stage-1 tables next to the sample times: the write-out loop below then runs on LDS latency (it used to
+    // take three L2 round trips per element with one element in flight per thread -- 2/3 of the kernel's time)
+    double* s1dx_l = reinterpret_cast<double*>(smem + L.s1);
+    double* s1of_l = s1dx_l + NS;
+    int* s1i_l = reinterpret_cast<int*>(s1of_l + NS);
+    if constexpr (MODE == MODE_LC || MODE == MODE_LC_ABS) {
+        for (int j = tid; j < NS; j += NTHR) {
+            s1dx_l[j] = P.s1_dx[(size_t)m * NS + j]; s1of_l[j] = P.s1_off[(size_t)m * NS + j]; s1i_l[j] = P.s1_idx[(size_t)m * NS + j];
+        }
+    }
     __syncthreads();
 
     // ---- MLP
@@ -2142,14 +2157,46 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     const int jlo = P.s1_range[m * 4 + 0], jhi = P.s1_range[m * 4 + 1];
     const bool identity = P.s1_range[m * 4 + 2] != 0;
     const double ebvc = P.has_ebv ? P.ebv_coeff[m] : 0.0;
-    gci32p s1i = as_global(P.s1_idx) + (size_t)m * NS;
-    gcf64p s1dx = as_global(P.s1_dx) + (size_t)m * NS, s1of = as_global(P.s1_off) + (size_t)m * NS;
     gcf64p VAt = as_global(P.VAt) + (size_t)m * NC * NT;
     const int SB = L.SB;
+    // (fallback loop below, taken when fewer than 16 samples fit the dense buffer -- SVD grids of more than 256 nodes: a per-thread
+    //  FMA chain, the block's threads shared by G groups of samples when the grid has fewer nodes than the block has threads)
+    const int G = NTHR / NT > 0 ? NTHR / NT : 1;
     for (int sb0 = 0; sb0 < TS; sb0 += SB) {
-        for (int t = tid; t < NT; t += NTHR) {
+#ifndef NMMA_FUSED_VALU_RECON
+        if (SB >= 16) {
+            // mag[t][s] = (VA[t, :] . c[s, :]) span[t] + mins[t] for all NT nodes: the one dense product of the path, on the fp64
+            // matrix cores -- 16 nodes x 16 samples per v_mfma_f64_16x16x4, K = NC in steps of 4 (zero-padded).  A lane holds
+            // A[node lane % 16][k = lane / 16], B[k = lane / 16][sample lane % 16] and D[node 4 r + lane / 16][sample lane % 16]
+            // (the fp64 result rows are interleaved, unlike the fp32 16x16x4 variant's 4 (lane / 16) + r: tools/ubench/mfma_f64_layout.hip).
+            // (as a per-thread FMA loop this phase took 35 us of the kernel's 80 at 4096 rows: 2/5 of its time)
+            typedef double f64x4_t __attribute__((ext_vector_type(4)));
+            gcf64p VA = as_global(P.VA) + (size_t)m * NT * NC;
+            const int n_tt = (NT + 15) / 16;
+            const int ntile = n_tt * (SB / 16);
+            for (int tile = wave; tile < ntile; tile += WPB) {
+                const int tt = tile % n_tt, st = tile / n_tt;
+                const int t_a = tt * 16 + (lane & 15);
+                const int s_b = sb0 + st * 16 + (lane & 15);
+                f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk * 4 < NC; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    const double a = (t_a < NT && k < NC) ? VA[(size_t)t_a * NC + k] : 0.0;
+                    const double bq = (k < NC) ? cd[s_b * NC + k] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = tt * 16 + 4 * r + (lane >> 4);
+                    if (t < NT) magb[(st * 16 + (lane & 15)) * NT + t] = acc[r] * P.span[m * NT + t] + P.mins[m * NT + t];
+                }
+            }
+        } else
+#endif
+        for (int idx = tid; idx < NT * G; idx += NTHR) {
+            const int g = idx / NT, t = idx - g * NT;
             const double sp = P.span[m * NT + t], mn = P.mins[m * NT + t];
-            for (int s = 0; s < SB; ++s) {
+            for (int s = g; s < SB; s += G) {
                 const double* c = cd + (sb0 + s) * NC;
                 double a = VAt[t] * c[0];
                 for (int j = 1; j < NC; ++j) a = fma(VAt[j * NT + t], c[j], a);
@@ -2170,13 +2217,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
             double v = dinf();
             if (j >= jlo && j <= jhi && jhi > jlo) {
                 const double* magrow = magb + sl * NT;
-                const int i1 = s1i[j];
+                const int i1 = s1i_l[j];
                 if (identity) {
                     v = magrow[i1];
                 } else {
                     const double y0 = magrow[i1], y1 = magrow[i1 + 1 < NT ? i1 + 1 : NT - 1];
-                    const double slope = (y1 - y0) / s1dx[j];
-                    v = slope * s1of[j] + y0;
+                    const double slope = (y1 - y0) / s1dx_l[j];
+                    v = slope * s1of_l[j] + y0;
                 }
                 if constexpr (MODE == MODE_LC) {
                     if (ext != 0.0) v = v + ext;
