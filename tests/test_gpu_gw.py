@@ -39,6 +39,26 @@ def test_inner_products_match_oracle(shape, torch_cuda):
     np.testing.assert_allclose(full, want + gw.noise_log_likelihood(), rtol=1e-10)
 
 
+def test_samples_per_workgroup_variants_give_the_same_bits(torch_cuda):
+    """The launcher groups 1, 2, 4 or 8 parameter vectors per workgroup depending on the batch size (the shared data / weight
+    arrays are read once per group); a sample's summation order does not depend on the grouping: bit-identical rows for
+    every batch size, including sizes that are not a multiple of the group."""
+    torch = torch_cuda
+    from nmma_amd.gw.gw_likelihood import GWStrainLikelihood
+    from oracle import gw_oracle as gwo
+    c = make_gw_case(n_ifo=2, batch=2500, duration=1.0, sampling_frequency=512.0)
+    gw = GWStrainLikelihood(c["data"], c["psd"], c["frequency_array"], c["duration"], minimum_frequency=c["minimum_frequency"])
+    s_dev = torch.as_tensor(c["strain"], device="cuda:0")
+    full = gw.log_likelihood_ratio_batch(s_dev).cpu().numpy()                       # 2500 rows: 8 per workgroup, ragged tail
+    want = gwo.log_likelihood_ratio_batch(c["strain"][:64], c["data"], c["psd"], c["mask"], c["duration"])
+    np.testing.assert_allclose(full[:64], want, rtol=1e-10, atol=1e-10 * np.abs(want).max())
+    for nrows in (1, 7, 300, 513, 1027, 2049):                                      # 1 / 1 / 1 / 2 / 4 / 8 per workgroup
+        part = gw.log_likelihood_ratio_batch(s_dev[:nrows]).cpu().numpy()
+        assert np.array_equal(part, full[:nrows]), nrows
+        tail = gw.log_likelihood_ratio_batch(s_dev[2500 - nrows:]).cpu().numpy()
+        assert np.array_equal(tail, full[2500 - nrows:]), nrows
+
+
 def test_bad_arguments_are_refused(torch_cuda):
     from nmma_amd import _lib as L
     from nmma_amd.gw.gw_likelihood import GWStrainLikelihood
