@@ -2159,12 +2159,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     const double ebvc = P.has_ebv ? P.ebv_coeff[m] : 0.0;
     gcf64p VAt = as_global(P.VAt) + (size_t)m * NC * NT;
     const int SB = L.SB;
-    // (fallback loop below, taken when fewer than 16 samples fit the dense buffer -- SVD grids of more than 256 nodes: a per-thread
-    //  FMA chain, the block's threads shared by G groups of samples when the grid has fewer nodes than the block has threads)
+    // (fallback loop below, taken when fewer than 16 samples fit the dense buffer -- SVD grids of more than 256 nodes -- or with more
+    //  than 16 coefficients: a per-thread FMA chain, the block's threads shared by G groups of samples when the grid has fewer nodes than the block has threads)
     const int G = NTHR / NT > 0 ? NTHR / NT : 1;
     for (int sb0 = 0; sb0 < TS; sb0 += SB) {
 #ifndef NMMA_FUSED_VALU_RECON
-        if (SB >= 16) {
+        if (SB >= 16 && NC <= 16) {
             // mag[t][s] = (VA[t, :] . c[s, :]) span[t] + mins[t] for all NT nodes: the one dense product of the path, on the fp64
             // matrix cores -- 16 nodes x 16 samples per v_mfma_f64_16x16x4, K = NC in steps of 4 (zero-padded).  A lane holds
             // A[node lane % 16][k = lane / 16], B[k = lane / 16][sample lane % 16] and D[node 4 r + lane / 16][sample lane % 16]
@@ -2173,22 +2173,40 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
             typedef double f64x4_t __attribute__((ext_vector_type(4)));
             gcf64p VA = as_global(P.VA) + (size_t)m * NT * NC;
             const int n_tt = (NT + 15) / 16;
-            const int ntile = n_tt * (SB / 16);
-            for (int tile = wave; tile < ntile; tile += WPB) {
-                const int tt = tile % n_tt, st = tile / n_tt;
-                const int t_a = tt * 16 + (lane & 15);
-                const int s_b = sb0 + st * 16 + (lane & 15);
-                f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
-                for (int kk = 0; kk * 4 < NC; ++kk) {
-                    const int k = kk * 4 + (lane >> 4);
-                    const double a = (t_a < NT && k < NC) ? VA[(size_t)t_a * NC + k] : 0.0;
-                    const double bq = (k < NC) ? cd[s_b * NC + k] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+            const int n_st = SB / 16;
+            // (the basis rows of up to four node tiles are requested before the first product -- one L2 round trip per group of
+            //  tiles instead of one per MFMA -- and serve every 16-sample tile of the sub-batch)
+            for (int tt0 = wave; tt0 < n_tt; tt0 += 4 * WPB) {
+                double av[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t_a = (tt0 + q * WPB) * 16 + (lane & 15);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = kk * 4 + (lane >> 4);
+                        av[q][kk] = (tt0 + q * WPB < n_tt && t_a < NT && k < NC) ? VA[(size_t)t_a * NC + k] : 0.0;
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = tt * 16 + 4 * r + (lane >> 4);
-                    if (t < NT) magb[(st * 16 + (lane & 15)) * NT + t] = acc[r] * P.span[m * NT + t] + P.mins[m * NT + t];
+                for (int q = 0; q < 4; ++q) {
+                    const int tt = tt0 + q * WPB;
+                    if (tt >= n_tt) break;
+                    for (int st = 0; st < n_st; ++st) {
+                        const int s_b = sb0 + st * 16 + (lane & 15);
+                        f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            if (kk * 4 >= NC) break;
+                            const int k = kk * 4 + (lane >> 4);
+                            const double bq = (k < NC) ? cd[s_b * NC + k] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bq, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int t = tt * 16 + 4 * r + (lane >> 4);
+                            if (t < NT) magb[(st * 16 + (lane & 15)) * NT + t] = acc[r] * P.span[m * NT + t] + P.mins[m * NT + t];
+                        }
+                    }
                 }
             }
         } else

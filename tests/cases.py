@@ -21,9 +21,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _base(seed=1234, model="Bu2019lm", filters=None, counts=None, batch=64, n_hidden=2048,
-          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0)):
+          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0), n_coeff=10):
     filters = list(filters or syn.AT2017GFO_FILTERS)
-    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden)
+    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden, n_coeff=n_coeff)
     grid = syn.flat_lcdm_grid(1.0, 200.0)
     data = syn.make_photometry(seed + 1, svd, mp, filters=filters, counts=counts,
                                cosmo_grid=grid, upper_limit_filter=upper_limit_filter,
@@ -310,6 +310,12 @@ def case_fast_single_filter():
     return _base(seed=9534, filters=["r"], counts=dict(r=17), batch=20, upper_limit_filter="r")
 
 
+def case_ncoeff7():
+    """svd_mag_ncoeff = 7 (the reference's --svd-mag-ncoeff): fewer SVD coefficients than the default 10 -- the generic item
+    phase, and a K that is not a multiple of 4 for the fp64-MFMA reconstruction of the light-curve kernels."""
+    return _base(seed=9644, batch=40, n_coeff=7, sample_times=np.arange(0.1, 20.5, 0.5))
+
+
 def case_fast_wide():
     """20 filters x 70 epochs (64 lanes per sample): with 32-sample tiles the task list (640 entries)
     exceeds the LDS task map and takes the scan fallback."""
@@ -364,6 +370,7 @@ def case_log_grid():
 SHAPE_CASES = {
     "fast_many_filters": case_fast_many_filters,
     "fast_np6": case_fast_np6,
+    "ncoeff7": case_ncoeff7,
     "many_points": case_many_points,
     "fast_single_filter": case_fast_single_filter,
     "fast_wide": case_fast_wide,

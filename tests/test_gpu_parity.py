@@ -80,7 +80,7 @@ def test_in_wave_kernel_matches_golden(name, torch_cuda, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["c2_default", "c2_dt05_limit", "c4_shape", "real_nets"])
+@pytest.mark.parametrize("name", ["c2_default", "c2_dt05_limit", "c4_shape", "real_nets", "ncoeff7"])
 def test_coefficients_and_lightcurves(name, torch_cuda):
     torch = torch_cuda
     from oracle import nmma_oracle as orc
