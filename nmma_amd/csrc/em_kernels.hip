@@ -2468,7 +2468,9 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
     double* lsum = tpw + NS;     // sum over layers of lum[:, j]
     double* rph = lsum + NS;     // photosphere radius
     double* tobs = rph + NS;     // effective temperature
-    double* vml = tobs + NS;     // vm per layer [MPREC]
+    double* enl = tobs + NS;     // exp(-t / 900 s) per node
+    double* tsl = enl + NS;      // node time in seconds
+    double* vml = tsl + NS;      // vm per layer [MPREC]
     const double* row = theta + b * ld;
 
     const double M0 = pow(10.0, apply_slot(P.model_param[0], row)) * msun;
@@ -2488,6 +2490,8 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
         tpw[j] = pow((td * day) / day, -1.3);
         lsum[j] = 0.0;
         rph[j] = 0.0;
+        tsl[j] = td * day;
+        enl[j] = exp(-(td * day) / 900.0);
     }
     // mass layers: m = geomspace(1e-8, M0/msun, 300)
     const double ls = log10(1e-8), le = log10(M0 / msun);
@@ -2498,6 +2502,9 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
         return pow(10.0, i * step + ls);
     };
     double mms[LPL], vm[LPL], xn0[LPL], xr[LPL], dmm[LPL], ene[LPL];
+    // per-layer factors of the time loop that do not depend on the time step (the loop then divides once per layer and
+    // step instead of five times: DESIGN.md section 8):  tdiff = kappa A / t,  tau = kappa Bt / t^2,  t vm / c = t Cv
+    double fa[LPL], fb[LPL], fc[LPL], krxr[LPL], omxr[LPL];
 #pragma unroll
     for (int q = 0; q < LPL; ++q) {
         const int i = lane + 64 * q;
@@ -2512,14 +2519,20 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
         dmm[q] = (mn - mi) * msun;
         ene[q] = 0.0;
         if (i < MPREC) vml[i] = v;
+        fa[q] = 0.08 * mms[q] * 3 / (v * c_cgs * beta);
+        fb[q] = mms[q] / (4 * kPi * (v * v));
+        fc[q] = v / c_cgs;
+        krxr[q] = kappa_r * xr[q];
+        omxr[q] = 1.0 - xr[q];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     for (int j = 0; j < NS - 1; ++j) {
-        const double t = P.st[j] * day, dt = P.st[j + 1] * day - t;
+        const double t = tsl[j], dt = tsl[j + 1] - t;
         const double edotr = 2.1e10 * eth[j] * tpw[j];
-        const double en = exp(-t / 900.0);
+        const double en = enl[j];
+        const double inv_t = 1.0 / t, inv_t2 = inv_t * inv_t;
         double part = 0.0, best = dinf();
         int besti = NL;
 #pragma unroll
@@ -2528,13 +2541,12 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
             if (i < NL) {
                 const double xn = xn0[q] * en;
                 const double edot = 3.2e14 * xn + edotr;
-                const double kappa = 0.4 * (1.0 - xn - xr[q]) + kappa_r * xr[q];
-                const double tdiff = 0.08 * kappa * mms[q] * 3 / (vm[q] * c_cgs * t * beta);
-                const double tv = t * vm[q];
-                const double tau = mms[q] * kappa / (4 * kPi * (tv * tv));
-                const double lum_j = ene[q] / (tdiff + t * (vm[q] / c_cgs));
+                const double kappa = 0.4 * (omxr[q] - xn) + krxr[q];
+                const double tdiff = (kappa * fa[q]) * inv_t;
+                const double tau = (kappa * fb[q]) * inv_t2;
+                const double lum_j = ene[q] / (tdiff + t * fc[q]);
                 part += lum_j * dmm[q];
-                ene[q] += dt * (edot - (ene[q] / t) - lum_j);
+                ene[q] += dt * (edot - (ene[q] * inv_t) - lum_j);
                 const double dtau = fabs(tau - 1);
                 if (dtau < best) { best = dtau; besti = i; }
             }
