@@ -370,6 +370,70 @@ def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     assert rel_err(got[~floor], gen[~floor]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_general_lean_task_random_feature_mixes(seed, torch_cuda, monkeypatch):
+    """Seeded random mixes of what the general lean task combines -- averaged bands or not, grid kind, systematics kind (budget /
+    em_syserr / time nodes on a random subset of the bands), extinction law, points per band (below and above the 16- and
+    32-point thresholds), upper limits -- against the oracle and against the task flavours that had these features before."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    rng = np.random.default_rng(7000 + seed)
+    averaged = bool((seed // 3) % 2)
+    sysk = ["budget", "param", "nodes"][int(rng.integers(0, 3))]
+    ext = ["none", "linear", "p92"][int(rng.integers(0, 3))]
+    grid = ["svd", "cli", "log"][seed % 3]
+    counts, n_new = int(rng.choice([7, 14, 23, 40, 70])), int(rng.choice([5, 12, 20, 45]))
+    names = list(AVG_NAMES)
+    if ext != "none":
+        names.append("Ebv")
+    n_nodes = int(rng.integers(2, 6))
+    node_names = [f"em_syserr_grp_{i}" for i in range(n_nodes)]
+    if sysk == "param":
+        names.append("em_syserr")
+    elif sysk == "nodes":
+        names += ["em_syserr_rest"] + node_names
+    if averaged:
+        case = cases.case_averaging(names=names, counts=counts, n_new=n_new)
+    else:
+        case = cases._base(seed=7100 + seed, filters=["g", "r", "i", "z", "y"], counts=counts, batch=32, names=names, upper_limit_filter="i")
+    obs = case["observed_filters"]
+    if sysk == "param":
+        case["systematics"] = dict(mode="param", name="em_syserr")
+    elif sysk == "nodes":
+        pick = [f for f in obs if rng.random() < 0.5] or [obs[0]]
+        nodes = {f: (node_names, np.linspace(0.3, 15.0, n_nodes)) for f in pick}
+        case["systematics"] = dict(mode="mixed", names={f: "em_syserr_rest" for f in obs if f not in nodes}, nodes=nodes)
+    else:
+        case["systematics"] = dict(mode="budget", values={f: float(rng.uniform(0.2, 1.0)) for f in obs})
+    if ext == "linear":
+        case["ebv_coeff"] = {f: float(rng.uniform(0.5, 4.0)) for f in case["model_filters"]}
+    elif ext == "p92":
+        case["filter_nu0"] = dict(zip(case["model_filters"], [2.99792458e14 / x for x in (0.48, 0.62, 0.75, 0.87, 0.96)]))
+    if ext != "none":
+        case["theta"][:2, names.index("Ebv")] = 0.0
+    if grid == "cli":
+        case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    elif grid == "log":
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    for k in ("NMMA_EM_NO_LEAN_AVG", "NMMA_EM_NO_LEAN_NODES"):
+        monkeypatch.setenv(k, "1")
+    eng = engine_from_case(case)
+    old = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    what = f"averaged={averaged} sys={sysk} ext={ext} grid={grid} counts={counts}/{n_new}"
+    assert np.array_equal(got == FLOOR, floor) and np.array_equal(old == FLOOR, floor), what
+    assert (~floor).sum() > 10 and rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL, what
+    assert rel_err(got[~floor], old[~floor]).max() <= 1e-9, what
+
+
 def test_lean_task_photometry_limits(torch_cuda):
     """The lean task keeps the photometry in LDS: up to ~2 400 points (BASELINE config 4's shape) it fits next to the ring,
     beyond that the handle falls back to the extended task -- same numbers either way (oracle spot check)."""
