@@ -117,6 +117,10 @@ def main():
     from tests.helpers import engine_from_case
 
     case = cases.case_c2_default()          # model + photometry of BASELINE config 2
+    if use_dist and not share_gpu and os.environ.get("NMMA_BENCH_BLOCKING") != "1":
+        # the collective of one step overlaps the kernel of the next: leave LDS on every CU for RCCL's kernels (a ring of 2 item
+        # slots instead of 4 costs the likelihood kernel 1.2 % and frees 57 KiB per CU)
+        os.environ.setdefault("NMMA_EM_RING", "2")
     eng = engine_from_case(case, device=local_rank)
     if args.scaling == "strong":
         from nmma_amd.parallel import shard_bounds

@@ -655,10 +655,13 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // Ring depth (items the MFMA role may run ahead): fast mode rings {partial sums, staged basis rows} per item and
 // takes as many slots (at most 4) as fit the 160 KiB of LDS, giving up the photometry staging before the last
 // slots; the generic path keeps 3 partial-sum buffers next to its double-buffered tables.
+// (ring_max: NMMA_EM_RING=<n>, read at nmma_em_create -- an upper bound on the ring depth: a shallower ring leaves LDS to kernels
+//  that share the CUs, e.g. RCCL's while a collective overlaps the likelihood)
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0) {
+                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
-    const int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
+    int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
+    if (want > ring_max) want = ring_max < 1 ? 1 : ring_max;
     LdsW L{};
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {

@@ -453,6 +453,29 @@ def test_lean_task_photometry_limits(torch_cuda):
         eng.close()
 
 
+@pytest.mark.parametrize("depth", ["2", "3"])
+def test_shallower_item_ring_gives_the_same_bits(depth, torch_cuda, monkeypatch):
+    """NMMA_EM_RING bounds the depth of the LDS ring of item slots (bench.py uses 2 when a collective overlaps the kernel, to
+    leave LDS to RCCL): fewer items in flight, same arithmetic -- bit-identical results."""
+    torch = torch_cuda
+    # (a band averaged from three model filters needs a ring of three: with two the handle takes the generic item phase)
+    for name in ("c2_default", "c2_dt05") + (("averaging",) if depth == "3" else ()):
+        case = cases.CASES[name]()
+        th = torch.as_tensor(case["theta"], device="cuda:0")
+        eng = engine_from_case(case)
+        ref = eng.loglike(th).cpu().numpy()
+        lds_ref = eng.last_launch_geometry()["lds_bytes"]
+        eng.close()
+        monkeypatch.setenv("NMMA_EM_RING", depth)
+        eng = engine_from_case(case)
+        got = eng.loglike(th).cpu().numpy()
+        eng.check()
+        assert eng.last_launch_geometry()["lds_bytes"] < lds_ref
+        eng.close()
+        monkeypatch.delenv("NMMA_EM_RING")
+        assert np.array_equal(got, ref), name
+
+
 def test_check_reports_clean_handle(torch_cuda):
     """nmma_em_check synchronises and finds no watchdog trip after ordinary launches."""
     torch = torch_cuda
