@@ -1752,6 +1752,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // TWO: pass 0 reconstructs the SVD rows around sample node lo, pass 1 those around node lo + 1.
         typedef const __attribute__((address_space(3))) int* lds_cip;
         double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
+        // a finite detection limit (uniform per band): the truncated Gaussian of em_likelihood.py:252-256 through detection_term,
+        // evaluated after the straight-line term like the upper limits -- a call per datum, on the lanes that hold a detection
+        const bool lim_fin = (it.lim - it.lim == 0.0);
+        double isig_[NSL], lsig_[NSL];
+        bool sbad_[NSL];
         const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter(s)
         const int svl = SYS ? __builtin_amdgcn_readfirstlane(P.sys_nn[o]) - 1 : 0;   // last node
         auto stage_q = [&]() {
@@ -1883,6 +1888,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             ul_[u] = valid_[u] & (isig == 0.0) & !sig_bad;    // infinite data error: an upper limit
             v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
             est_[u] = est; m_[u] = tm[1];
+            isig_[u] = isig; lsig_[u] = lsig; sbad_[u] = sig_bad;
+        }
+        if (lim_fin) {
+#pragma unroll
+            for (int u = 0; u < NSL; ++u)
+                if (valid_[u] & !ul_[u])
+                    v_[u] = sbad_[u] ? dnan() : detection_term(m_[u], inside_[u] ? est_[u] : dinf(), 1.0 / isig_[u], lsig_[u], it.lim);
         }
         gp_[0] = 0.0; gp_[1] = 0.0;
         if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit

