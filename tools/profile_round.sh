@@ -3,7 +3,7 @@
 # condensed by tools/summarize_profiles.py into the tracked profiles/<tag>_*:
 #   bench line (with cpu baselines)          -> <tag>/bench_line.json
 #   rocprofv3 --kernel-trace --stats         -> <tag>/stats_<what>/   for: bench (config 2, lean task), c2_dt05_limit @ 4096
-#                                               (extended task), c4_shape @ 8192 (config 4 shape), models (Me2017, combined,
+#                                               (general lean task; dt05ext: the same on the extended task), c4_shape @ 8192 (config 4 shape), models (Me2017, combined,
 #                                               em_fused outputs), bench with the opt-in in-wave kernel, gw (inner products)
 #   rocprofv3 --pmc (separate passes)        -> <tag>/pmc_<set>/      for the bench command
 # Under rocprofv3 the program goes directly after `--` (no env / bash -c hops).
@@ -14,6 +14,9 @@ export TMPDIR=/tmp
 python3 bench.py --steps 200 --warmup 20 > $o/bench_line.json 2> $o/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05 -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05.log 2>&1
+export NMMA_EM_NO_LEAN_LIM=1       # the same case on the extended task (em_logl<.., 2>), which had the finite limits before
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05ext -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05ext.log 2>&1
+unset NMMA_EM_NO_LEAN_LIM
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 tools/perf_gw.py 2048 > $o/stats_gw.log 2>&1

@@ -22,7 +22,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-for what in ("bench", "dt05", "c4", "models", "iw", "gw"):
+for what in ("bench", "dt05", "dt05ext", "c4", "models", "iw", "gw"):
     f = newest(os.path.join(src, f"stats_{what}", "**", "*kernel_stats.csv"))
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_{what}_kernel_stats.csv"))
@@ -67,7 +67,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(dst, f"{tag}_bench_line.json"))
-for name in ("stats_models.log", "stats_dt05.log", "stats_c4.log", "stats_gw.log"):
+for name in ("stats_models.log", "stats_dt05.log", "stats_dt05ext.log", "stats_c4.log", "stats_gw.log"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
