@@ -21,9 +21,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _base(seed=1234, model="Bu2019lm", filters=None, counts=None, batch=64, n_hidden=2048,
-          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0), n_coeff=10):
+          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0), n_coeff=10, tt=None):
     filters = list(filters or syn.AT2017GFO_FILTERS)
-    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden, n_coeff=n_coeff)
+    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden, n_coeff=n_coeff, tt=tt)
     grid = syn.flat_lcdm_grid(1.0, 200.0)
     data = syn.make_photometry(seed + 1, svd, mp, filters=filters, counts=counts,
                                cosmo_grid=grid, upper_limit_filter=upper_limit_filter,
@@ -114,12 +114,12 @@ def case_syserr_time_nodes():
     return c
 
 
-def case_averaging(names=None, counts=12, n_new=9):
+def case_averaging(names=None, counts=12, n_new=9, tt=None):
     """Observed filters the model does not provide (``w``, ``o``, ``I``): arithmetic mean
     of mapped model bands (em_likelihood.py:326-333), plus renamed ``B -> g``.
     (The keyword arguments make variants for the lean-task tests; the defaults are the golden case.)"""
     model_filters = ["g", "r", "i", "z", "y"]
-    c = _base(seed=5234, filters=model_filters, counts=counts, batch=32, upper_limit_filter="i", names=names)
+    c = _base(seed=5234, filters=model_filters, counts=counts, batch=32, upper_limit_filter="i", names=names, tt=tt)
     times, mags, sigmas = c["data"]
     rng = np.random.default_rng(99)
     for new, src in (("w", ["g", "r", "i"]), ("o", ["r", "i"]), ("I", ["z", "y"]), ("B", ["g"])):
@@ -365,6 +365,14 @@ def case_log_grid():
     return c
 
 
+def case_nonuniform_tt():
+    """An SVD model trained on an UNEQUALLY spaced time grid (geometric, as ``--tmin/--tmax`` training without ``--dt`` gives,
+    em/utils.py:87-88) evaluated on its own grid (``sample_times=None``): identity stage 1 on a non-uniform grid -- bisection
+    for the bracket, tabulated node spacings, and no stage-1 lerp (round-2 advisor finding: the non-uniform lean task read
+    stage-1 tables that were not staged for this combination)."""
+    return _base(seed=9934, batch=40, tt=np.geomspace(0.1, 21.0, 160))
+
+
 #: geometry cases: the reference runs all of them unchanged except the two extinction cases (its dust law is third-party),
 #: so they are golden cases too (tools/make_golden.py writes tests/golden/<name>.npz for every entry of CASES)
 SHAPE_CASES = {
@@ -378,6 +386,7 @@ SHAPE_CASES = {
     "extinction_linear": case_extinction_linear,
     "extinction_p92": case_extinction_p92,
     "log_grid": case_log_grid,
+    "nonuniform_tt": case_nonuniform_tt,
 }
 ORACLE_ONLY_CASES = ("extinction_limit", "extinction_linear", "extinction_p92")
 CASES.update({k: v for k, v in SHAPE_CASES.items() if k not in ORACLE_ONLY_CASES})

@@ -370,6 +370,60 @@ def test_averaged_bands_on_lean_task(variant, torch_cuda, monkeypatch):
     assert rel_err(got[~floor], gen[~floor]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("variant", ["plain", "em_syserr", "averaged", "averaged_p92", "time_nodes", "many_points", "limit"])
+def test_nonuniform_svd_grid_evaluated_on_itself(variant, torch_cuda, monkeypatch):
+    """An unequally spaced SVD grid with default sample_times (identity stage 1, non-uniform grid): the non-uniform lean tasks are
+    compiled two-stage and read the stage-1 tables, which therefore have to be staged for this combination too (round-2 advisor
+    finding).  Each lean flavour against the oracle and against the extended / generic tasks."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    tt = np.geomspace(0.1, 21.0, 160)
+    if variant == "em_syserr":
+        case = cases._base(seed=9935, batch=40, tt=tt, names=AVG_NAMES + ["em_syserr"])
+        case["systematics"] = dict(mode="param", name="em_syserr")
+    elif variant == "averaged":
+        case = cases.case_averaging(tt=tt)
+    elif variant == "averaged_p92":
+        case = cases.case_averaging(names=AVG_NAMES + ["Ebv"], tt=tt)
+        case["filter_nu0"] = dict(zip(case["model_filters"], [2.99792458e14 / x for x in (0.48, 0.62, 0.75, 0.87, 0.96)]))
+        case["theta"][:3, -1] = 0.0
+    elif variant == "time_nodes":
+        n_a = [f"em_syserr_grp_{i}" for i in range(4)]
+        case = cases._base(seed=9936, batch=40, tt=tt, names=AVG_NAMES + ["em_syserr_rest"] + n_a)
+        obs = case["observed_filters"]
+        nodes = {f: (n_a, np.linspace(0.3, 15.0, 4)) for f in obs[:3]}
+        case["systematics"] = dict(mode="mixed", names={f: "em_syserr_rest" for f in obs if f not in nodes}, nodes=nodes)
+    elif variant == "many_points":
+        case = cases._base(seed=9937, filters=["a", "b", "d"], counts=dict(a=40, b=75, d=9), batch=40, upper_limit_filter="b", tt=tt)
+    else:
+        case = cases._base(seed=9934, batch=40, tt=tt)
+    if variant == "limit":
+        case["detection_limit"] = {f: float(np.max(case["data"][1][f]) + 0.4) for f in case["observed_filters"]}
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    monkeypatch.setenv("NMMA_EM_TILE", "2")
+    eng = engine_from_case(case)
+    got32 = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    monkeypatch.delenv("NMMA_EM_TILE")
+    for k in ("NMMA_EM_NO_LEAN", "NMMA_EM_NO_LEAN_AVG"):
+        monkeypatch.setenv(k, "1")
+    eng = engine_from_case(case)
+    old = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and np.array_equal(old == FLOOR, floor) and np.array_equal(got32 == FLOOR, floor)
+    assert (~floor).sum() > 10 and rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    assert rel_err(got32[~floor], want[~floor]).max() <= LOGL_RTOL
+    assert rel_err(got[~floor], old[~floor]).max() <= 1e-9
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_general_lean_task_random_feature_mixes(seed, torch_cuda, monkeypatch):
     """Seeded random mixes of what the general lean task combines -- averaged bands or not, grid kind, systematics kind (budget /
