@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 2
+#define NMMA_ABI_VERSION 3
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -42,7 +42,8 @@ enum nmma_slot_op {
     NMMA_OP_LOG10 = 3,        /* v = log10(theta[col])         (model.py:279-280)            */
     NMMA_OP_POW10 = 4,        /* v = 10 ** theta[col]          (model.py:281-282)            */
     NMMA_OP_THETAJN2DEG = 5,  /* v = min(t, pi - t) * 180/pi   (conversion.py:120-123)       */
-    NMMA_OP_COSTHETAJN2DEG = 6 /* t = arccos(theta[col]) then as 5                           */
+    NMMA_OP_COSTHETAJN2DEG = 6, /* t = arccos(theta[col]) then as 5                          */
+    NMMA_OP_ACOS = 7          /* v = arccos(theta[col])        (a sampled cos_theta_jn, GW leg)  */
 };
 
 typedef struct nmma_slot {
@@ -228,6 +229,71 @@ int32_t nmma_lc_regrid(nmma_em_handle* h, const double* lc_src_dev, int32_t n_sr
  * bilby.gw.detector) stay with the caller; parity against bilby is unpinned (absent from the build image). */
 int32_t nmma_gw_loglike_ratio(const double* strain_dev, const double* data_dev, const double* weight_dev, int64_t B,
                               int32_t n_ifo, int64_t n_freq, double duration, double* out_dev, int32_t device, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GW term from PARAMETERS (BASELINE config 5): replaces B calls of
+ *   GravitationalWaveTransientLikelihood.log_likelihood (nmma/gw/gw_likelihood.py:97-247) ->
+ *   bilby.gw.likelihood.GravitationalWaveTransient.log_likelihood_ratio [+ noise_log_likelihood] (:185-203), i.e.
+ *   waveform_generator.frequency_domain_strain (bilby.gw.source.lal_binary_neutron_star, approximant
+ *   IMRPhenomD_NRTidalv2 or IMRPhenomD, aligned spins) -> Interferometer.get_detector_response (antenna pattern, arrival-time
+ *   shift) -> noise-weighted inner products -> sum over detectors, optionally marginalised over the coalescence phase (:164,
+ *   :174-178: phase_marginalization; time and distance marginalisation are refused).
+ * The strain is never materialised: one fused kernel evaluates the waveform per (frequency bin, sample) and reduces it.
+ * bilby / lalsimulation are absent from the build image: PARITY UNPINNED (oracle/gw_waveform_oracle.py restates the
+ * published algorithms). */
+#define NMMA_GW_MAX_IFO 4
+
+enum nmma_gw_mass_mode {
+    NMMA_GW_CHIRP_MASS_RATIO = 0,   /* mass_a = chirp_mass, mass_b = mass_ratio (bilby: convert_to_lal_binary_neutron_star_parameters) */
+    NMMA_GW_COMPONENT_MASSES = 1    /* mass_a = mass_1, mass_b = mass_2 */
+};
+
+typedef struct nmma_gw_config {
+    int32_t abi_version;          /* NMMA_ABI_VERSION */
+    int32_t device;
+    int32_t n_ifo;                /* <= NMMA_GW_MAX_IFO */
+    int32_t tidal;                /* 1: IMRPhenomD_NRTidalv2, 0: IMRPhenomD */
+    int64_t n_freq;               /* bins of the one-sided frequency array f_k = k / duration, k = 0 .. n_freq-1 */
+    double duration;              /* strain_data.duration [s] */
+    double start_time;            /* strain_data.start_time [GPS s] */
+    const double* data;           /* [n_ifo][n_freq][2] frequency_domain_strain (re, im) */
+    const double* psd;            /* [n_ifo][n_freq]    power_spectral_density_array */
+    const uint8_t* mask;          /* [n_ifo][n_freq]    frequency_mask */
+    const double* detector_tensor;/* [n_ifo][9] */
+    const double* vertex;         /* [n_ifo][3] metres, geocentric */
+    double gmst_ref_time;         /* GMST is linearised about this GPS time: gmst(t) = gmst_ref + gmst_rate (t - ref) */
+    double gmst_ref;
+    double gmst_rate;
+    double reference_frequency;   /* waveform_arguments["reference_frequency"] */
+    double waveform_minimum_frequency;   /* waveform_arguments["minimum_frequency"]: zero strain below */
+    double waveform_maximum_frequency;   /* ... ["maximum_frequency"] (+inf if absent) */
+    int32_t phase_marginalization;
+    int32_t mass_mode;            /* enum nmma_gw_mass_mode */
+    int32_t n_dim;                /* columns of theta */
+    nmma_slot mass_a, mass_b, chi_1, chi_2, lambda_1, lambda_2, luminosity_distance, theta_jn, phase, ra, dec, psi, geocent_time;
+} nmma_gw_config;
+
+typedef struct nmma_gw_handle nmma_gw_handle;
+
+int32_t nmma_gw_create(const nmma_gw_config* cfg, nmma_gw_handle** out);
+void nmma_gw_destroy(nmma_gw_handle* h);
+
+/* out_dev[b] = log-likelihood RATIO of theta row b (add nmma_gw_noise_log_likelihood for log L); rows with non-finite or
+ * unphysical parameters get NMMA_LOGL_FLOOR.  Asynchronous on `stream`. */
+int32_t nmma_gw_loglike(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* out_dev, void* stream);
+double nmma_gw_noise_log_likelihood(const nmma_gw_handle* h);
+
+/* The projected strain itself, strain_dev[B][n_ifo][n_freq][2] (zero outside the evaluated band): for parity tests and
+ * plots, not on the sampler's path. */
+int32_t nmma_gw_strain(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* strain_dev, void* stream);
+
+/* <d|h> (re, im) and <h|h> per row: parts_dev[B][3], before the marginalisation / combination step. */
+int32_t nmma_gw_inner_products(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* parts_dev, void* stream);
+
+/* Introspection: bins inside the evaluated band, and HIP-event timing of the fused kernel on the launch stream. */
+int64_t nmma_gw_n_bins(const nmma_gw_handle* h);
+int32_t nmma_gw_profile_begin(nmma_gw_handle* h, int32_t max_launches);
+int32_t nmma_gw_profile_end(nmma_gw_handle* h, double* kernel_ms_total, int32_t* n_launches);
 
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,

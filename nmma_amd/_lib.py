@@ -13,14 +13,18 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMMA_HIP_LIB") or os.path.join(_HERE, "libnmma_hip.so")   # env: experiment builds
 SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
+#: translation units of the library; every other file under csrc/ and include/ is a dependency of both
+SOURCES = ("em_kernels.hip", "gw_kernels.hip")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
 LOGL_FLOOR = -1.7976931348623157e308
 
-OP_IDENT, OP_RAD2DEG, OP_DEG2RAD, OP_LOG10, OP_POW10, OP_THETAJN2DEG, OP_COSTHETAJN2DEG = range(7)
+OP_IDENT, OP_RAD2DEG, OP_DEG2RAD, OP_LOG10, OP_POW10, OP_THETAJN2DEG, OP_COSTHETAJN2DEG, OP_ACOS = range(8)
+GW_MAX_IFO = 4
+GW_CHIRP_MASS_RATIO, GW_COMPONENT_MASSES = range(2)
 Z_ZERO, Z_SLOT, Z_GRID = range(3)
 SYS_CONST, SYS_PARAM, SYS_NODES = range(3)
 MODEL_SVD, MODEL_ME2017, MODEL_EXTERNAL = range(3)
@@ -72,6 +76,22 @@ class EmConfig(C.Structure):
     ]
 
 
+class GwConfig(C.Structure):
+    """Mirror of ``struct nmma_gw_config`` (field order must match the header)."""
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("n_ifo", C.c_int32), ("tidal", C.c_int32),
+        ("n_freq", C.c_int64), ("duration", C.c_double), ("start_time", C.c_double),
+        ("data", _pd), ("psd", _pd), ("mask", C.POINTER(C.c_uint8)), ("detector_tensor", _pd), ("vertex", _pd),
+        ("gmst_ref_time", C.c_double), ("gmst_ref", C.c_double), ("gmst_rate", C.c_double),
+        ("reference_frequency", C.c_double), ("waveform_minimum_frequency", C.c_double),
+        ("waveform_maximum_frequency", C.c_double),
+        ("phase_marginalization", C.c_int32), ("mass_mode", C.c_int32), ("n_dim", C.c_int32),
+        ("mass_a", Slot), ("mass_b", Slot), ("chi_1", Slot), ("chi_2", Slot), ("lambda_1", Slot), ("lambda_2", Slot),
+        ("luminosity_distance", Slot), ("theta_jn", Slot), ("phase", Slot), ("ra", Slot), ("dec", Slot), ("psi", Slot),
+        ("geocent_time", Slot),
+    ]
+
+
 #: name -> (restype, argtypes); every symbol ``include/nmma_hip.h`` declares
 PROTOTYPES = {
     "nmma_abi_version": (C.c_int32, []),
@@ -93,6 +113,15 @@ PROTOTYPES = {
                                    C.c_void_p]),
     "nmma_gw_loglike_ratio": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double,
                                          C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
+    "nmma_gw_destroy": (None, [C.c_void_p]),
+    "nmma_gw_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_gw_noise_log_likelihood": (C.c_double, [C.c_void_p]),
+    "nmma_gw_strain": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_gw_inner_products": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_gw_n_bins": (C.c_int64, [C.c_void_p]),
+    "nmma_gw_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "nmma_gw_profile_end": (C.c_int32, [C.c_void_p, _pd, _pi]),
     "nmma_em_coefficients": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
     "nmma_em_check": (C.c_int32, [C.c_void_p]),
@@ -108,18 +137,42 @@ PROTOTYPES = {
 _lib = None
 
 
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-comment"]
+
+
+def _dependencies():
+    """Every file a translation unit may include: all of csrc/ (sources, .inc, .h) and the public header."""
+    csrc = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".inc"))]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "nmma_hip.h"))
+    return deps
+
+
 def build_library(force=False, extra_flags=()):
-    """Compile ``csrc/em_kernels.hip`` for gfx950 into ``libnmma_hip.so`` (in-tree)."""
-    srcs = [SRC_PATH] + [os.path.join(_HERE, "csrc", f) for f in ("em_api.inc", "em_math.h", "em_device.h")]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "nmma_hip.h"))
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
-        return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-shared", "-Wno-comment", SRC_PATH, "-o", LIB_PATH, *extra_flags]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise NMMAHipError("hipcc failed:\n" + proc.stderr[-4000:])
+    """Compile the translation units under ``csrc/`` for gfx950 and link them into ``libnmma_hip.so`` (in-tree).
+    A unit is recompiled when it or ANY header / .inc under ``csrc/`` or ``include/`` is newer than its object."""
+    csrc = os.path.join(_HERE, "csrc")
+    objdir = os.path.join(csrc, "build")
+    os.makedirs(objdir, exist_ok=True)
+    deps_mtime = max(os.path.getmtime(d) for d in _dependencies())
+    objs, procs, rebuilt = [], [], False
+    for name in SOURCES:
+        src = os.path.join(csrc, name)
+        obj = os.path.join(objdir, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or extra_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps_mtime):
+            procs.append((name, subprocess.Popen(["hipcc", *HIPCC_FLAGS, "-c", src, "-o", obj, *extra_flags],
+                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+            rebuilt = True
+    for name, proc in procs:      # (the units compile concurrently)
+        _, err = proc.communicate()
+        if proc.returncode != 0:
+            raise NMMAHipError(f"hipcc failed on {name}:\n" + err[-4000:])
+    if rebuilt or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs):
+        proc = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH],
+                              capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise NMMAHipError("hipcc link failed:\n" + proc.stderr[-4000:])
     return LIB_PATH
 
 

@@ -192,3 +192,101 @@ def convert_mtot_mni(params):
     params["mni_c"] = params["mni"] / params["mtot"]
     params["mrp_c"] = params["xmix"] * (params["mtot"] - params["mni"]) - params["mrp"]
     return params
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compact-binary conversions of the GW messenger (reference core/conversion.py:104-173; bilby/gw/conversion.py)
+# All of them work on floats and on columns (numpy arrays) alike.
+# ---------------------------------------------------------------------------------------------------------------------
+def tidal_deformabilities_and_mass_ratio_to_eff_tidal_deformabilities(lambda1, lambda2, q):
+    """(lambda_tilde, delta_lambda_tilde) from the component deformabilities (reference :164-173)."""
+    eta = q / np.power(1. + q, 2.)
+    eta2, eta3 = eta * eta, eta * eta * eta
+    root14eta = np.sqrt(1. - 4 * eta)
+    lam_t = (8. / 13.) * ((1. + 7 * eta - 31 * eta2) * (lambda1 + lambda2)
+                          + root14eta * (1. + 9 * eta - 11. * eta2) * (lambda1 - lambda2))
+    dlam_t = 0.5 * (root14eta * (1. - 13272. * eta / 1319. + 8944. * eta2 / 1319.) * (lambda1 + lambda2)
+                    + (1. - 15910. * eta / 1319. + 32850. * eta2 / 1319. + 3380. * eta3 / 1319.) * (lambda1 - lambda2))
+    return lam_t, dlam_t
+
+
+def generate_mass_parameters(p):
+    """Whatever two mass parameters are present -> mass_1, mass_2, total_mass, chirp_mass, mass_ratio,
+    symmetric_mass_ratio (bilby: generate_mass_parameters / generate_component_masses)."""
+    if "mass_1" not in p or "mass_2" not in p:
+        if "chirp_mass" in p and "mass_ratio" in p:
+            q = p["mass_ratio"]
+            total = p["chirp_mass"] * (1 + q) ** 1.2 / q ** 0.6
+            p["mass_1"] = total / (1 + q)
+            p["mass_2"] = p["mass_1"] * q
+        elif "chirp_mass" in p and "symmetric_mass_ratio" in p:
+            eta = np.minimum(p["symmetric_mass_ratio"], 0.25)
+            q = (1 - 2 * eta - np.sqrt(np.maximum(1 - 4 * eta, 0.0))) / (2 * eta)
+            total = p["chirp_mass"] / eta ** 0.6
+            p["mass_1"] = total / (1 + q)
+            p["mass_2"] = p["mass_1"] * q
+        elif "total_mass" in p and "mass_ratio" in p:
+            p["mass_1"] = p["total_mass"] / (1 + p["mass_ratio"])
+            p["mass_2"] = p["mass_1"] * p["mass_ratio"]
+        elif "mass_1" in p and "mass_ratio" in p:
+            p["mass_2"] = p["mass_1"] * p["mass_ratio"]
+        elif "mass_2" in p and "mass_ratio" in p:
+            p["mass_1"] = p["mass_2"] / p["mass_ratio"]
+        else:
+            return p
+    m1, m2 = p["mass_1"], p["mass_2"]
+    p.setdefault("total_mass", m1 + m2)
+    p.setdefault("mass_ratio", m2 / m1)
+    p.setdefault("symmetric_mass_ratio", m1 * m2 / (m1 + m2) ** 2)
+    p.setdefault("chirp_mass", (m1 * m2) ** 0.6 / (m1 + m2) ** 0.2)
+    return p
+
+
+def _aligned_spin_conversion(p):
+    """chi_i -> (a_i, cos_tilt_i) and cos_theta_jn -> theta_jn, as convert_to_lal_binary_black_hole_parameters does for
+    the aligned-spin parametrisation."""
+    for idx in ("1", "2"):
+        key = f"chi_{idx}"
+        if key in p:
+            p.setdefault(f"a_{idx}", np.abs(p[key]))
+            p.setdefault(f"cos_tilt_{idx}", np.sign(p[key]))
+    if "cos_theta_jn" in p and "theta_jn" not in p:
+        p["theta_jn"] = np.arccos(p["cos_theta_jn"])
+    return p
+
+
+def source_frame_masses(p, cosmology=None):
+    """Reference :104-117: mass parameters, the redshift of the luminosity distance when none is given, source-frame masses."""
+    p = generate_mass_parameters(p)
+    if "redshift" not in p and "luminosity_distance" in p:
+        p["redshift"] = luminosity_distance_to_redshift(p["luminosity_distance"], cosmology)
+    if "redshift" in p and "mass_1" in p:
+        z = p["redshift"]
+        p.setdefault("mass_1_source", np.array(p["mass_1"] / (1 + z)))
+        p.setdefault("mass_2_source", np.array(p["mass_2"] / (1 + z)))
+    return p
+
+
+def bbh_source_frame(params):
+    """Reference :131-134 (bilby's convert_to_lal_binary_black_hole_parameters for aligned spins, then source_frame_masses)."""
+    return source_frame_masses(_aligned_spin_conversion(dict(params)))
+
+
+def bns_source_frame(params):
+    """Reference :136-139: the black-hole conversion plus the tidal parameters -- (lambda_tilde, delta_lambda_tilde) are
+    turned into component deformabilities when those are what is sampled (bilby:
+    lambda_tilde_delta_lambda_tilde_to_lambda_1_lambda_2)."""
+    p = source_frame_masses(_aligned_spin_conversion(dict(params)))
+    if "lambda_1" not in p and "lambda_tilde" in p and "mass_1" in p:
+        eta = p["symmetric_mass_ratio"]
+        lt, dlt = p["lambda_tilde"], p.get("delta_lambda_tilde", 0.0)
+        root = np.sqrt(np.maximum(1 - 4 * eta, 0.0))
+        a = (8 / 13) * (1 + 7 * eta - 31 * eta ** 2)
+        b = (8 / 13) * root * (1 + 9 * eta - 11 * eta ** 2)
+        c = 0.5 * root * (1 - 13272 / 1319 * eta + 8944 / 1319 * eta ** 2)
+        d = 0.5 * (1 - 15910 / 1319 * eta + 32850 / 1319 * eta ** 2 + 3380 / 1319 * eta ** 3)
+        # [lt, dlt] = [[a, b], [c, d]] [lambda_1 + lambda_2, lambda_1 - lambda_2]
+        det = a * d - b * c
+        s, dl = (d * lt - b * dlt) / det, (-c * lt + a * dlt) / det
+        p["lambda_1"], p["lambda_2"] = 0.5 * (s + dl), 0.5 * (s - dl)
+    return p

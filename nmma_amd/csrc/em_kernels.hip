@@ -41,6 +41,7 @@
 
 #include "em_device.h"
 #include "em_math.h"
+#include "nmma_common.h"
 
 namespace nmma {
 
@@ -2687,5 +2688,4 @@ __global__ __launch_bounds__(256) void ext_prepass_kernel(const EmDev* __restric
 }  // namespace nmma
 
 #include "em_logl_iw.inc"
-#include "gw_kernels.inc"
 #include "em_api.inc"

@@ -18,7 +18,7 @@
 #define NM_HD __host__ __device__ __forceinline__
 // rarely-taken, transcendental-heavy paths: keep them out of line so they do not
 // inflate the register budget of the MFMA loop they share a kernel with
-#define NM_HD_COLD __host__ __device__ __noinline__
+#define NM_HD_COLD inline __host__ __device__ __noinline__
 #else
 #define NM_HD inline
 #define NM_HD_COLD inline
@@ -44,6 +44,7 @@ NM_HD_COLD double apply_slot_op(double v, int op) {
         case NMMA_OP_POW10: return pow(10.0, v);
         case NMMA_OP_THETAJN2DEG: { const double t = fmin(v, kPi - v); return t * 180.0 / kPi; }
         case NMMA_OP_COSTHETAJN2DEG: { double t = acos(v); t = fmin(t, kPi - t); return t * 180.0 / kPi; }
+        case NMMA_OP_ACOS: return acos(v);
         default: return v;
     }
 }

@@ -1,0 +1,585 @@
+// gw_kernels.hip -- gfx950 kernels and host API of the gravitational-wave leg of the joint likelihood
+// (BASELINE config 5).  Second translation unit of libnmma_hip.so.
+//
+// Reference path (third-party arithmetic, see gw_math.h): nmma/gw/gw_likelihood.py:97-247 ->
+//   bilby.gw.likelihood.GravitationalWaveTransient.log_likelihood_ratio:
+//     waveform_generator.frequency_domain_strain(theta)         lalsimulation IMRPhenomD_NRTidalv2 on the full frequency array
+//     for each interferometer: get_detector_response            F+ h+ + Fx hx, time shift to the detector
+//                              <d|h>, <h|h>                      4/T sum conj(a) b / S over the frequency mask
+//     sum_ifo Re<d|h> - <h|h>/2   (or ln I0(|<d|h>|) - <h|h>/2 with phase marginalisation)
+// i.e. per sample ~n_freq x (waveform + n_ifo projections) -- 2.6e5 bins x 3 detectors for a 128 s segment sampled at 4096 Hz.
+//
+// Here: the strain is never written.
+//   gw_source_kernel   one thread per sample: theta row -> GwSource record (all frequency-independent quantities: Table V fits,
+//                      PN coefficients folded with the total mass, connection coefficients, tidal constants, per-detector antenna
+//                      factor and arrival time).  Heavy scalar code, run once per sample.
+//   gw_logl_kernel     the hot loop.  A 256-thread workgroup owns a chunk of GW_CHUNK consecutive bins and a group of GW_GROUP
+//                      samples; lanes map to consecutive bins (coalesced 32-byte loads of the per-bin basis and of the
+//                      pre-weighted data, which stay L2-resident: sample groups are the fast grid index, so the workgroups in
+//                      flight share a handful of chunks), the sample's record is uniform across the workgroup and is read
+//                      through the scalar cache.  Two samples are evaluated per pass over the chunk (the bin loads are shared),
+//                      per-lane partial sums are reduced with DPP and leave through LDS in a fixed order.
+//   gw_finish_kernel   sums the chunk partials in chunk order (the order does not depend on the batch size), applies 4/T,
+//                      the phase marginalisation and the floor.
+// Roofline: fp64 vector FMA (78.6 TFLOP/s); algorithmic flops per (bin, sample) are counted in DESIGN section 3.5.
+//
+// Also here: gw_loglike_ratio_kernel, the HBM-streaming reduction for strain supplied by the caller (round 2).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "em_math.h"
+#include "gw_math.h"
+#include "nmma_common.h"
+
+namespace nmma {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double gw_dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes of a wave; the total lands in the LAST row (lanes 48..63)
+__device__ __forceinline__ double gw_wave_sum(double v) {
+    v += gw_dpp_mov_f64<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v += gw_dpp_mov_f64<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v += gw_dpp_mov_f64<0x141, 0xf>(v);    // row_half_mirror
+    v += gw_dpp_mov_f64<0x140, 0xf>(v);    // row_mirror: every lane holds its row's sum
+    v += gw_dpp_mov_f64<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3
+    v += gw_dpp_mov_f64<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// =======================================================================================
+// strain supplied by the caller (round 2): one pass over strain[B][n_ifo * n_freq]
+// =======================================================================================
+constexpr int GW_THREADS = 1024;
+
+template <int GW_SAMPLES>
+__global__ __launch_bounds__(GW_THREADS) void gw_loglike_ratio_kernel(
+    const double2* __restrict__ strain,      // [B][n_ifo * n_freq]
+    const double2* __restrict__ data,        // [n_ifo * n_freq]
+    const double* __restrict__ weight,       // [n_ifo * n_freq]  = mask_f / S_f
+    const long B, const long n, const double four_over_T, double* __restrict__ out) {
+    __shared__ double wsum[GW_SAMPLES][GW_THREADS / 64];
+    typedef double f64x2v __attribute__((ext_vector_type(2)));
+    const long b0 = (long)blockIdx.x * GW_SAMPLES;
+    const f64x2v* h[GW_SAMPLES];
+#pragma unroll
+    for (int q = 0; q < GW_SAMPLES; ++q) {
+        const long b = b0 + q < B ? b0 + q : B - 1;      // (a sample beyond the batch re-reads the last one; nothing is stored)
+        h[q] = reinterpret_cast<const f64x2v*>(strain + b * n);
+    }
+    double acc[GW_SAMPLES][2];
+#pragma unroll
+    for (int q = 0; q < GW_SAMPLES; ++q) { acc[q][0] = 0.0; acc[q][1] = 0.0; }
+    auto term = [&](const f64x2v hv, const double2 dv, const double w) -> double {
+        const double dh = dv.x * hv[0] + dv.y * hv[1];
+        const double hh = hv[0] * hv[0] + hv[1] * hv[1];
+        return (dh - hh / 2.0) * w;
+    };
+    long i = threadIdx.x;
+    for (; i + GW_THREADS < n; i += 2 * GW_THREADS) {
+        f64x2v hv[GW_SAMPLES][2];
+#pragma unroll
+        for (int q = 0; q < GW_SAMPLES; ++q) {
+            hv[q][0] = __builtin_nontemporal_load(h[q] + i);
+            hv[q][1] = __builtin_nontemporal_load(h[q] + i + GW_THREADS);
+        }
+        const double2 d0 = data[i], d1 = data[i + GW_THREADS];
+        const double w0 = weight[i], w1 = weight[i + GW_THREADS];
+#pragma unroll
+        for (int q = 0; q < GW_SAMPLES; ++q) { acc[q][0] += term(hv[q][0], d0, w0); acc[q][1] += term(hv[q][1], d1, w1); }
+    }
+    for (; i < n; i += GW_THREADS) {
+        const double2 d0 = data[i];
+        const double w0 = weight[i];
+#pragma unroll
+        for (int q = 0; q < GW_SAMPLES; ++q) acc[q][0] += term(__builtin_nontemporal_load(h[q] + i), d0, w0);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < GW_SAMPLES; ++q) {
+        const double a = gw_wave_sum(acc[q][0] + acc[q][1]);
+        if (lane == 63) wsum[q][wave] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < GW_SAMPLES && b0 + threadIdx.x < B) {
+        double s = 0.0;
+        for (int w = 0; w < GW_THREADS / 64; ++w) s += wsum[threadIdx.x][w];
+        out[b0 + threadIdx.x] = four_over_T * s;
+    }
+}
+
+// =======================================================================================
+// GW log-likelihood from parameters
+// =======================================================================================
+constexpr int GWL_THREADS = 256;
+constexpr int GWL_WAVES = GWL_THREADS / 64;
+constexpr int GW_CHUNK_ITERS = 8;                         // passes of 256 bins per chunk
+constexpr int GW_CHUNK = GWL_THREADS * GW_CHUNK_ITERS;    // 2048 bins
+constexpr int GW_GROUP = 16;                              // samples per workgroup
+
+struct GwDev {
+    int32_t n_ifo, tidal, mass_mode, phase_marg;
+    int64_t n_bins;                // bins k0 .. k0 + n_bins - 1 of the frequency array
+    int64_t k0, n_freq;
+    int32_t n_chunks, n_dim;
+    double df, f_ref, start_time, gmst_ref_time, gmst_ref, gmst_rate, four_over_T;
+    const double4* basis;          // [n_bins] {f13, 1/f13, ln f13, f^(-7/6)}
+    const double4* dat;            // [n_ifo][n_bins] {w d_re, w d_im, w, 0},  w = mask / S
+    gw::GwDetector det[gw::kMaxIfo];
+    nmma_slot mass_a, mass_b, chi_1, chi_2, lambda_1, lambda_2, luminosity_distance, theta_jn, phase, ra, dec, psi, geocent_time;
+};
+
+__global__ __launch_bounds__(64) void gw_source_kernel(const GwDev* __restrict__ Pp, const double* __restrict__ theta, const long B,
+                                                       const long ld, gw::GwSource* __restrict__ src) {
+    const GwDev& P = *Pp;
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* row = theta + b * ld;
+    gw::GwParams q;
+    const double ma = apply_slot(P.mass_a, row), mb = apply_slot(P.mass_b, row);
+    if (P.mass_mode == NMMA_GW_CHIRP_MASS_RATIO) {
+        // bilby/gw/conversion.py: chirp_mass_and_mass_ratio_to_total_mass, total_mass_and_mass_ratio_to_component_masses
+        const double total = ma * pow(1.0 + mb, 1.2) / pow(mb, 0.6);
+        q.mass_1 = total / (1.0 + mb);
+        q.mass_2 = q.mass_1 * mb;
+    } else {
+        q.mass_1 = ma; q.mass_2 = mb;
+    }
+    q.chi_1 = apply_slot(P.chi_1, row); q.chi_2 = apply_slot(P.chi_2, row);
+    q.lambda_1 = apply_slot(P.lambda_1, row); q.lambda_2 = apply_slot(P.lambda_2, row);
+    q.luminosity_distance = apply_slot(P.luminosity_distance, row);
+    q.theta_jn = apply_slot(P.theta_jn, row); q.phase = apply_slot(P.phase, row);
+    q.ra = apply_slot(P.ra, row); q.dec = apply_slot(P.dec, row); q.psi = apply_slot(P.psi, row);
+    q.geocent_time = apply_slot(P.geocent_time, row);
+    gw::GwSource S;
+    for (int i = 0; i < gw::kMaxIfo; ++i) { S.k_re[i] = 0.0; S.k_im[i] = 0.0; S.k_sq[i] = 0.0; S.dt[i] = 0.0; }
+    gw::setup_source(q, P.f_ref, P.tidal != 0, S);
+    if (S.valid != 0.0)
+        for (int i = 0; i < P.n_ifo; ++i) gw::project_source(q, P.det[i], i, P.start_time, P.gmst_ref_time, P.gmst_ref, P.gmst_rate, S);
+    src[b] = S;
+}
+
+// One (bin, sample): amplitude and phase of the waveform, then every detector's term.
+//   h_ifo = K A exp(-i pi (ph + 2 f dt)),  <d|h> += w conj(d) h,  <h|h> += w |K|^2 A^2
+template <int NIFO, bool PM>
+__device__ __forceinline__ void gw_bin_sample(const gw::GwSource& S, const gw::GwBin& bin, const double4 (&dat)[NIFO], double& a_re,
+                                              double& a_im, double& a_hh) {
+    double amp, ph;
+    gw::eval_bin(S, bin, amp, ph);
+    double re = 0.0, im = 0.0, hh = 0.0;
+#pragma unroll
+    for (int i = 0; i < NIFO; ++i) {
+        // theta / pi = -(ph + 2 f dt): reduce to [-1, 1] exactly before sincospi
+        double t = -(ph + 2.0 * bin.f * S.dt[i]);
+        t -= 2.0 * rint(0.5 * t);
+        double sn, cs;
+        sincospi(t, &sn, &cs);
+        const double zr = dat[i].x * cs + dat[i].y * sn;     // conj(w d) e^{i theta}
+        const double zi = dat[i].x * sn - dat[i].y * cs;
+        re += S.k_re[i] * zr - S.k_im[i] * zi;
+        if (PM) im += S.k_re[i] * zi + S.k_im[i] * zr;
+        hh += dat[i].z * S.k_sq[i];
+    }
+    a_re += amp * re;
+    if (PM) a_im += amp * im;
+    a_hh += amp * amp * hh;
+}
+
+template <int NIFO, bool PM>
+__global__ __launch_bounds__(GWL_THREADS) void gw_logl_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                              const long B, double* __restrict__ partial) {
+    const GwDev& P = *Pp;
+    __shared__ double red[GW_GROUP][GWL_WAVES][3];
+    const long n_groups = (B + GW_GROUP - 1) / GW_GROUP;
+    const long g = (long)blockIdx.x % n_groups;       // sample group: the fast index (workgroups in flight share chunks)
+    const long c = (long)blockIdx.x / n_groups;       // chunk
+    const long b0 = g * GW_GROUP;
+    const long bin0 = c * GW_CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double4* __restrict__ basis = P.basis;
+    const double4* __restrict__ dat = P.dat;
+    const long nb = P.n_bins;
+    for (int s2 = 0; s2 < GW_GROUP; s2 += 2) {
+        // (a sample beyond the batch re-evaluates the last one; nothing of it is stored)
+        const long ba = b0 + s2 < B ? b0 + s2 : B - 1;
+        const long bb = b0 + s2 + 1 < B ? b0 + s2 + 1 : B - 1;
+        const gw::GwSource& Sa = src[ba];
+        const gw::GwSource& Sb = src[bb];
+        double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        const bool va = Sa.valid != 0.0, vb = Sb.valid != 0.0;
+        for (int j = 0; j < GW_CHUNK_ITERS; ++j) {
+            const long i = bin0 + (long)j * GWL_THREADS + threadIdx.x;
+            if (i < nb) {
+                const double4 bs = basis[i];
+                gw::GwBin bin;
+                bin.f = (double)(P.k0 + i) * P.df;
+                bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
+                double4 d[NIFO];
+#pragma unroll
+                for (int k = 0; k < NIFO; ++k) d[k] = dat[(long)k * nb + i];
+                if (va) gw_bin_sample<NIFO, PM>(Sa, bin, d, acc[0][0], acc[0][1], acc[0][2]);
+                if (vb) gw_bin_sample<NIFO, PM>(Sb, bin, d, acc[1][0], acc[1][1], acc[1][2]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k == 1 && !PM) continue;
+                const double t = gw_wave_sum(acc[q][k]);
+                if (lane == 63) red[s2 + q][wave][k] = t;
+            }
+    }
+    __syncthreads();
+    // partial[(c * 3 + k) * B + b]: waves summed in wave order
+    for (int t = threadIdx.x; t < GW_GROUP * 3; t += GWL_THREADS) {
+        const int s = t / 3, k = t - 3 * s;
+        if (b0 + s < B) {
+            double v = 0.0;
+            if (k != 1 || PM)
+                for (int w = 0; w < GWL_WAVES; ++w) v += red[s][w][k];
+            partial[((long)c * 3 + k) * B + b0 + s] = v;
+        }
+    }
+}
+
+// mode 0: log-likelihood ratio (floor for invalid / non-finite); mode 1: the three inner products parts[b][3]
+__global__ __launch_bounds__(256) void gw_finish_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                        const double* __restrict__ partial, const long B, const int mode,
+                                                        double* __restrict__ out) {
+    const GwDev& P = *Pp;
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double re = 0.0, im = 0.0, hh = 0.0;
+    for (int c = 0; c < P.n_chunks; ++c) {
+        re += partial[((long)c * 3 + 0) * B + b];
+        im += partial[((long)c * 3 + 1) * B + b];
+        hh += partial[((long)c * 3 + 2) * B + b];
+    }
+    re *= P.four_over_T; im *= P.four_over_T; hh *= P.four_over_T;
+    const bool valid = src[b].valid != 0.0;
+    if (mode == 1) {
+        out[3 * b + 0] = valid ? re : dnan();
+        out[3 * b + 1] = valid ? im : dnan();
+        out[3 * b + 2] = valid ? hh : dnan();
+        return;
+    }
+    double r;
+    if (P.phase_marg) r = gw::ln_bessel_i0(sqrt(re * re + im * im)) - hh / 2.0;      // bilby: ln_i0(abs(d_inner_h)) - optimal_snr_squared / 2
+    else r = re - hh / 2.0;
+    out[b] = (valid && isfinite(r)) ? r : NMMA_LOGL_FLOOR;                            // core/base.py:82, :181
+}
+
+template <int NIFO>
+__global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src, const long B,
+                                                        double2* __restrict__ strain) {
+    const GwDev& P = *Pp;
+    const long b = blockIdx.y;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;     // bin of the full frequency array
+    if (k >= P.n_freq) return;
+    const gw::GwSource& S = src[b];
+    const long i = k - P.k0;
+    double amp = 0.0, ph = 0.0;
+    gw::GwBin bin;
+    bin.f = (double)k * P.df;
+    const bool in_band = i >= 0 && i < P.n_bins && S.valid != 0.0;
+    if (in_band) {
+        const double4 bs = P.basis[i];
+        bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
+        gw::eval_bin(S, bin, amp, ph);
+    }
+#pragma unroll
+    for (int d = 0; d < NIFO; ++d) {
+        double2 h = make_double2(0.0, 0.0);
+        // (zero where the detector's own mask is zero, like bilby's get_detector_response)
+        if (in_band && P.dat[(long)d * P.n_bins + i].z != 0.0) {
+            double t = -(ph + 2.0 * bin.f * S.dt[d]);
+            t -= 2.0 * rint(0.5 * t);
+            double sn, cs;
+            sincospi(t, &sn, &cs);
+            h.x = amp * (S.k_re[d] * cs - S.k_im[d] * sn);
+            h.y = amp * (S.k_re[d] * sn + S.k_im[d] * cs);
+        }
+        strain[((long)b * NIFO + d) * P.n_freq + k] = h;
+    }
+}
+
+}  // namespace nmma
+
+// =======================================================================================
+// host API
+// =======================================================================================
+using nmma::fail;
+
+#define GW_HIP(call)                                                                                              \
+    do {                                                                                                          \
+        hipError_t _e = (call);                                                                                   \
+        if (_e != hipSuccess) return fail(std::string(#call) + " failed: " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct nmma_gw_handle {
+    nmma::GwDev dev{};
+    nmma::GwDev* dev_d = nullptr;
+    int device = 0;
+    double noise_logl = 0.0;
+    std::vector<void*> owned;
+    nmma::gw::GwSource* src = nullptr;
+    double* partial = nullptr;
+    int64_t cap = 0;
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev;
+    int prof_max = 0;
+};
+
+extern "C" {
+
+int32_t nmma_gw_loglike_ratio(const double* strain_dev, const double* data_dev, const double* weight_dev, int64_t B,
+                              int32_t n_ifo, int64_t n_freq, double duration, double* out_dev, int32_t device, void* stream) {
+    using namespace nmma;
+    if (!strain_dev || !data_dev || !weight_dev || !out_dev || B < 0 || n_ifo < 1 || n_freq < 1 || !(duration > 0))
+        return fail("nmma_gw_loglike_ratio: bad argument");
+    if (B == 0) return 0;
+    GW_HIP(hipSetDevice(device));
+#define NM_GW(S)                                                                                                         \
+    hipLaunchKernelGGL(gw_loglike_ratio_kernel<S>, dim3((unsigned)((B + S - 1) / S)), dim3(GW_THREADS), 0,                \
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const double2*>(strain_dev),                    \
+                       reinterpret_cast<const double2*>(data_dev), weight_dev, (long)B, (long)n_ifo * (long)n_freq,       \
+                       4.0 / duration, out_dev)
+    // samples per workgroup: as many as leave one workgroup per CU (the data / weight arrays are then read once per group)
+    if (B >= 8 * 256) NM_GW(8);
+    else if (B >= 4 * 256) NM_GW(4);
+    else if (B >= 2 * 256) NM_GW(2);
+    else NM_GW(1);
+#undef NM_GW
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_gw_loglike_ratio launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+void nmma_gw_destroy(nmma_gw_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->src) (void)hipFree(h->src);
+    if (h->partial) (void)hipFree(h->partial);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
+    using namespace nmma;
+    if (!c || !out) return fail("nmma_gw_create: null argument");
+    *out = nullptr;
+    if (c->abi_version != NMMA_ABI_VERSION) return fail("nmma_gw_create: ABI version mismatch");
+    if (c->n_ifo < 1 || c->n_ifo > NMMA_GW_MAX_IFO) return fail("nmma_gw_create: n_ifo must be 1..4");
+    if (c->n_freq < 2 || !(c->duration > 0)) return fail("nmma_gw_create: bad frequency array");
+    if (!c->data || !c->psd || !c->mask || !c->detector_tensor || !c->vertex) return fail("nmma_gw_create: null array");
+    if (!(c->reference_frequency > 0)) return fail("nmma_gw_create: reference_frequency must be positive");
+    if (c->mass_mode != NMMA_GW_CHIRP_MASS_RATIO && c->mass_mode != NMMA_GW_COMPONENT_MASSES) return fail("nmma_gw_create: bad mass_mode");
+    const nmma_slot* slots[13] = {&c->mass_a, &c->mass_b, &c->chi_1, &c->chi_2, &c->lambda_1, &c->lambda_2, &c->luminosity_distance,
+                                  &c->theta_jn, &c->phase, &c->ra, &c->dec, &c->psi, &c->geocent_time};
+    for (const nmma_slot* s : slots)
+        if (s->col >= c->n_dim || s->op < 0 || s->op > NMMA_OP_ACOS) return fail("nmma_gw_create: parameter slot out of range");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail("nmma_gw_create: no HIP device (nmma_amd has no CPU fallback)");
+    if (c->device < 0 || c->device >= n_dev) return fail("nmma_gw_create: device ordinal out of range");
+    GW_HIP(hipSetDevice(c->device));
+    const int n_ifo = c->n_ifo;
+    const int64_t NF = c->n_freq;
+    const double df = 1.0 / c->duration;
+    // evaluated band: union of the detectors' masks inside the waveform's own band (source.py: frequency_bounds), f > 0
+    const double fmax_w = c->waveform_maximum_frequency > 0 ? c->waveform_maximum_frequency : HUGE_VAL;
+    int64_t k_lo = NF, k_hi = -1;
+    for (int d = 0; d < n_ifo; ++d)
+        for (int64_t k = 1; k < NF; ++k) {
+            const double f = (double)k * df;
+            if (c->mask[(size_t)d * NF + k] && f >= c->waveform_minimum_frequency && f <= fmax_w) {
+                k_lo = std::min(k_lo, k);
+                k_hi = std::max(k_hi, k);
+            }
+        }
+    if (k_hi < k_lo) return fail("nmma_gw_create: the frequency masks and the waveform band do not overlap");
+    const int64_t nb = k_hi - k_lo + 1;
+    nmma_gw_handle* h = new nmma_gw_handle();
+    h->device = c->device;
+    GwDev& P = h->dev;
+    P.n_ifo = n_ifo; P.tidal = c->tidal ? 1 : 0; P.mass_mode = c->mass_mode; P.phase_marg = c->phase_marginalization ? 1 : 0;
+    P.n_bins = nb; P.k0 = k_lo; P.n_freq = NF; P.n_dim = c->n_dim;
+    P.n_chunks = (int32_t)((nb + GW_CHUNK - 1) / GW_CHUNK);
+    P.df = df; P.f_ref = c->reference_frequency; P.start_time = c->start_time;
+    P.gmst_ref_time = c->gmst_ref_time; P.gmst_ref = c->gmst_ref; P.gmst_rate = c->gmst_rate;
+    P.four_over_T = 4.0 / c->duration;
+    for (int d = 0; d < n_ifo; ++d) {
+        std::memcpy(P.det[d].tensor, c->detector_tensor + 9 * d, 9 * sizeof(double));
+        std::memcpy(P.det[d].vertex, c->vertex + 3 * d, 3 * sizeof(double));
+    }
+    P.mass_a = c->mass_a; P.mass_b = c->mass_b; P.chi_1 = c->chi_1; P.chi_2 = c->chi_2; P.lambda_1 = c->lambda_1; P.lambda_2 = c->lambda_2;
+    P.luminosity_distance = c->luminosity_distance; P.theta_jn = c->theta_jn; P.phase = c->phase; P.ra = c->ra; P.dec = c->dec;
+    P.psi = c->psi; P.geocent_time = c->geocent_time;
+    std::vector<double> basis((size_t)4 * nb), dat((size_t)4 * nb * n_ifo, 0.0);
+    for (int64_t i = 0; i < nb; ++i) {
+        const gw::GwBin b = gw::make_bin((double)(k_lo + i) * df);
+        basis[4 * i] = b.f13; basis[4 * i + 1] = b.inv13; basis[4 * i + 2] = b.lnf13; basis[4 * i + 3] = b.fm76;
+    }
+    double noise = 0.0;
+    for (int d = 0; d < n_ifo; ++d) {
+        double acc = 0.0;
+        for (int64_t k = 0; k < NF; ++k) {
+            if (!c->mask[(size_t)d * NF + k]) continue;
+            const double S = c->psd[(size_t)d * NF + k];
+            if (!(S > 0) || !std::isfinite(S)) { delete h; return fail("nmma_gw_create: the PSD must be positive and finite inside the frequency mask"); }
+            const double re = c->data[2 * ((size_t)d * NF + k)], im = c->data[2 * ((size_t)d * NF + k) + 1];
+            acc += (re * re + im * im) / S;
+            const double f = (double)k * df;
+            if (k >= k_lo && k <= k_hi && f >= c->waveform_minimum_frequency && f <= fmax_w) {
+                const size_t o = 4 * ((size_t)d * nb + (k - k_lo));
+                dat[o] = re / S; dat[o + 1] = im / S; dat[o + 2] = 1.0 / S;
+            }
+        }
+        noise -= 0.5 * (4.0 / c->duration) * acc;       // bilby: noise_log_likelihood = -sum_ifo <d|d> / 2
+    }
+    h->noise_logl = noise;
+    auto up = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        h->owned.push_back(p);
+        e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+        *dst = p;
+        return e;
+    };
+    void* p = nullptr;
+    hipError_t e = up(basis.data(), basis.size() * 8, &p);
+    if (e == hipSuccess) { P.basis = reinterpret_cast<const double4*>(p); e = up(dat.data(), dat.size() * 8, &p); }
+    if (e == hipSuccess) { P.dat = reinterpret_cast<const double4*>(p); e = up(&P, sizeof(P), &p); }
+    if (e != hipSuccess) { nmma_gw_destroy(h); return fail(std::string("nmma_gw_create: ") + hipGetErrorString(e)); }
+    h->dev_d = reinterpret_cast<GwDev*>(p);
+    *out = h;
+    return 0;
+}
+
+double nmma_gw_noise_log_likelihood(const nmma_gw_handle* h) { return h ? h->noise_logl : 0.0; }
+int64_t nmma_gw_n_bins(const nmma_gw_handle* h) { return h ? h->dev.n_bins : 0; }
+
+static int32_t gw_reserve(nmma_gw_handle* h, int64_t B) {
+    if (B <= h->cap) return 0;
+    // (outside any capture; the previous buffers may still be in use by launches in flight on the caller's stream)
+    GW_HIP(hipDeviceSynchronize());
+    if (h->src) (void)hipFree(h->src);
+    if (h->partial) (void)hipFree(h->partial);
+    h->src = nullptr; h->partial = nullptr; h->cap = 0;
+    const int64_t cap = std::max<int64_t>(B, 256);
+    GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->src), (size_t)cap * sizeof(nmma::gw::GwSource)));
+    GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->partial), (size_t)cap * h->dev.n_chunks * 3 * sizeof(double)));
+    h->cap = cap;
+    return 0;
+}
+
+static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* out_dev, void* stream, int mode,
+                      const char* what) {
+    using namespace nmma;
+    if (!h || !theta_dev || !out_dev || B < 0 || ld < h->dev.n_dim) return fail(std::string(what) + ": bad argument");
+    if (B == 0) return 0;
+    GW_HIP(hipSetDevice(h->device));
+    if (gw_reserve(h, B) != 0) return 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const GwDev& P = h->dev;
+    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld, h->src);
+    const long n_groups = (B + GW_GROUP - 1) / GW_GROUP;
+    const dim3 grid((unsigned)(n_groups * P.n_chunks));
+    const bool pm = P.phase_marg != 0 || mode == 1;
+    const bool prof = h->prof_on && (int)h->ev.size() + 2 <= 2 * h->prof_max;
+    if (prof) {
+        hipEvent_t a, b;
+        GW_HIP(hipEventCreate(&a)); GW_HIP(hipEventCreate(&b));
+        h->ev.push_back(a); h->ev.push_back(b);
+        GW_HIP(hipEventRecord(a, s));
+    }
+#define GW_LAUNCH(N)                                                                                                                  \
+    do {                                                                                                                              \
+        if (pm) hipLaunchKernelGGL((gw_logl_kernel<N, true>), grid, dim3(GWL_THREADS), 0, s, h->dev_d, h->src, (long)B, h->partial);   \
+        else hipLaunchKernelGGL((gw_logl_kernel<N, false>), grid, dim3(GWL_THREADS), 0, s, h->dev_d, h->src, (long)B, h->partial);     \
+    } while (0)
+    switch (P.n_ifo) {
+        case 1: GW_LAUNCH(1); break;
+        case 2: GW_LAUNCH(2); break;
+        case 3: GW_LAUNCH(3); break;
+        default: GW_LAUNCH(4); break;
+    }
+#undef GW_LAUNCH
+    if (prof) GW_HIP(hipEventRecord(h->ev.back(), s));
+    hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode, out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string(what) + " launch failed: " + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_gw_loglike(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* out_dev, void* stream) {
+    return gw_run(h, theta_dev, B, ld, out_dev, stream, 0, "nmma_gw_loglike");
+}
+
+int32_t nmma_gw_inner_products(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* parts_dev, void* stream) {
+    return gw_run(h, theta_dev, B, ld, parts_dev, stream, 1, "nmma_gw_inner_products");
+}
+
+int32_t nmma_gw_strain(nmma_gw_handle* h, const double* theta_dev, int64_t B, int64_t ld, double* strain_dev, void* stream) {
+    using namespace nmma;
+    if (!h || !theta_dev || !strain_dev || B < 0 || B > 65535 || ld < h->dev.n_dim) return fail("nmma_gw_strain: bad argument");
+    if (B == 0) return 0;
+    GW_HIP(hipSetDevice(h->device));
+    if (gw_reserve(h, B) != 0) return 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const GwDev& P = h->dev;
+    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld, h->src);
+    const dim3 grid((unsigned)((P.n_freq + 255) / 256), (unsigned)B);
+    double2* o = reinterpret_cast<double2*>(strain_dev);
+    switch (P.n_ifo) {
+        case 1: hipLaunchKernelGGL(gw_strain_kernel<1>, grid, dim3(256), 0, s, h->dev_d, h->src, (long)B, o); break;
+        case 2: hipLaunchKernelGGL(gw_strain_kernel<2>, grid, dim3(256), 0, s, h->dev_d, h->src, (long)B, o); break;
+        case 3: hipLaunchKernelGGL(gw_strain_kernel<3>, grid, dim3(256), 0, s, h->dev_d, h->src, (long)B, o); break;
+        default: hipLaunchKernelGGL(gw_strain_kernel<4>, grid, dim3(256), 0, s, h->dev_d, h->src, (long)B, o); break;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_gw_strain launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_gw_profile_begin(nmma_gw_handle* h, int32_t max_launches) {
+    if (!h || max_launches < 1) return fail("nmma_gw_profile_begin: bad argument");
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->prof_on = true;
+    h->prof_max = max_launches;
+    return 0;
+}
+
+int32_t nmma_gw_profile_end(nmma_gw_handle* h, double* kernel_ms_total, int32_t* n_launches) {
+    if (!h || !kernel_ms_total || !n_launches) return fail("nmma_gw_profile_end: bad argument");
+    GW_HIP(hipSetDevice(h->device));
+    GW_HIP(hipDeviceSynchronize());
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < h->ev.size(); i += 2) {
+        float ms = 0.f;
+        GW_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        total += ms;
+    }
+    *kernel_ms_total = total;
+    *n_launches = (int32_t)(h->ev.size() / 2);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->prof_on = false;
+    return 0;
+}
+
+}  // extern "C"

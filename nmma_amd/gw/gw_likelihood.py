@@ -1,19 +1,21 @@
-"""The data-parallel part of the gravitational-wave term (``nmma/gw/gw_likelihood.py:97-247`` ->
-``bilby.gw.likelihood.GravitationalWaveTransient``): noise-weighted inner products on the GPU for strain that
-has already been projected onto each detector.
+"""The gravitational-wave messenger (``nmma/gw/gw_likelihood.py:97-247`` -> ``bilby.gw.likelihood.GravitationalWaveTransient``).
 
-Scope: the reference's class holds no arithmetic (bilby does); its waveform generator (lalsimulation) and
-detector response stay third-party and on the caller's side.  What this module offers is the reduction that
-follows them -- for a whole batch of parameter vectors in one launch -- and its constant noise term, shaped so
-that the result plugs into :class:`nmma_amd.joint.MultiMessengerLikelihood` as the GW messenger of BASELINE
-config 5::
+Two entry levels, both batched and both GPU-only (a missing library or device raises :class:`nmma_amd._lib.NMMAHipError`):
 
-    gw = GWStrainLikelihood(data, psd, frequency_array, duration, minimum_frequency=20.0)
-    joint = MultiMessengerLikelihood([em_likelihood, ExternalLogLikelihood("gw")], priors)
-    logl = joint.log_likelihood_batch(theta, names, external_logl={"gw": gw.log_likelihood_batch(strain)})
+* :class:`GravitationalWaveTransientLikelihood` -- the reference's class (same constructor and attributes) over
+  :class:`GWEngine`: from PARAMETERS to log-likelihood in one fused kernel (frequency-domain IMRPhenomD_NRTidalv2 / IMRPhenomD
+  waveform, antenna response and arrival-time shift per detector, noise-weighted inner products, optional phase
+  marginalisation); the strain is never written to memory.  BASELINE config 5::
 
-There is no CPU fallback: a missing library or device raises :class:`nmma_amd._lib.NMMAHipError`.
-Parity against bilby is unpinned (absent from the build image); the oracle restates its published formulas.
+      gw = GravitationalWaveTransientLikelihood(priors, interferometers, waveform_generator, phase_marginalization=True)
+      joint = MultiMessengerLikelihood([em_likelihood, gw], priors)
+      logl = joint.log_likelihood_batch(theta, names)
+
+* :class:`GWStrainLikelihood` -- the reduction alone, for strain the caller generated with another waveform model and already
+  projected onto the detectors (an HBM-bound stream).
+
+bilby and lalsimulation are absent from the build image: parity of this leg is UNPINNED (``oracle/gw_waveform_oracle.py``
+restates the published algorithms; the HIP path is tested against that restatement).
 """
 from __future__ import annotations
 
@@ -22,6 +24,8 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib as L
+from ..core.base import NMMALikelihood
+from .detector import gmst_linearisation
 
 
 class GWStrainLikelihood:
@@ -90,3 +94,352 @@ class GWStrainLikelihood:
     def log_likelihood_batch(self, strain, out=None, stream=None):
         """log L = log L ratio + noise log-likelihood (bilby: ``GravitationalWaveTransient.log_likelihood``)."""
         return self.log_likelihood_ratio_batch(strain, out=out, stream=stream) + self._noise
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The GW term from PARAMETERS: waveform + detector projection + inner products fused on the device
+# ---------------------------------------------------------------------------------------------------------------------
+#: parameters of bilby's aligned-spin binary-neutron-star source model (bilby/gw/source.py: lal_binary_neutron_star)
+GW_PARAMETERS = ("chi_1", "chi_2", "lambda_1", "lambda_2", "luminosity_distance", "theta_jn", "phase", "ra", "dec", "psi",
+                 "geocent_time")
+SUPPORTED_APPROXIMANTS = {"IMRPhenomD_NRTidalv2": 1, "IMRPhenomD": 0}
+
+
+class WaveformGenerator:
+    """Stand-in for ``bilby.gw.WaveformGenerator`` when bilby is absent: the attributes the likelihood reads
+    (``duration``, ``sampling_frequency``, ``start_time``, ``frequency_domain_source_model.__name__``, ``waveform_arguments``)."""
+
+    def __init__(self, duration, sampling_frequency, start_time=0.0, waveform_arguments=None, frequency_domain_source_model=None,
+                 parameter_conversion=None):
+        self.duration, self.sampling_frequency, self.start_time = float(duration), float(sampling_frequency), float(start_time)
+        self.waveform_arguments = dict(waveform_arguments or {})
+        if frequency_domain_source_model is None:
+            def lal_binary_neutron_star(*_a, **_k):       # name only: the arithmetic runs on the device
+                raise NotImplementedError("evaluated on the GPU by GWEngine")
+            frequency_domain_source_model = lal_binary_neutron_star
+        self.frequency_domain_source_model = frequency_domain_source_model
+        self.parameter_conversion = parameter_conversion
+
+
+class GWEngine:
+    """One GPU-resident GW likelihood (a ``nmma_gw_handle``): replaces, for a whole batch of parameter vectors per call,
+    ``waveform_generator.frequency_domain_strain`` -> ``Interferometer.get_detector_response`` -> the inner products of
+    ``bilby.gw.likelihood.GravitationalWaveTransient.log_likelihood_ratio`` (as wrapped by nmma/gw/gw_likelihood.py:185-203).
+
+    ``parameter_names`` are the columns of ``theta``; anything of the source model that is not a column must be in ``fixed``.
+    Masses: ``chirp_mass`` + ``mass_ratio`` or ``mass_1`` + ``mass_2`` (detector frame, solar masses); spins: aligned
+    ``chi_1`` / ``chi_2``; inclination: ``theta_jn`` or ``cos_theta_jn``.  No CPU fallback."""
+
+    def __init__(self, interferometers, parameter_names, fixed=None, waveform_arguments=None, phase_marginalization=False,
+                 gmst_reference_time=None, device=0):
+        import torch  # noqa: F401  (device buffers / stream)
+        self._handle = None
+        self._lib = L.load_library()
+        self.device = int(device)
+        names, fixed = list(parameter_names), dict(fixed or {})
+        self.parameter_names = names
+        wa = dict(waveform_arguments or {})
+        approximant = wa.get("waveform_approximant", "IMRPhenomD_NRTidalv2")
+        if approximant not in SUPPORTED_APPROXIMANTS:
+            raise L.NMMAHipError(f"waveform_approximant {approximant!r} is not built on the device path "
+                                 f"(available: {sorted(SUPPORTED_APPROXIMANTS)})")
+        ifos = list(interferometers)
+        if not 1 <= len(ifos) <= L.GW_MAX_IFO:
+            raise L.NMMAHipError(f"1..{L.GW_MAX_IFO} interferometers, got {len(ifos)}")
+        n_freq = len(ifos[0].frequency_array)
+        duration, start = float(ifos[0].strain_data.duration), float(ifos[0].strain_data.start_time)
+        for ifo in ifos:
+            if len(ifo.frequency_array) != n_freq or float(ifo.strain_data.duration) != duration or \
+                    float(ifo.strain_data.start_time) != start:
+                raise L.NMMAHipError("all interferometers must share one frequency array and one data segment")
+        if abs(ifos[0].frequency_array[1] * duration - 1.0) > 1e-9:
+            raise L.NMMAHipError("frequency_array must be k / duration")
+        self.n_ifo, self.n_freq, self.duration, self.start_time = len(ifos), n_freq, duration, start
+        data = np.ascontiguousarray(np.stack([np.asarray(i.frequency_domain_strain, dtype=np.complex128) for i in ifos]))
+        psd = np.ascontiguousarray(np.stack([np.asarray(i.power_spectral_density_array, dtype=np.float64) for i in ifos]))
+        mask = np.ascontiguousarray(np.stack([np.asarray(i.frequency_mask, dtype=bool) for i in ifos]).astype(np.uint8))
+        tensor = np.ascontiguousarray(np.stack([np.asarray(i.detector_tensor, dtype=np.float64).reshape(9) for i in ifos]))
+        vertex = np.ascontiguousarray(np.stack([np.asarray(i.vertex, dtype=np.float64).reshape(3) for i in ifos]))
+
+        def slot(key, default=None, op=L.OP_IDENT):
+            if key in names:
+                return L.Slot.column(names.index(key), op)
+            if key in fixed:
+                v = float(fixed[key])
+                return L.Slot.constant(float(np.arccos(v)) if op == L.OP_ACOS else v)
+            if default is None:
+                raise L.NMMAHipError(f"GW parameter {key!r} is neither sampled nor fixed (sampled: {names}, fixed: {sorted(fixed)})")
+            return L.Slot.constant(default)
+
+        have = set(names) | set(fixed)
+        cfg = L.GwConfig()
+        if {"chirp_mass", "mass_ratio"} <= have:
+            cfg.mass_mode, cfg.mass_a, cfg.mass_b = L.GW_CHIRP_MASS_RATIO, slot("chirp_mass"), slot("mass_ratio")
+        elif {"mass_1", "mass_2"} <= have:
+            cfg.mass_mode, cfg.mass_a, cfg.mass_b = L.GW_COMPONENT_MASSES, slot("mass_1"), slot("mass_2")
+        else:
+            raise L.NMMAHipError("the GW leg needs chirp_mass + mass_ratio or mass_1 + mass_2")
+        cfg.theta_jn = slot("cos_theta_jn", op=L.OP_ACOS) if ("cos_theta_jn" in have and "theta_jn" not in have) else slot("theta_jn")
+        cfg.chi_1, cfg.chi_2 = slot("chi_1", 0.0), slot("chi_2", 0.0)
+        cfg.lambda_1, cfg.lambda_2 = slot("lambda_1", 0.0), slot("lambda_2", 0.0)
+        cfg.luminosity_distance, cfg.phase = slot("luminosity_distance"), slot("phase", 0.0)
+        cfg.ra, cfg.dec, cfg.psi, cfg.geocent_time = slot("ra"), slot("dec"), slot("psi"), slot("geocent_time")
+        cfg.abi_version, cfg.device, cfg.n_ifo, cfg.tidal = L.ABI_VERSION, self.device, self.n_ifo, SUPPORTED_APPROXIMANTS[approximant]
+        cfg.n_freq, cfg.duration, cfg.start_time = n_freq, duration, start
+        cfg.data = np.ascontiguousarray(data.view(np.float64)).ctypes.data_as(L._pd)
+        cfg.psd = psd.ctypes.data_as(L._pd)
+        cfg.mask = mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        cfg.detector_tensor, cfg.vertex = tensor.ctypes.data_as(L._pd), vertex.ctypes.data_as(L._pd)
+        t_ref = float(gmst_reference_time if gmst_reference_time is not None else fixed.get("geocent_time", start + duration - 2.0))
+        cfg.gmst_ref_time = t_ref
+        cfg.gmst_ref, cfg.gmst_rate = gmst_linearisation(t_ref)
+        cfg.reference_frequency = float(wa.get("reference_frequency", 50.0))           # bilby's default
+        cfg.waveform_minimum_frequency = float(wa.get("minimum_frequency", 20.0))
+        cfg.waveform_maximum_frequency = float(wa.get("maximum_frequency", np.inf))
+        cfg.phase_marginalization = 1 if phase_marginalization else 0
+        cfg.n_dim = len(names)
+        keep = (data, psd, mask, tensor, vertex)        # alive until create returns (the library copies)
+        h = C.c_void_p()
+        L.check(self._lib.nmma_gw_create(C.byref(cfg), C.byref(h)), "nmma_gw_create")
+        del keep
+        self._handle = h
+        self.n_bins = int(self._lib.nmma_gw_n_bins(h))
+        self.phase_marginalization = bool(phase_marginalization)
+        self._noise = float(self._lib.nmma_gw_noise_log_likelihood(h))
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.nmma_gw_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def noise_log_likelihood(self):
+        return self._noise
+
+    def _theta(self, theta):
+        import torch
+        dev = torch.device(f"cuda:{self.device}")
+        if not isinstance(theta, torch.Tensor):
+            theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64))
+        if theta.dtype != torch.float64 or theta.dim() != 2 or theta.shape[1] < len(self.parameter_names):
+            raise L.NMMAHipError(f"theta must be float64 [B, >= {len(self.parameter_names)}], got {theta.dtype} {tuple(theta.shape)}")
+        return theta.to(dev).contiguous(), dev
+
+    def _call(self, fn, what, theta, width, out=None, stream=None):
+        import torch
+        theta, dev = self._theta(theta)
+        n = theta.shape[0]
+        shape = (n,) if width == 1 else (n, width)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=dev)
+        elif out.dtype != torch.float64 or out.device != dev or tuple(out.shape) != shape or not out.is_contiguous():
+            raise L.NMMAHipError(f"out must be a contiguous float64 tensor of shape {shape} on {dev}")
+        if n == 0:
+            return out
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if s.device.index != self.device:
+            raise L.NMMAHipError(f"stream belongs to cuda:{s.device.index}, the engine to cuda:{self.device}")
+        # theta / out were staged on torch's current stream: a different launch stream has to wait for that work
+        cur = torch.cuda.current_stream(self.device)
+        if s.cuda_stream != cur.cuda_stream:
+            s.wait_stream(cur)
+        L.check(fn(self._handle, C.c_void_p(theta.data_ptr()), n, theta.stride(0), C.c_void_p(out.data_ptr()),
+                   C.c_void_p(s.cuda_stream)), what)
+        return out
+
+    def loglike_ratio(self, theta, out=None, stream=None):
+        """``theta[B, D]`` -> log-likelihood ratio ``[B]`` (torch CUDA tensor; asynchronous)."""
+        return self._call(self._lib.nmma_gw_loglike, "nmma_gw_loglike", theta, 1, out, stream)
+
+    def inner_products(self, theta, out=None, stream=None):
+        """``[B, 3]``: Re<d|h>, Im<d|h>, <h|h> summed over the detectors."""
+        return self._call(self._lib.nmma_gw_inner_products, "nmma_gw_inner_products", theta, 3, out, stream)
+
+    def strain(self, theta):
+        """The projected strain ``[B, n_ifo, n_freq]`` complex128 (tests / plots; B x n_ifo x n_freq x 16 bytes of HBM)."""
+        import torch
+        theta, dev = self._theta(theta)
+        n = theta.shape[0]
+        out = torch.empty((n, self.n_ifo, self.n_freq, 2), dtype=torch.float64, device=dev)
+        L.check(self._lib.nmma_gw_strain(self._handle, C.c_void_p(theta.data_ptr()), n, theta.stride(0), C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "nmma_gw_strain")
+        return torch.view_as_complex(out)
+
+    def profile_begin(self, max_launches=64):
+        L.check(self._lib.nmma_gw_profile_begin(self._handle, int(max_launches)), "nmma_gw_profile_begin")
+
+    def profile_end(self):
+        ms, n = C.c_double(), C.c_int32()
+        L.check(self._lib.nmma_gw_profile_end(self._handle, C.byref(ms), C.byref(n)), "nmma_gw_profile_end")
+        return ms.value, n.value
+
+
+def _noise_log_likelihood_host(interferometers):
+    """``-sum_ifo <d|d> / 2`` (bilby: GravitationalWaveTransient.noise_log_likelihood) -- a constant of the data, evaluated once
+    on the host at construction so that the object answers without touching the GPU."""
+    total = 0.0
+    for ifo in interferometers:
+        m = np.asarray(ifo.frequency_mask, dtype=bool)
+        d = np.asarray(ifo.frequency_domain_strain)[m]
+        s = np.asarray(ifo.power_spectral_density_array)[m]
+        total -= 0.5 * 4.0 / float(ifo.strain_data.duration) * float(np.sum((d.real ** 2 + d.imag ** 2) / s))
+    return total
+
+
+class GravitationalWaveTransient:
+    """What ``GravitationalWaveTransientLikelihood.sub_model`` exposes of ``bilby.gw.likelihood.GravitationalWaveTransient``:
+    the objects it was built from, the marginalisation flags, ``noise_log_likelihood`` and the evaluation -- per sample
+    (``log_likelihood(parameters)``, a batch of one) and batched (``log_likelihood_ratio_batch``).  The GPU handle is created
+    lazily per process and dropped on pickling, like the EM likelihood's."""
+
+    def __init__(self, interferometers, waveform_generator, priors=None, phase_marginalization=False, device=0):
+        self.interferometers, self.waveform_generator, self.priors = list(interferometers), waveform_generator, priors
+        self.phase_marginalization, self.distance_marginalization, self.time_marginalization = bool(phase_marginalization), False, False
+        self.device = int(device)
+        self._noise = _noise_log_likelihood_host(self.interferometers)
+        self._engine, self._names = None, None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"], state["_names"] = None, None
+        return state
+
+    def fixed_parameters(self, names):
+        from ..core.base import fixed_value
+        fixed = {}
+        for key, prior in (self.priors.items() if hasattr(self.priors, "items") else ()):
+            val = fixed_value(prior)
+            if val is not None and key not in names:
+                fixed[key] = val
+        if self.phase_marginalization:
+            fixed["phase"] = 0.0        # bilby: the phase prior becomes a delta function at 0
+        return fixed
+
+    def engine(self, names):
+        names = [n for n in names]
+        if self.phase_marginalization and "phase" in names:
+            raise L.NMMAHipError("phase is marginalised: it must not be a sampled column")
+        if self._engine is None or self._names != names:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = GWEngine(self.interferometers, names, fixed=self.fixed_parameters(names),
+                                    waveform_arguments=self.waveform_generator.waveform_arguments,
+                                    phase_marginalization=self.phase_marginalization, device=self.device)
+            self._names = names
+        return self._engine
+
+    def noise_log_likelihood(self):
+        return self._noise
+
+    def log_likelihood_ratio_batch(self, theta, names, out=None, stream=None):
+        return self.engine(names).loglike_ratio(theta, out=out, stream=stream)
+
+    def log_likelihood_ratio(self, parameters):
+        fixed = self.fixed_parameters(())
+        names = sorted(k for k in parameters if k in _GW_KEYS and k not in fixed)
+        row = np.array([[float(parameters[k]) for k in names]])
+        return float(self.log_likelihood_ratio_batch(row, names).cpu().numpy()[0])
+
+    def log_likelihood(self, parameters):
+        return self.log_likelihood_ratio(parameters) + self._noise
+
+
+_GW_KEYS = set(GW_PARAMETERS) | {"chirp_mass", "mass_ratio", "mass_1", "mass_2", "cos_theta_jn"}
+
+
+class GravitationalWaveTransientLikelihood(NMMALikelihood):
+    """``nmma/gw/gw_likelihood.py:97-247``: the GW messenger.  Same constructor, same attributes (``sub_model`` with
+    ``interferometers`` / ``waveform_generator``, ``parameter_conversion`` = the neutron-star or black-hole source-frame
+    conversion chosen from the source model's name, :207-210), with the arithmetic bilby + lalsimulation do per sample
+    moved to the GPU for a whole batch (``log_likelihood_batch``).
+
+    Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` on or off,
+    sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
+    Refused at construction (never approximated): the ROQ / relative-binning / multibanded likelihood classes (they need
+    bilby's basis files and fiducial waveforms), time and distance marginalisation (:174-178), other reference frames."""
+
+    def __init__(self, priors, interferometers, waveform_generator, gw_likelihood_type="GravitationalWaveTransient",
+                 time_marginalization=False, distance_marginalization=False, phase_marginalization=False,
+                 distance_marginalization_lookup_table=None, jitter_time=True, reference_frame="sky",
+                 time_reference="geocenter", device=0, **kwargs):
+        waveform_generator.parameter_conversion = self.gw_identity_conversion            # :167
+        waveform_generator.start_time = interferometers[0].time_array[0]                 # :168
+        known = ("GravitationalWaveTransient", "ROQGravitationalWaveTransient", "RelativeBinningGravitationalWaveTransient",
+                 "MBGravitationalWaveTransient")
+        if gw_likelihood_type not in known:
+            raise ValueError("Unknown GW Likelihood class {}")                            # :205 (sic)
+        if gw_likelihood_type != "GravitationalWaveTransient":
+            raise L.NMMAHipError(f"{gw_likelihood_type} is not built on the device path (it needs bilby's basis / fiducial data)")
+        if time_marginalization or distance_marginalization:
+            raise L.NMMAHipError("time and distance marginalisation are not built on the device path")
+        if reference_frame != "sky" or time_reference not in ("geocent", "geocenter"):
+            raise L.NMMAHipError("only reference_frame='sky' and time_reference='geocenter' are built on the device path")
+        sub_model = GravitationalWaveTransient(interferometers, waveform_generator, priors=priors,
+                                               phase_marginalization=phase_marginalization, device=device)
+        super().__init__(sub_model, priors)
+        from ..core import conversion
+        name = getattr(waveform_generator.frequency_domain_source_model, "__name__", "")
+        self.parameter_conversion = conversion.bns_source_frame if "neutron_star" in name else conversion.bbh_source_frame
+
+    def gw_identity_conversion(self, parameters):
+        return parameters, []
+
+    def sanity_checks(self):
+        return True
+
+    def final_diagnostics(self, bestfit_params, args, result=None):
+        return None
+
+    def noise_log_likelihood(self):
+        return self.sub_model.noise_log_likelihood()
+
+    def posterior_conversion(self, posterior_samples):
+        """:212-236: chi_eff and the effective tidal deformabilities, where their ingredients are present."""
+        from ..core.conversion import tidal_deformabilities_and_mass_ratio_to_eff_tidal_deformabilities as tidal_conversion
+        if "chi_eff" not in posterior_samples:
+            try:
+                q = posterior_samples["mass_ratio"]
+                chi_1 = posterior_samples.get("chi_1", posterior_samples["spin_1z"])
+                chi_2 = posterior_samples.get("chi_2", posterior_samples["spin_2z"])
+                posterior_samples["chi_eff"] = (chi_1 + q * chi_2) / (1 + q)
+            except KeyError:
+                pass
+        if "lambda_tilde" not in posterior_samples:
+            try:
+                lam_t, dlam_t = tidal_conversion(posterior_samples["lambda_1"], posterior_samples["lambda_2"],
+                                                 posterior_samples["mass_ratio"])
+                posterior_samples["lambda_tilde"], posterior_samples["delta_lambda_t"] = lam_t, dlam_t
+            except KeyError:
+                pass
+        return posterior_samples
+
+    # ---- batched path
+    def log_likelihood_batch(self, theta, names=None, out=None, stream=None):
+        """log L for every row of ``theta[B, D]`` (columns ``names``; default: the non-fixed, non-constraint priors in order):
+        log-likelihood ratio from the fused kernel + the noise term; rows that violate a Constraint prior or hold
+        unphysical parameters get the floor.  Returns a torch CUDA tensor."""
+        import torch
+        from ..core.base import LOGL_FLOOR
+        if names is None:
+            from ..core.base import fixed_value, is_constraint
+            names = [k for k, p in self.priors.items() if fixed_value(p) is None and not is_constraint(p)]
+        names = list(names)
+        gw_cols = [i for i, n in enumerate(names) if n in _GW_KEYS]
+        gw_names = [names[i] for i in gw_cols]
+        th = theta if isinstance(theta, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64))
+        if gw_cols != list(range(len(names))):
+            th = th[:, gw_cols]
+        ratio = self.sub_model.log_likelihood_ratio_batch(th, gw_names, out=out, stream=stream)
+        logl = torch.where(ratio > LOGL_FLOOR, ratio + self.sub_model.noise_log_likelihood(), ratio)
+        if self.constraints:
+            host = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta)
+            columns = {n: host[:, i] for i, n in enumerate(names)}
+            columns.update(self.sub_model.fixed_parameters(names))
+            logl = self.floor_constrained_rows(logl, columns)
+        return logl

@@ -173,3 +173,86 @@ def draw_theta(seed, batch, names=None):
         else:
             raise KeyError(n)
     return names, np.stack(cols, axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gravitational-wave leg (BASELINE config 5: "GW170817 + AT2017gfo synthetic")
+# ---------------------------------------------------------------------------------------------------------------------
+#: GW170817-like source (detector-frame masses; GPS time of the event) used as the centre of the synthetic config-5 runs
+GW170817_LIKE = dict(chirp_mass=1.1977, mass_ratio=0.87, chi_1=0.02, chi_2=-0.01, lambda_1=400.0, lambda_2=600.0,
+                     luminosity_distance=40.0, theta_jn=2.6, phase=1.3, ra=3.44616, dec=-0.408084, psi=0.7,
+                     geocent_time=1187008882.43)
+GW_NAMES = ["chirp_mass", "mass_ratio", "chi_1", "chi_2", "lambda_1", "lambda_2", "luminosity_distance", "theta_jn", "phase",
+            "ra", "dec", "psi", "geocent_time"]
+
+
+def analytic_psd(frequency, scale=1.0):
+    """Smooth advanced-detector-like one-sided PSD [1/Hz] (Sathyaprakash & Schutz 2009, eq. 3.8 shape): an INPUT of the
+    synthetic runs, not a claim about any real detector."""
+    f = np.maximum(np.asarray(frequency, float), 1.0)
+    x = f / 215.0
+    return scale * 1e-49 * (x ** -4.14 - 5.0 / (x * x) + 111.0 * (1.0 - x * x + 0.5 * x ** 4) / (1.0 + 0.5 * x * x))
+
+
+def make_gw_noise(seed, duration, sampling_frequency, ifo_names=("H1", "L1", "V1")):
+    """Coloured Gaussian noise per detector on ``f_k = k / duration``: returns ``(frequency_array, {name: (noise, psd)})``
+    with ``<|n_k|^2> = S_k T / 2`` (bilby's convention for frequency-domain strain)."""
+    rng = np.random.default_rng(seed)
+    n = int(round(duration * sampling_frequency)) // 2 + 1
+    freq = np.arange(n) / float(duration)
+    out = {}
+    for i, name in enumerate(ifo_names):
+        psd = analytic_psd(freq, scale=2.5 if name == "V1" else 1.0 + 0.1 * i)
+        sigma = np.sqrt(psd * duration / 4.0)
+        noise = sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        noise[0] = 0.0
+        out[name] = (noise, psd)
+    return freq, out
+
+
+def draw_gw_theta(seed, batch, centre=None, names=None, width=1.0):
+    """Parameter vectors scattered around ``centre`` the way a late-stage live-point set is (every row a physically valid
+    binary): returns ``(names, theta[B, D])``."""
+    rng = np.random.default_rng(seed)
+    c = dict(centre or GW170817_LIKE)
+    names = list(names or GW_NAMES)
+    spread = dict(chirp_mass=2e-4, mass_ratio=0.08, chi_1=0.03, chi_2=0.03, lambda_1=300.0, lambda_2=400.0,
+                  luminosity_distance=12.0, theta_jn=0.35, cos_theta_jn=0.2, phase=np.pi, ra=0.08, dec=0.08, psi=np.pi / 2,
+                  geocent_time=2e-3, mass_1=0.05, mass_2=0.05)
+    cols = []
+    for n in names:
+        v = c[n] + width * spread[n] * rng.uniform(-1.0, 1.0, batch)
+        if n == "mass_ratio":
+            v = np.clip(v, 0.4, 1.0)
+        elif n in ("lambda_1", "lambda_2"):
+            v = np.clip(v, 0.0, 5000.0)
+        elif n == "theta_jn":
+            v = np.clip(v, 0.0, np.pi)
+        elif n == "cos_theta_jn":
+            v = np.clip(v, -1.0, 1.0)
+        elif n == "luminosity_distance":
+            v = np.clip(v, 5.0, None)
+        cols.append(v)
+    return names, np.stack(cols, axis=1)
+
+
+def make_gw_interferometers(seed, duration, sampling_frequency, ifo_names=("H1", "L1", "V1"), injection=None,
+                            minimum_frequency=20.0, reference_frequency=20.0, approximant="IMRPhenomD_NRTidalv2",
+                            post_trigger=2.0, device=0):
+    """Synthetic detector data for the GW leg WITHOUT the oracle: coloured noise plus an injection whose strain the device
+    path itself generates (a first engine over signal-free data evaluates ``nmma_gw_strain`` for the injected parameters).
+    Needs a HIP device.  Returns ``(interferometers, waveform_arguments, injection)``."""
+    from .gw import GWEngine, Interferometer
+    inj = dict(injection or GW170817_LIKE)
+    start = inj["geocent_time"] + post_trigger - duration
+    freq, noise = make_gw_noise(seed, duration, sampling_frequency, ifo_names)
+    wa = dict(waveform_approximant=approximant, reference_frequency=reference_frequency, minimum_frequency=minimum_frequency)
+    blank = [Interferometer(n, np.zeros(len(freq), complex), noise[n][1], duration, start, minimum_frequency=minimum_frequency,
+                            sampling_frequency=sampling_frequency) for n in ifo_names]
+    names = list(inj)
+    eng = GWEngine(blank, names, waveform_arguments=wa, device=device)
+    h = eng.strain(np.array([[inj[k] for k in names]])).cpu().numpy()[0]
+    eng.close()
+    ifos = [Interferometer(n, noise[n][0] + h[i], noise[n][1], duration, start, minimum_frequency=minimum_frequency,
+                           sampling_frequency=sampling_frequency) for i, n in enumerate(ifo_names)]
+    return ifos, wa, inj

@@ -189,7 +189,9 @@ def octupole_from_quadrupole(qm):
 class PhenomDNRTidalv2:
     """All frequency-independent quantities of one source (masses in solar masses, detector frame; aligned spins)."""
 
-    def __init__(self, mass_1, mass_2, chi_1, chi_2, lambda_1, lambda_2):
+    def __init__(self, mass_1, mass_2, chi_1, chi_2, lambda_1, lambda_2, tidal=True):
+        """``tidal=False``: plain IMRPhenomD (no tidal terms, black-hole multipoles, no taper)."""
+        self.tidal = tidal
         if mass_1 < mass_2:            # LAL swaps so that body 1 is the heavier one
             mass_1, mass_2, chi_1, chi_2, lambda_1, lambda_2 = mass_2, mass_1, chi_2, chi_1, lambda_2, lambda_1
         self.m1, self.m2, self.chi1, self.chi2, self.lam1, self.lam2 = mass_1, mass_2, chi_1, chi_2, lambda_1, lambda_2
@@ -209,8 +211,11 @@ class PhenomDNRTidalv2:
         fr, fd = qnm_220(fs)
         self.fRD, self.fDM = fr / (1.0 - erad), fd / (1.0 - erad)
         # ---- spin-induced multipoles (NRTidalv2 passes quadparam - 1 to the PN phasing)
-        self.qm1, self.qm2 = quadrupole_from_lambda(lambda_1), quadrupole_from_lambda(lambda_2)
-        self.oct1, self.oct2 = octupole_from_quadrupole(self.qm1), octupole_from_quadrupole(self.qm2)
+        if tidal:
+            self.qm1, self.qm2 = quadrupole_from_lambda(lambda_1), quadrupole_from_lambda(lambda_2)
+            self.oct1, self.oct2 = octupole_from_quadrupole(self.qm1), octupole_from_quadrupole(self.qm2)
+        else:
+            self.qm1 = self.qm2 = self.oct1 = self.oct2 = 1.0
         self._setup_amplitude(seta)
         self._setup_phase()
         self._setup_tides()
@@ -468,9 +473,12 @@ class PhenomDNRTidalv2:
         phi_ref = float(self.phase(np.array([Mf_ref]))[0])
         phi = self.phase(Mf) - self.t0 * (Mf - Mf_ref) - (2.0 * phase + phi_ref)
         x = (PI * Mf) ** (2.0 / 3.0)
-        phi = phi + self.tidal_phase(fh) + self.ho_spin * x
-        amp = self.amplitude(Mf) + self.amp0 * Mf ** (-7.0 / 6.0) * self.tidal_amplitude_bracket(fh)
-        out[ok] = amp0 * amp * self.planck_taper(fh) * np.exp(-1j * phi)
+        phi = phi + self.ho_spin * x
+        amp = self.amplitude(Mf)
+        if self.tidal:
+            phi = phi + self.tidal_phase(fh)
+            amp = (amp + self.amp0 * Mf ** (-7.0 / 6.0) * self.tidal_amplitude_bracket(fh)) * self.planck_taper(fh)
+        out[ok] = amp0 * amp * np.exp(-1j * phi)
         return out
 
 
@@ -483,14 +491,14 @@ def component_masses(chirp_mass, mass_ratio):
     return m1, m1 * mass_ratio
 
 
-def polarizations(params, frequency_array, f_ref, f_min, f_max=np.inf):
+def polarizations(params, frequency_array, f_ref, f_min, f_max=np.inf, tidal=True):
     """(h_plus, h_cross) on ``frequency_array`` for a bilby-style parameter dict with aligned spins chi_1, chi_2."""
     if "mass_1" in params:
         m1, m2 = params["mass_1"], params["mass_2"]
     else:
         m1, m2 = component_masses(params["chirp_mass"], params["mass_ratio"])
     src = PhenomDNRTidalv2(m1, m2, params.get("chi_1", 0.0), params.get("chi_2", 0.0),
-                           params.get("lambda_1", 0.0), params.get("lambda_2", 0.0))
+                           params.get("lambda_1", 0.0), params.get("lambda_2", 0.0), tidal=tidal)
     h = src.h22(frequency_array, params["luminosity_distance"], params.get("phase", 0.0), f_ref)
     band = (frequency_array >= f_min) & (frequency_array <= f_max)     # source.py: frequency_bounds
     h = h * band
@@ -567,9 +575,9 @@ def time_delay_from_geocenter(vertex, ra, dec, gps):
 # ------------------------------------------------------------------------------------------------------------------
 # likelihood (bilby/gw/likelihood/base.py, bilby/gw/detector/interferometer.py, bilby/gw/utils.py)
 # ------------------------------------------------------------------------------------------------------------------
-def detector_strain(params, name, frequency_array, start_time, f_ref, f_min, f_max=np.inf):
+def detector_strain(params, name, frequency_array, start_time, f_ref, f_min, f_max=np.inf, tidal=True):
     """Interferometer.get_detector_response without a calibration model."""
-    hp, hc = polarizations(params, frequency_array, f_ref, f_min, f_max)
+    hp, hc = polarizations(params, frequency_array, f_ref, f_min, f_max, tidal)
     vertex, tensor = detector_geometry(name)
     fp, fc = antenna_response(tensor, params["ra"], params["dec"], params["geocent_time"], params["psi"])
     signal = fp * hp + fc * hc
@@ -582,13 +590,13 @@ def ln_i0(x):
     return math.log(ive(0, x)) + abs(x)
 
 
-def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalization=False):
+def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalization=False, tidal=True, f_max_waveform=np.inf):
     """``ifos``: list of dicts with name, frequency_array, data, psd, mask, start_time, duration."""
     d_inner_h, opt = 0.0 + 0.0j, 0.0
     for ifo in ifos:
         m = ifo["mask"]
         fa = ifo["frequency_array"]
-        h = detector_strain(params, ifo["name"], fa, ifo["start_time"], f_ref, f_min_waveform)
+        h = detector_strain(params, ifo["name"], fa, ifo["start_time"], f_ref, f_min_waveform, f_max_waveform, tidal)
         d_inner_h += 4.0 / ifo["duration"] * np.sum(np.conj(ifo["data"][m]) * h[m] / ifo["psd"][m])
         opt += (4.0 / ifo["duration"] * np.sum(np.conj(h[m]) * h[m] / ifo["psd"][m])).real
     if phase_marginalization:

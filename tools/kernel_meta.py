@@ -16,11 +16,16 @@ def kernel_table(lib):
     data = open(lib, "rb").read()
     starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
     out = {}
-    with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
-        tmp.write(data[starts[1]:])
-        tmp.flush()
-        notes = subprocess.run([LLVM + "llvm-readelf", "--notes", tmp.name], capture_output=True, text=True).stdout
-        dis = subprocess.run([LLVM + "llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", tmp.name], capture_output=True, text=True).stdout
+    notes, dis = "", ""
+    for start in starts[1:]:          # one embedded code object per translation unit (the first ELF is the host library itself)
+        with tempfile.NamedTemporaryFile(suffix=".co") as tmp:
+            tmp.write(data[start:])
+            tmp.flush()
+            n = subprocess.run([LLVM + "llvm-readelf", "--notes", tmp.name], capture_output=True, text=True).stdout
+            if "amdhsa.kernels" not in n:
+                continue
+            notes += n
+            dis += subprocess.run([LLVM + "llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", tmp.name], capture_output=True, text=True).stdout
     name = None
     for line in notes.splitlines():
         m = re.search(r"\.name:\s+(\S+)", line)
