@@ -295,6 +295,11 @@ int64_t nmma_gw_n_bins(const nmma_gw_handle* h);
 int32_t nmma_gw_profile_begin(nmma_gw_handle* h, int32_t max_launches);
 int32_t nmma_gw_profile_end(nmma_gw_handle* h, double* kernel_ms_total, int32_t* n_launches);
 
+/* MultiMessengerLikelihood.sub_log_likelihood for a batch (joint/joint_likelihood.py:62-67): out_dev[b] = sum_k parts[k][b] in
+ * messenger order, NMMA_LOGL_FLOOR where the sum is not finite or a messenger already returned the floor.
+ * parts_dev: HOST array of n_parts (1..8) device pointers to [B] doubles. */
+int32_t nmma_logl_sum_floor(const double* const* parts_dev, int32_t n_parts, int64_t B, double* out_dev, int32_t device, void* stream);
+
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                              float* coeff_dev, void* stream);

@@ -113,6 +113,7 @@ PROTOTYPES = {
                                    C.c_void_p]),
     "nmma_gw_loglike_ratio": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double,
                                          C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_logl_sum_floor": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
     "nmma_gw_destroy": (None, [C.c_void_p]),
     "nmma_gw_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -315,6 +315,23 @@ __global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict_
     }
 }
 
+// =======================================================================================
+// sum over messengers + floor (MultiMessengerLikelihood.sub_log_likelihood, joint/joint_likelihood.py:62-67)
+// =======================================================================================
+struct LoglParts {
+    const double* p[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void logl_sum_floor_kernel(const LoglParts parts, const long B, double* __restrict__ out) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double total = 0.0;
+    for (int k = 0; k < parts.n; ++k) total += parts.p[k][b];      // messenger order, like Python's sum()
+    // a messenger's own floor (-1.797e308) plus anything stays at or below the floor (two floors overflow to -inf):
+    // `logl if np.isfinite(logl) else nan_to_num(-inf)`, and a floored messenger floors the sum
+    out[b] = (isfinite(total) && total > NMMA_LOGL_FLOOR) ? total : NMMA_LOGL_FLOOR;
+}
+
 }  // namespace nmma
 
 // =======================================================================================
@@ -364,6 +381,23 @@ int32_t nmma_gw_loglike_ratio(const double* strain_dev, const double* data_dev, 
 #undef NM_GW
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_gw_loglike_ratio launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_logl_sum_floor(const double* const* parts_dev, int32_t n_parts, int64_t B, double* out_dev, int32_t device, void* stream) {
+    using namespace nmma;
+    if (!parts_dev || n_parts < 1 || n_parts > 8 || B < 0 || !out_dev) return fail("nmma_logl_sum_floor: bad argument (1..8 messengers)");
+    if (B == 0) return 0;
+    LoglParts parts{};
+    parts.n = n_parts;
+    for (int k = 0; k < n_parts; ++k) {
+        if (!parts_dev[k]) return fail("nmma_logl_sum_floor: null messenger array");
+        parts.p[k] = parts_dev[k];
+    }
+    GW_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(logl_sum_floor_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), parts, (long)B, out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_logl_sum_floor launch failed: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -95,16 +95,18 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
 
     # ---- batched path ---------------------------------------------------------------------
     def log_likelihood_batch(self, theta, names=None, external_logl=None, external_lc=None):
-        """Sum over messengers for every row of ``theta`` with the reference's floor.
+        """``log_likelihood`` for every row of ``theta`` (core/base.py:77-82 with joint_likelihood.py:62-67 inside): each
+        messenger's per-row log-likelihood, summed in messenger order and floored by one HIP kernel
+        (``nmma_logl_sum_floor``), then the JOINT likelihood's own Constraint priors on the converted columns.
 
-        EM messengers (anything with ``log_likelihood_batch``) run on the GPU; an
-        :class:`ExternalLogLikelihood` takes its values from ``external_logl[name]`` (torch tensor on the
-        device, or numpy).  torch in -> torch out, numpy in -> numpy out."""
+        Messengers with ``log_likelihood_batch`` (EM, GW) run on the GPU; an :class:`ExternalLogLikelihood` takes its values from
+        ``external_logl[name]`` (torch tensor on the device, or numpy).  torch in -> torch out, numpy in -> numpy out."""
+        import ctypes as C
         import torch
         from .. import _lib as L
         external_logl = external_logl or {}
         as_torch = isinstance(theta, torch.Tensor)
-        total, dev = None, None
+        parts, dev = [], None
         for lh in self.likelihoods:
             if isinstance(lh, ExternalLogLikelihood):
                 if lh.name not in external_logl:
@@ -118,10 +120,46 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
             part = part if isinstance(part, torch.Tensor) else torch.as_tensor(np.asarray(part, dtype=np.float64))
             if dev is None and part.is_cuda:
                 dev = part.device
-            total = part if total is None else total.to(part.device if part.is_cuda else total.device) + \
-                part.to(total.device if total.is_cuda else part.device)
-        # a messenger's own floor (-1.797e308) plus anything stays below every finite log-likelihood and is re-floored
-        # here exactly like the reference's `if np.isfinite(logl)` (the sum of two floors overflows to -inf)
-        floor = torch.full_like(total, LOGL_FLOOR)
-        total = torch.where(torch.isfinite(total) & (total > LOGL_FLOOR), total, floor)
+            parts.append(part)
+        if dev is None:
+            dev = torch.device("cuda:0")
+        parts = [p.to(dev, dtype=torch.float64).contiguous() for p in parts]
+        n = parts[0].shape[0]
+        if any(p.shape != (n,) for p in parts):
+            raise L.NMMAHipError(f"messengers returned different batch sizes: {[tuple(p.shape) for p in parts]}")
+        total = torch.empty(n, dtype=torch.float64, device=dev)
+        if n:
+            ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+            L.check(L.load_library().nmma_logl_sum_floor(ptrs, len(parts), n, C.c_void_p(total.data_ptr()), dev.index or 0,
+                                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                    "nmma_logl_sum_floor")
+        if self.constraints:
+            total = self.floor_constrained_rows(total, self._columns(theta, names))
         return total if as_torch else total.cpu().numpy()
+
+    def _columns(self, theta, names):
+        """Sampled columns + fixed priors as a dict of arrays: what ``parameter_conversion`` and the constraints work on."""
+        import torch
+        from ..core.base import fixed_value, is_constraint
+        from .. import _lib as L
+        if names is None:
+            names = [k for k, p in self.priors.items() if fixed_value(p) is None and not is_constraint(p)]
+        host = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta, dtype=float)
+        cols = {n: host[:, i] for i, n in enumerate(names)}
+        for key, prior in self.priors.items():
+            val = fixed_value(prior)
+            if val is not None and key not in cols:
+                cols[key] = np.full(len(host), val)
+        return cols
+
+    def floor_constrained_rows(self, logl, columns):
+        """As the mixin's, with a clear error when a constrained key is neither a column nor derived by a messenger's
+        conversion (the reference would raise the same KeyError per sample, core/base.py:67-68)."""
+        from .. import _lib as L
+        converted = self.parameter_conversion(dict(columns))
+        missing = [k for k in self.constraints if k not in converted]
+        if missing:
+            raise L.NMMAHipError(f"Constraint priors on {missing} cannot be evaluated on the batched path: no messenger's "
+                                 "parameter_conversion derives them from the sampled columns")
+        from ..core.base import floor_rows
+        return floor_rows(logl, self.evaluate_constraints(converted))

@@ -130,6 +130,67 @@ def test_config5_joint_em_leg_at_16384():
         assert mm.log_likelihood(p) == pytest.approx(got[r], rel=1e-12)
 
 
+def test_config5_joint_gw_plus_em_from_parameters_at_16384():
+    """BASELINE config 5 from PARAMETERS: IMRPhenomD_NRTidalv2 GW log-likelihood (3 detectors, 128 s at 4096 Hz: 259 585 bins in
+    band) + Bu2019lm EM log-likelihood, one joint theta[16 384, 17] whose luminosity_distance and theta_jn feed both messengers,
+    summed and floored by MultiMessengerLikelihood (joint/joint_likelihood.py:62-67).  Properties at the full batch + an oracle spot
+    check of both legs (the GW oracle restates third-party algorithms: parity unpinned against bilby / lalsimulation)."""
+    import time
+    import torch
+    from nmma_amd import synthetic as syn
+    from nmma_amd.gw import GravitationalWaveTransientLikelihood, WaveformGenerator
+    from nmma_amd.joint.joint_likelihood import MultiMessengerLikelihood
+    from oracle import nmma_oracle as orc
+    from tests.gw_helpers import make_case, oracle_loglike_ratio
+    from oracle import gw_waveform_oracle as gwo
+    em_names = ["luminosity_distance", "KNphi", "theta_jn", "timeshift", "log10_mej_dyn", "log10_mej_wind"]
+    case = cases._base(seed=1234, names=em_names)            # config 2's model and photometry, inclination from theta_jn
+    _, _, em = plugin_from_case(case)
+    gwc = make_case(seed=55, duration=128.0, sampling_frequency=4096.0, minimum_frequency=23.0)
+    B = 16384
+    gw_names = [n for n in syn.GW_NAMES if n != "phase"]     # phase marginalised, as NMMA's GW170817 runs do
+    names = gw_names + [n for n in em_names if n not in gw_names]
+    _, th_gw = syn.draw_gw_theta(77, B, centre=gwc["injection"], names=gw_names, width=0.3)
+    _, th_em = syn.draw_theta(78, B, em_names)
+    theta = np.concatenate([th_gw, th_em[:, [em_names.index(n) for n in names[len(gw_names):]]]], axis=1)
+    theta[5, names.index("timeshift")] = np.nan              # EM failure -> joint floor
+    theta[7, names.index("chirp_mass")] = np.nan             # GW failure -> joint floor
+    theta[9, names.index("lambda_1")] = -5.0                 # unphysical -> GW floor -> joint floor
+    priors = {n: SimplePrior(0.0, 1.0) for n in names}
+    wg = WaveformGenerator(128.0, 4096.0, waveform_arguments=gwc["waveform_arguments"])
+    gw = GravitationalWaveTransientLikelihood(priors, gwc["ifos"], wg, phase_marginalization=True)
+    mm = MultiMessengerLikelihood([gw, em], priors)
+
+    def fn(th):
+        return mm.log_likelihood_batch(torch.as_tensor(th, device="cuda:0"), names).cpu().numpy()
+
+    fn(theta[:64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a = _properties(fn, theta, 1000)
+    print(f"config 5 joint GW+EM from parameters: 4 evaluations of <= {B} rows in {time.perf_counter() - t0:.2f} s")
+    assert a[5] == FLOOR and a[7] == FLOOR and a[9] == FLOOR and (a > FLOOR).sum() == B - 3
+    rows = np.concatenate([np.linspace(0, B - 1, 20).astype(int), [5, 7, 9, 10]])
+    olik = oracle_from_case(case, use_scipy=False)
+    em_cols = [names.index(n) for n in em_names]
+    em_want = orc.log_likelihood_batch(olik, em_names, theta[np.ix_(rows, em_cols)])
+    good = np.array([r not in (7, 9) for r in rows])
+    gw_want = np.full(len(rows), FLOOR)
+    gw_want[good] = oracle_loglike_ratio(gwc, gw_names, theta[np.ix_(rows[good], np.arange(len(gw_names)))], phase_marginalization=True) \
+        + gwo.noise_log_likelihood(gwc["oracle_ifos"])
+    want = em_want + gw_want
+    want = np.where(np.isfinite(want) & (want > FLOOR), want, FLOOR)      # joint_likelihood.py:64-67
+    floor = want == FLOOR
+    assert np.array_equal(a[rows] == FLOOR, floor)
+    err = rel_err(a[rows][~floor], want[~floor])
+    print(f"  oracle spot check of {int((~floor).sum())} rows: max rel err {err.max():.3e}")
+    assert err.max() <= LOGL_RTOL
+    # the per-sample reference API (one dict per call) gives the same numbers
+    for r in (0, 4097):
+        p = dict(zip(names, (float(v) for v in theta[r])))
+        assert mm.log_likelihood(p) == pytest.approx(a[r], rel=1e-9)
+
+
 def test_constraints_on_the_batch_path_match_per_sample_calls():
     """Constraint priors (core/base.py:67-68): the batched entry point floors exactly the rows the per-sample
     log_likelihood floors."""
