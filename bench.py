@@ -16,7 +16,8 @@ Without a launcher (RANK unset) and N > 1 the script starts ``torch.distributed.
 before anything here touches the GPU -- and relays the child's JSON line.  ``--scaling weak`` (default) keeps 4096
 live points per GPU; ``--scaling strong`` splits ONE 4096-point batch over the ranks (north_star's 8-GPU target).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
+With N > 1 BOTH scaling modes are measured in the one invocation: the line's top level is the mode ``--scaling`` names, the
+other one sits under ``other_scaling``.  Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
 MLP on the f32 MFMA pipe, SVD reconstruction, interpolation and likelihood terms in one launch)
 against the dense fp32 MFMA peak with the ALGORITHMIC flop count of SURVEY.md section 8d
 (sum over filters of 2*NP*NH + 2*NH*NC + 2*NC*NT = 369 384 flop/eval); its duration is
@@ -113,122 +114,135 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from nmma_amd import synthetic as syn
-    from tests import cases
-    from tests.helpers import engine_from_case
+    from nmma_amd.engine import EMEngine
 
-    case = cases.case_c2_default()          # model + photometry of BASELINE config 2
+    case = syn.config2_case()               # model + photometry of BASELINE config 2
     if use_dist and not share_gpu and os.environ.get("NMMA_BENCH_BLOCKING") != "1":
         # the collective of one step overlaps the kernel of the next: leave LDS on every CU for RCCL's kernels (a ring of 2 item
         # slots instead of 4 costs the likelihood kernel 1.2 % and frees 57 KiB per CU)
         os.environ.setdefault("NMMA_EM_RING", "2")
-    eng = engine_from_case(case, device=local_rank)
-    if args.scaling == "strong":
-        from nmma_amd.parallel import shard_bounds
-        lo, hi = shard_bounds(args.batch, world, rank)
-        B = hi - lo
-    else:
-        B = args.batch
-    global_batch = args.batch if args.scaling == "strong" else world * args.batch
+    eng = EMEngine.from_case(case, device=local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    thetas = [torch.as_tensor(syn.draw_theta(1000 + 97 * rank + i, B, case["names"])[1], device=dev)
-              for i in range(N_THETA_SETS)]
-    out = torch.empty(B, dtype=torch.float64, device=dev)
-    slot = -(-global_batch // world)         # equal-sized all-gather slots (ragged strong-scaling shards are padded)
-    send = torch.zeros(slot, dtype=torch.float64, device=dev) if use_dist else None
-    gathered = torch.empty(world * slot, dtype=torch.float64, device=dev) if use_dist else None
-
-    # N > 1: the all-gather of step i runs on a second stream while the kernel of step i + 1 runs on the first (two logL
-    # buffers; events order "kernel i -> gather i" and "gather i -> kernel i + 2").  Host cost per step is the same as the
-    # blocking form (~38 us, tools/overlap_probe.py), but the GPU no longer serialises kernel + collective.
-    # NMMA_BENCH_BLOCKING=1 keeps everything on one stream.
-    pipelined = use_dist and not share_gpu and slot == B and os.environ.get("NMMA_BENCH_BLOCKING") != "1"
-    if pipelined:
-        s_eval, s_coll = torch.cuda.Stream(), torch.cuda.Stream()
-        outs = [out, torch.empty_like(out)]
-        gathers = [gathered, torch.empty_like(gathered)]
-        ev_eval = [torch.cuda.Event() for _ in range(2)]
-        ev_coll = [torch.cuda.Event() for _ in range(2)]
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(s_coll)            # torch.distributed enqueues on the current stream
-
-    def step(i):
-        if pipelined:
-            b = i & 1
-            if i >= 2:
-                s_eval.wait_event(ev_coll[b])    # the gather that read outs[b] two steps ago
-            eng.loglike(thetas[i % N_THETA_SETS], out=outs[b], stream=s_eval)
-            ev_eval[b].record(s_eval)
-            s_coll.wait_event(ev_eval[b])
-            dist.all_gather_into_tensor(gathers[b], outs[b])
-            ev_coll[b].record(s_coll)
-            return
-        eng.loglike(thetas[i % N_THETA_SETS], out=out)
-        if use_dist:
-            if share_gpu:
-                send[:B] = out
-                parts = [torch.empty(slot, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, send.cpu())
-            elif slot == B:
-                dist.all_gather_into_tensor(gathered, out)
-            else:
-                send[:B] = out
-                dist.all_gather_into_tensor(gathered, send)
-
-    # A full collection of Python's garbage collector takes ~75 ms with torch imported (2 400 launches' worth) and fires
-    # whenever enough container objects have been allocated: none inside the timed region
     import gc
-    gc.collect()
-    gc.disable()
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
-    # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
-    # by the dispatch latency behind the start event); with a collective between launches, single launches.
-    os.environ["NMMA_PROFILE_GROUP"] = "8" if world == 1 else "1"
-    os.environ["NMMA_PROFILE_STRIDE"] = "2" if world == 1 else "4"
-    eng.profile_begin(args.steps)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_end()
-    gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # sanity: the numbers we just timed are real likelihood values
-    last = out.cpu().numpy()
-    assert np.all(np.isfinite(last)) and np.all(last < 0)
+    def measure(scaling):
+        """W untimed + K timed steps of one scaling mode: (elapsed max over ranks, rows of this rank, global batch, pipelined, prof)."""
+        if scaling == "strong":
+            from nmma_amd.parallel import shard_bounds
+            lo, hi = shard_bounds(args.batch, world, rank)
+            B = hi - lo
+        else:
+            B = args.batch
+        global_batch = args.batch if scaling == "strong" else world * args.batch
+        thetas = [torch.as_tensor(syn.draw_theta(1000 + 97 * rank + i, B, case["names"])[1], device=dev)
+                  for i in range(N_THETA_SETS)]
+        out = torch.empty(B, dtype=torch.float64, device=dev)
+        slot = -(-global_batch // world)         # equal-sized all-gather slots (ragged strong-scaling shards are padded)
+        send = torch.zeros(slot, dtype=torch.float64, device=dev) if use_dist else None
+        gathered = torch.empty(world * slot, dtype=torch.float64, device=dev) if use_dist else None
+
+        # N > 1: the all-gather of step i runs on a second stream while the kernel of step i + 1 runs on the first (two logL
+        # buffers; events order "kernel i -> gather i" and "gather i -> kernel i + 2").  Host cost per step is the same as the
+        # blocking form (~38 us, tools/overlap_probe.py), but the GPU no longer serialises kernel + collective.
+        # NMMA_BENCH_BLOCKING=1 keeps everything on one stream.
+        pipelined = use_dist and not share_gpu and slot == B and os.environ.get("NMMA_BENCH_BLOCKING") != "1"
+        prev_stream = torch.cuda.current_stream()
+        if pipelined:
+            s_eval, s_coll = torch.cuda.Stream(), torch.cuda.Stream()
+            outs = [out, torch.empty_like(out)]
+            gathers = [gathered, torch.empty_like(gathered)]
+            ev_eval = [torch.cuda.Event() for _ in range(2)]
+            ev_coll = [torch.cuda.Event() for _ in range(2)]
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(s_coll)            # torch.distributed enqueues on the current stream
+
+        def step(i):
+            if pipelined:
+                b = i & 1
+                if i >= 2:
+                    s_eval.wait_event(ev_coll[b])    # the gather that read outs[b] two steps ago
+                eng.loglike(thetas[i % N_THETA_SETS], out=outs[b], stream=s_eval)
+                ev_eval[b].record(s_eval)
+                s_coll.wait_event(ev_eval[b])
+                dist.all_gather_into_tensor(gathers[b], outs[b])
+                ev_coll[b].record(s_coll)
+                return
+            eng.loglike(thetas[i % N_THETA_SETS], out=out)
+            if use_dist:
+                if share_gpu:
+                    send[:B] = out
+                    parts = [torch.empty(slot, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, send.cpu())
+                elif slot == B:
+                    dist.all_gather_into_tensor(gathered, out)
+                else:
+                    send[:B] = out
+                    dist.all_gather_into_tensor(gathered, send)
+
+        # A full collection of Python's garbage collector takes ~75 ms with torch imported (2 400 launches' worth) and fires
+        # whenever enough container objects have been allocated: none inside the timed region
+        gc.collect()
+        gc.disable()
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
+        # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
+        # by the dispatch latency behind the start event); with a collective between launches, single launches.
+        os.environ["NMMA_PROFILE_GROUP"] = "8" if world == 1 else "1"
+        os.environ["NMMA_PROFILE_STRIDE"] = "2" if world == 1 else "4"
+        eng.profile_begin(args.steps)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_end()
+        gc.enable()
+        if pipelined:
+            torch.cuda.set_stream(prev_stream)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # sanity: the numbers we just timed are real likelihood values
+        last = (outs[(args.steps - 1) & 1] if pipelined else out).cpu().numpy()
+        assert np.all(np.isfinite(last)) and np.all(last < 0)
+        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry())
+
+    def exchange_label(m):
+        if world == 1:
+            return "none"
+        if share_gpu:
+            return "gloo all_gather (TEST MODE: ranks share one GPU)"
+        return "RCCL all_gather of logL per step" + (", pipelined with the next evaluation" if m["pipelined"] else "")
+
+    main_mode = measure(args.scaling)
+    # with more than one GPU the other scaling mode is measured in the same invocation and reported under "other_scaling"
+    other = measure("strong" if args.scaling == "weak" else "weak") if world > 1 else None
 
     if rank == 0:
-        geom = eng.last_launch_geometry()
+        m = main_mode
+        B, global_batch, prof = m["B"], m["global_batch"], m["prof"]
         evals = global_batch * args.steps
         fused_ms = prof["fused_ms_total"] / max(1, prof["n_launches"])
         achieved = eng.flops_per_eval * B / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None
         line = {
             "metric": "log-likelihood evals/sec (Bu2019lm, AT2017gfo filters)",
-            "value": evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "value": evals / m["elapsed"], "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 MLP + f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: Bu2019lm SVD surrogate (NP=4, NH=2048, NC=10, NT=211), "
                                    "AT2017gfo 6-filter synthetic photometry (99 epochs, 1 upper limit), "
                                    f"batch={B} live points per GPU, sigma_sys=1, detection_limit=inf",
-                       "batch_per_gpu": B, "global_batch": global_batch,
-                       "exchange": ("gloo all_gather (TEST MODE: ranks share one GPU)" if share_gpu else
-                                    ("RCCL all_gather of logL per step, pipelined with the next evaluation" if pipelined else
-                                     "RCCL all_gather of logL per step")) if world > 1 else "none",
-                       "launch": geom},
+                       "batch_per_gpu": B, "global_batch": global_batch, "exchange": exchange_label(m), "launch": m["geom"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
                          "traffic": TRAFFIC, "traffic_source": (f"{TRAFFIC_SOURCE}: rocprofv3 --pmc passes of this command, "
@@ -237,6 +251,13 @@ def main():
                          "kernel_launches_timed": prof["n_launches"], "flops_per_eval": eng.flops_per_eval,
                          "traffic_unit": "bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"},
         }
+        if other is not None:
+            o_scaling = "strong" if args.scaling == "weak" else "weak"
+            o_ms = other["prof"]["fused_ms_total"] / max(1, other["prof"]["n_launches"])
+            line["other_scaling"] = {"scaling": o_scaling, "value": other["global_batch"] * args.steps / other["elapsed"],
+                                     "unit": "evals/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
+                                     "batch_per_gpu": other["B"], "global_batch": other["global_batch"],
+                                     "exchange": exchange_label(other), "kernel_ms": o_ms}
         if not args.no_cpu_baseline and world == 1:      # (the profiled command lines pass --no-cpu-baseline: device launches only)
             line["host_call_ms"] = host_call_ms(eng, case, syn)
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
@@ -274,10 +295,9 @@ def host_call_ms(eng, case, syn):
 
 def _oracle_rows():
     from nmma_amd import synthetic as syn
-    from tests import cases
-    from tests.helpers import oracle_from_case
-    case = cases.case_c2_default()
-    lik = oracle_from_case(case, use_scipy=True)
+    from oracle.nmma_oracle import likelihood_from_case
+    case = syn.config2_case()
+    lik = likelihood_from_case(case, use_scipy=True)
     names, theta = syn.draw_theta(555, 4096, case["names"])
     return lik, [dict(zip(names, (float(v) for v in r))) for r in theta]
 
@@ -338,8 +358,8 @@ def cpu_baseline(case, budget_s):
     except Exception:
         limiter = None
     from nmma_amd import synthetic as syn
-    from tests.helpers import oracle_from_case
-    lik = oracle_from_case(case, use_scipy=True)
+    from oracle.nmma_oracle import likelihood_from_case
+    lik = likelihood_from_case(case, use_scipy=True)
     names, theta = syn.draw_theta(555, 4096, case["names"])
     rows = [dict(zip(names, (float(v) for v in r))) for r in theta]
     for r in rows[:20]:

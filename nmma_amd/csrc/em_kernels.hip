@@ -959,6 +959,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 for (int w = 0; w < NSLICE; ++w) cmine += pbuf[((w * R + rb) * 16 + sidx) * PSTR + gi];
                 cmine += b2l[gi];
                 cdl[(vwave * (64 / 16) + (lane >> 4)) * 16 + gi] = (double)cmine;   // row: 16-lane slot of this wave
+                // a model filter nobody observed (nf == 0): its light curve still has to be a usable one -- a non-finite
+                // coefficient makes every node non-finite, the reference's sanity_check then floors the sample
+                // (em_likelihood.py:305-311; with data the NaN reaches the sum through the terms themselves)
+                if (nf == 0 && active && gi < NC && !(cmine - cmine == 0.f)) bad[s] = 1;
             }
             const double* crow = cdl + (vwave * 4 + ((lane & ~(G - 1)) >> 4)) * 16;     // the group's first slot
             // NCT > 0: exactly NCT coefficients, kept in registers; NCT == 0: any NC, re-read from LDS

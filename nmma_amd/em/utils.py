@@ -71,6 +71,21 @@ def setup_filtered_lc_data(light_curve_data, trigger_time):
     return (lc_times, lc_mags, lc_unc, trigger_time)
 
 
+def cut_data_to_time_range(data, args=None, trigger_time=0.0, tmin=0, tmax=np.inf):
+    """utils.py:233-253: keep the rows of every filter whose time since the trigger lies in [data_tmin, data_tmax]
+    (taken from ``args`` when it has them), dropping filters left empty.  ``data``: ``{filt: {time, mag, mag_error}}`` in MJD."""
+    tmin = getattr(args, "data_tmin", tmin)
+    tmax = getattr(args, "data_tmax", tmax)
+    for filt in list(data.keys()):
+        detector_time = np.asarray(data[filt]["time"]) - trigger_time
+        mask = (tmin <= detector_time) & (detector_time <= tmax)
+        if not np.any(mask):
+            del data[filt]
+        else:
+            data[filt] = {k: np.asarray(data[filt][k])[mask] for k in ("time", "mag", "mag_error")}
+    return data
+
+
 def _prior_bounds(priors, key, default=None):
     """(minimum, maximum) of a prior; a plain number or delta function counts as both."""
     if key not in priors:

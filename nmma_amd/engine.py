@@ -221,8 +221,22 @@ class EMEngine:
                                  "ebv_coeff, or extinction_law='P92_SMC_host' with filter_nu0 / filter_lambdas")
 
         # photometry + systematics
-        obs = self.observed_filters
-        cfg.n_obs_filters = len(obs)
+        obs = list(self.observed_filters)
+        srcs = dict(sources or {f: [f] for f in obs})
+        self.n_real_observed = len(obs)
+        if obs and model_kind == "svd":
+            # the reference evaluates and sanity-checks EVERY model filter (em_likelihood.py:305-311), observed or not: a model
+            # filter no observed band draws on rides along as a band without data (its coefficients are checked, nothing else)
+            used = {mf for f in obs for mf in srcs[f]}
+            times, mags, sigmas = (dict(d) for d in data)
+            for mf in model_filters:
+                if mf not in used:
+                    ghost = f"__unobserved__{mf}"
+                    obs.append(ghost)
+                    srcs[ghost] = [mf]
+                    times[ghost] = mags[ghost] = sigmas[ghost] = np.zeros(0)
+            data = (times, mags, sigmas)
+        cfg.n_obs_filters = self._n_obs_uploaded = len(obs)
         if obs:
             times, mags, sigmas = data
             offs = np.zeros(len(obs) + 1, dtype=np.int32)
@@ -234,7 +248,6 @@ class EMEngine:
                                  if offs[-1] else np.zeros(0))
             dt, dm, ds = cat(times), cat(mags), cat(sigmas)
             lim = _f64([np.inf if detection_limit is None else detection_limit.get(f, np.inf) for f in obs])
-            srcs = sources or {f: [f] for f in obs}
             nsrc = _i32([len(srcs[f]) for f in obs])
             src = np.zeros((len(obs), L.MAX_SOURCES), dtype=np.int32)
             for i, f in enumerate(obs):
@@ -275,6 +288,9 @@ class EMEngine:
         mode = spec["mode"]
         for i, f in enumerate(obs):
             off[i] = len(slots)
+            if f.startswith("__unobserved__"):          # a band without data: no systematics to evaluate
+                kind[i], const[i] = L.SYS_CONST, 1.0
+                continue
             if mode == "budget":
                 kind[i], const[i] = L.SYS_CONST, float(spec["values"][f])
                 continue
@@ -297,6 +313,24 @@ class EMEngine:
                     node_t.append(float(t))
         off[len(obs)] = len(slots)
         return kind, _f64(const), nn, off, slots, _f64(node_t if node_t else [0.0])
+
+    @classmethod
+    def from_case(cls, case, device=0):
+        """Engine for a case dict of ``nmma_amd.synthetic.make_case`` (what bench.py, smoke() and the parity tests build)."""
+        from .em.utils import FILTER_AVERAGES, resolve_sources
+        obs = list(case["observed_filters"])
+        lim = case["detection_limit"]
+        if not isinstance(lim, dict):
+            lim = {f: float(lim) for f in obs}
+        return cls(case["svd"], case["model_filters"], case["model_parameters"], case["names"],
+                   fixed=case.get("fixed"), sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
+                   data=case["data"], observed_filters=obs,
+                   sources=resolve_sources(obs, case["model_filters"],
+                                           known_filters=[f for f in obs if f not in FILTER_AVERAGES]),
+                   detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
+                   filter_nu0=case.get("filter_nu0"),
+                   extinction_law="P92_SMC_host" if case.get("filter_nu0") is not None else None,
+                   device=device)
 
     # ------------------------------------------------------------------ calls
     def _dev_theta(self, theta):
@@ -353,13 +387,14 @@ class EMEngine:
         """(chi[O, B], gp[O, B]) per observed filter (em_likelihood.py:337-352)."""
         import torch
         t = self._dev_theta(theta)
-        n_o = len(self.observed_filters)
+        n_o = self._n_obs_uploaded            # (incl. the bands without data that stand for unobserved model filters)
         chi = torch.empty((n_o, t.shape[0]), dtype=torch.float64, device=t.device)
         gp = torch.empty_like(chi)
         L.check(self._lib.nmma_em_loglike_parts(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0),
                                                 C.c_void_p(chi.data_ptr()), C.c_void_p(gp.data_ptr()),
                                                 self._stream()), "nmma_em_loglike_parts")
-        return chi, gp
+        n_real = len(self.observed_filters)
+        return chi[:n_real], gp[:n_real]
 
     def lightcurves(self, theta):
         """(obs_times[B, NS], mag[B, M, NS]) -- gen_detector_lc for every row (model.py:352-404)."""

@@ -53,3 +53,56 @@ class ShardedEvaluator:
             a, b = shard_bounds(n, self.world, r)
             pieces.append(out[r * slot: r * slot + (b - a)])
         return torch.cat(pieces)
+
+
+class MultiDeviceEvaluator:
+    """ONE process driving several GPUs ("single process x 8 devices (ctypes + streams) avoids MPI").
+
+    ``engine_factory(device) -> engine`` builds one engine per entry of ``devices`` (an ``EMEngine``, a ``GWEngine`` -- anything
+    with ``loglike(theta, out=..., stream=...)`` or a plain callable ``theta_shard -> logL_shard`` on that device).  Every
+    ``evaluate`` splits the rows with :func:`shard_bounds`, copies each shard to its device (peer copy over xGMI when theta
+    lives on a GPU), launches all shards asynchronously on per-device streams -- the C ABI only enqueues, so one host thread
+    keeps every device busy -- and gathers the pieces on ``devices[0]``.  No collective library is involved."""
+
+    def __init__(self, engine_factory, devices):
+        import torch
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("MultiDeviceEvaluator needs at least one device")
+        self.engines = [engine_factory(d) for d in self.devices]
+        self.streams = [torch.cuda.Stream(device=d) for d in self.devices]
+
+    def evaluate(self, theta):
+        import torch
+        if not isinstance(theta, torch.Tensor):
+            theta = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64))
+        n, world = theta.shape[0], len(self.devices)
+        home = torch.device(f"cuda:{self.devices[0]}")
+        out = torch.empty(n, dtype=torch.float64, device=home)
+        src_stream = torch.cuda.current_stream(theta.device) if theta.is_cuda else None
+        pieces = []
+        for r, (d, eng, s) in enumerate(zip(self.devices, self.engines, self.streams)):
+            lo, hi = shard_bounds(n, world, r)
+            if hi == lo:
+                continue
+            with torch.cuda.device(d), torch.cuda.stream(s):
+                if src_stream is not None:
+                    s.wait_stream(src_stream)          # theta may still be in flight on its producer's stream
+                shard = theta[lo:hi].to(f"cuda:{d}", non_blocking=True).contiguous()
+                if hasattr(eng, "loglike"):
+                    part = eng.loglike(shard, stream=s)
+                elif hasattr(eng, "loglike_ratio"):
+                    part = eng.loglike_ratio(shard, stream=s)
+                else:
+                    part = eng(shard)
+                pieces.append((lo, hi, part, s))
+        cur = torch.cuda.current_stream(home)
+        for lo, hi, part, s in pieces:
+            cur.wait_stream(s)
+            out[lo:hi].copy_(part, non_blocking=True)
+        return out
+
+    def close(self):
+        for eng in self.engines:
+            if hasattr(eng, "close"):
+                eng.close()

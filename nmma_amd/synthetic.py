@@ -175,6 +175,33 @@ def draw_theta(seed, batch, names=None):
     return names, np.stack(cols, axis=1)
 
 
+def make_case(seed=1234, model="Bu2019lm", filters=None, counts=None, batch=64, n_hidden=2048,
+          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0), n_coeff=10, tt=None):
+    """One seeded likelihood configuration as a plain dict of inputs (model tensors, photometry, systematics spec, theta):
+    the defaults are BASELINE config 2 (Bu2019lm-shaped surrogate, 6 AT2017gfo filters with 13/19/20/18/15/14 epochs, one
+    upper limit, sigma_sys = 1 mag, the SVD training grid as sample_times)."""
+    filters = list(filters or AT2017GFO_FILTERS)
+    mp, svd = make_svd_model(seed, filters, model=model, n_hidden=n_hidden, n_coeff=n_coeff, tt=tt)
+    grid = flat_lcdm_grid(1.0, 200.0)
+    data = make_photometry(seed + 1, svd, mp, filters=filters, counts=counts,
+                               cosmo_grid=grid, upper_limit_filter=upper_limit_filter,
+                               t_range=t_range)
+    names, theta = draw_theta(seed + 2, batch, names)
+    return dict(model=model, model_parameters=mp, svd=svd, model_filters=filters,
+                sample_times=sample_times, cosmo_grid=grid, data=data,
+                observed_filters=filters, detection_limit=np.inf,
+                systematics=dict(mode="budget", values={f: 1.0 for f in filters}),
+                systematics_ref=dict(error_budget=1.0, systematics_file=None),
+                names=names, theta=theta)
+
+
+
+
+def config2_case():
+    """BASELINE config 2: the headline workload of bench.py."""
+    return make_case()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Gravitational-wave leg (BASELINE config 5: "GW170817 + AT2017gfo synthetic")
 # ---------------------------------------------------------------------------------------------------------------------

@@ -20,21 +20,8 @@ from nmma_amd import synthetic as syn
 GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _base(seed=1234, model="Bu2019lm", filters=None, counts=None, batch=64, n_hidden=2048,
-          sample_times=None, names=None, upper_limit_filter="ps1::i", t_range=(0.5, 14.0), n_coeff=10, tt=None):
-    filters = list(filters or syn.AT2017GFO_FILTERS)
-    mp, svd = syn.make_svd_model(seed, filters, model=model, n_hidden=n_hidden, n_coeff=n_coeff, tt=tt)
-    grid = syn.flat_lcdm_grid(1.0, 200.0)
-    data = syn.make_photometry(seed + 1, svd, mp, filters=filters, counts=counts,
-                               cosmo_grid=grid, upper_limit_filter=upper_limit_filter,
-                               t_range=t_range)
-    names, theta = syn.draw_theta(seed + 2, batch, names)
-    return dict(model=model, model_parameters=mp, svd=svd, model_filters=filters,
-                sample_times=sample_times, cosmo_grid=grid, data=data,
-                observed_filters=filters, detection_limit=np.inf,
-                systematics=dict(mode="budget", values={f: 1.0 for f in filters}),
-                systematics_ref=dict(error_budget=1.0, systematics_file=None),
-                names=names, theta=theta)
+#: the seeded case builder lives with the other synthetic inputs (bench.py and smoke() use it without importing tests/)
+_base = syn.make_case
 
 
 def case_c2_default():
@@ -236,6 +223,79 @@ def case_real_nets():
                 systematics_ref=dict(error_budget=1.0, systematics_file=None), names=names, theta=theta)
 
 
+AT2017GFO_TRIGGER_MJD = 57982.5285236896      # GW170817: 2017-08-17 12:41:04 UTC
+
+
+def at2017gfo_raw_photometry():
+    """The reference's example data set ``example_files/lightcurves/AT2017gfo.dat`` (141 rows, 9 filters, 3 upper limits) as the
+    arrays its reader produces -- committed as the fixture tests/golden/at2017gfo_photometry.npz by tools/make_golden_at2017gfo.py
+    (data, not source)."""
+    with np.load(os.path.join(GOLDEN_DIR, "at2017gfo_photometry.npz")) as z:
+        filters = [str(f) for f in z["filters"]]
+        return {f: {"time": z[f"{f}/time"].copy(), "mag": z[f"{f}/mag"].copy(), "mag_error": z[f"{f}/mag_error"].copy()}
+                for f in filters}
+
+
+def case_at2017gfo():
+    """The REAL AT2017gfo photometry (all 9 filters, 3 upper limits) through the reference's own preparation chain -- time cut
+    (utils.py:233-253), times relative to the trigger (:255-286), model-window check (:289-353) -- on the documented CLI grid
+    ``--tmin .1 --tmax 20 --dt .5`` with the sampled ``em_syserr`` of current NMMA priors.  The Bu2019lm surrogate itself is
+    synthetic (the trained networks are not in the reference tree); rows later than 14.5 d are cut because the model window
+    ends at 18.1 d for the earliest allowed trigger time (the reference raises otherwise)."""
+    from nmma_amd.em import utils as em_utils
+    raw = em_utils.cut_data_to_time_range(at2017gfo_raw_photometry(), None, AT2017GFO_TRIGGER_MJD, tmin=0.0, tmax=14.5)
+    filters = list(raw)
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind", "em_syserr"]
+    mp, svd = syn.make_svd_model(8734, filters, model="Bu2019lm")
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    times, mags, sigmas, _ = em_utils.setup_filtered_lc_data(raw, AT2017GFO_TRIGGER_MJD)
+    names, theta = syn.draw_theta(8736, 64, names)
+    # a synthetic surrogate does not know the real magnitudes: shift every filter's span so that the model passes through the data
+    # (keeps log L in a numerically meaningful range; the time stamps, error bars and limits stay the real ones)
+    for f in filters:
+        off = float(np.median(mags[f][np.isfinite(sigmas[f])])) - (5.0 * (5 + np.log10(40.0)) - 13.0)
+        svd[f]["mins"] = svd[f]["mins"] + off
+        svd[f]["maxs"] = svd[f]["maxs"] + off
+    return dict(model="Bu2019lm", model_parameters=mp, svd=svd, model_filters=filters,
+                sample_times=np.arange(0.1, 20.5, 0.5), cosmo_grid=grid, data=(times, mags, sigmas), raw_data=raw,
+                trigger_time=AT2017GFO_TRIGGER_MJD, data_window=(0.0, 14.5),
+                prior_bounds=dict(luminosity_distance=(1.0, 200.0), timeshift=(-2.0, 0.1)),
+                observed_filters=filters, detection_limit=np.inf,
+                systematics=dict(mode="param", name="em_syserr"),
+                systematics_ref=dict(error_budget=None, systematics_file=None), names=names, theta=theta)
+
+
+def case_unobserved_filter_overflow():
+    """A model filter NOBODY observed whose surrogate overflows for part of the prior: the reference evaluates every model
+    filter and its sanity_check floors a sample as soon as one of the curves is unusable (em_likelihood.py:305-311) -- here the
+    7th filter's leading coefficient is +inf exactly for the samples with a large first surrogate input (one hidden unit
+    relu(10 x_0 - 5) times a weight of 3e38 overflows fp32 above x_0 = 0.61), everything observed stays finite."""
+    filters = list(syn.AT2017GFO_FILTERS) + ["2massh"]
+    c = _base(seed=8934, filters=filters, batch=48)
+    obs = filters[:-1]
+    c["observed_filters"] = obs
+    c["data"] = tuple({f: d[f] for f in obs} for d in c["data"])
+    c["systematics"] = dict(mode="budget", values={f: 1.0 for f in obs})
+    t = c["svd"]["2massh"]
+    t["W1"][:, 0] = 0.0; t["W1"][0, 0] = 10.0
+    t["b1"][0] = -5.0
+    t["W2"][0, :] = 0.0; t["W2"][0, 0] = 3.0e38
+    return c
+
+
+def case_unobserved_filter_dead():
+    """A model filter nobody observed whose basis has a non-finite column: fewer than two finite nodes, the curve is all-inf
+    (model.py:381-404) and sanity_check floors EVERY sample."""
+    c = case_unobserved_filter_overflow()
+    c["svd"] = {f: dict(t) for f, t in c["svd"].items()}
+    mp, fresh = syn.make_svd_model(8934, ["2massh"])
+    va = fresh["2massh"]["VA"].copy()
+    va[:, 3] = np.inf
+    c["svd"]["2massh"] = dict(fresh["2massh"], VA=va)
+    c["theta"] = c["theta"][:16]
+    return c
+
+
 def case_small_hidden():
     """Tiny surrogate (NH=64) for fast pure-Python loops."""
     return _base(seed=8234, n_hidden=64, batch=16)
@@ -258,6 +318,9 @@ CASES = {
     "real_nets": case_real_nets,
     "conversions": case_conversions,
     "conversions_cos": case_conversions_cos,
+    "at2017gfo": case_at2017gfo,
+    "unobserved_filter_overflow": case_unobserved_filter_overflow,
+    "unobserved_filter_dead": case_unobserved_filter_dead,
 }
 
 

@@ -4,25 +4,12 @@ import numpy as np
 
 def engine_from_case(case, device=0):
     from nmma_amd.engine import EMEngine
-    from nmma_amd.em.utils import resolve_sources, FILTER_AVERAGES
-    obs = list(case["observed_filters"])
-    lim = case["detection_limit"]
-    if not isinstance(lim, dict):
-        lim = {f: float(lim) for f in obs}
-    return EMEngine(case["svd"], case["model_filters"], case["model_parameters"], case["names"],
-                    fixed=case.get("fixed"), sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
-                    data=case["data"], observed_filters=obs,
-                    sources=resolve_sources(obs, case["model_filters"],
-                                            known_filters=[f for f in obs if f not in FILTER_AVERAGES]),
-                    detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
-                    filter_nu0=case.get("filter_nu0"),
-                    extinction_law="P92_SMC_host" if case.get("filter_nu0") is not None else None,
-                    device=device)
+    return EMEngine.from_case(case, device=device)
 
 
 def oracle_from_case(case, **kw):
-    from tools.make_golden import build_oracle_likelihood
-    return build_oracle_likelihood(case, **kw)
+    from oracle.nmma_oracle import likelihood_from_case
+    return likelihood_from_case(case, **kw)
 
 
 def rel_err(got, want):

@@ -57,3 +57,24 @@ def test_sharded_all_gather_even():
 
 def test_sharded_all_gather_ragged():
     _run(33)
+
+
+def test_sharded_all_gather_ragged_three_ranks():
+    """10 rows over 3 ranks: shards of 4, 3 and 3 rows, the short ones padded to the 4-row slot of the all-gather."""
+    _run(10, world=3)
+
+
+def test_sharded_all_gather_fewer_rows_than_ranks():
+    """2 rows over 3 ranks: the last rank owns an empty shard and still takes part in the collective."""
+    _run(2, world=3)
+
+
+def test_shard_bounds_partition_every_batch():
+    from nmma_amd.parallel import shard_bounds
+    for n in (0, 1, 2, 7, 33, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)

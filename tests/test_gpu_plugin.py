@@ -37,6 +37,37 @@ def test_likelihood_plugin_matches_golden(name):
     assert "EMTransientLikelihood" in repr(lik)
 
 
+def test_at2017gfo_real_photometry_through_build_em_likelihood():
+    """The data set the metric is named after: the reference's example_files/lightcurves/AT2017gfo.dat (fixture
+    tests/golden/at2017gfo_photometry.npz: 9 filters, 141 rows, 3 upper limits) from raw MJD photometry through the drivers'
+    own order of calls -- cut_data_to_time_range, then build_em_likelihood (trigger-relative times, model-window check,
+    systematics handler with the sampled em_syserr, likelihood) -- against the golden the reference produced from the same
+    arrays; and the uncut data set is refused like the reference refuses it."""
+    from nmma_amd.em import utils as em_utils
+    from nmma_amd.em.em_likelihood import build_em_likelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from tests.helpers import SimplePrior
+    case = cases.case_at2017gfo()
+    gold = cases.load_golden("at2017gfo")["logl"]
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    for key, (lo, hi) in case["prior_bounds"].items():
+        priors[key] = SimplePrior(lo, hi)
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"],
+                               model_parameters=case["model_parameters"], sample_times=case["sample_times"],
+                               cosmo_grid=case["cosmo_grid"])
+    raw = em_utils.cut_data_to_time_range(cases.at2017gfo_raw_photometry(), None, case["trigger_time"], *case["data_window"])
+    lik = build_em_likelihood(model, raw, case["trigger_time"], priors, error_budget=None)
+    assert sorted(lik.sub_model.observed_filters) == sorted(case["observed_filters"]) and len(case["observed_filters"]) == 9
+    n_ul = sum(int(np.sum(~np.isfinite(lik.sub_model.light_curve_uncertainties[f]))) for f in case["observed_filters"])
+    assert n_ul == 3
+    got = lik.log_likelihood_batch(case["theta"], case["names"])
+    assert np.all(gold > FLOOR) and rel_err(got, gold).max() <= 1e-6
+    p = dict(zip(case["names"], (float(v) for v in case["theta"][3])))
+    assert lik.log_likelihood(p) == pytest.approx(gold[3], rel=1e-6)
+    with pytest.raises(ValueError, match="Last data point"):
+        build_em_likelihood(model, cases.at2017gfo_raw_photometry(), case["trigger_time"], priors, error_budget=None)
+
+
 def test_gen_detector_lc_matches_golden():
     case = cases.case_c2_dt05_limit()
     gold = cases.load_golden("c2_dt05_limit")

@@ -129,18 +129,7 @@ def run_case(name):
 
 
 def build_oracle_likelihood(case, use_scipy=True, mlp_mode="f32"):
-    ext = None
-    if case.get("ebv_coeff") is not None:           # A_f = k_f * Ebv (stands in for the absent dust_extinction law)
-        coeff = np.array([case["ebv_coeff"][f] for f in case["model_filters"]], float)
-        ext = lambda redshift, ebv: coeff * ebv      # noqa: E731
-    elif case.get("filter_nu0") is not None:        # the default law, restated (oracle/nmma_oracle.py: P92 SMC, host frame)
-        nu0 = np.array([case["filter_nu0"][f] for f in case["model_filters"]], float)
-        ext = lambda redshift, ebv: orc.extinction_mags_p92_smc(nu0, redshift, ebv)      # noqa: E731
-    model = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=case["model_filters"],
-                               sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
-                               ext_mag_func=ext, mlp_mode=mlp_mode)
-    return orc.OracleLikelihood(model, case["data"], case["systematics"], case["observed_filters"],
-                                detection_limit=case["detection_limit"], use_scipy=use_scipy)
+    return orc.likelihood_from_case(case, use_scipy=use_scipy, mlp_mode=mlp_mode)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def timed(fn, n=30, warm=5):
 def main():
     rows = [("c2_default", 4096), ("c2_default", 65536), ("c2_dt05", 4096), ("syserr_param", 4096), ("syserr_time_nodes", 4096),
             ("c2_dt05_limit", 4096), ("extinction_limit", 4096), ("extinction_p92", 4096), ("log_grid", 4096),
-            ("averaging", 4096), ("c4_shape", 8192), ("c4_shape", 65536)]
+            ("averaging", 4096), ("c4_shape", 8192), ("c4_shape", 65536), ("at2017gfo", 4096)]
     for name, B in rows:
         case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
         eng = engine_from_case(case)
