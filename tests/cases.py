@@ -337,6 +337,7 @@ def weights_digest(svd):
     for f in sorted(svd):
         for k in ("W1", "b1", "W2", "b2", "VA", "mins", "maxs"):
             a = np.asarray(svd[f][k], dtype=np.float64)
+            a = np.where(np.isfinite(a), a, 0.0)          # (cases with deliberately broken tensors)
             acc += float(np.sum(a * np.cos(np.arange(a.size).reshape(a.shape) % 97)))
     return acc
 
