@@ -691,7 +691,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
-    const EmDev& P = *Pp;
+    // (blockIdx.y > 0 only in the split launch of small batches: one copy of the configuration per observed band)
+    const EmDev& P = Pp[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* praw = reinterpret_cast<double*>(smem + L.praw);
     double* scal = reinterpret_cast<double*>(smem + L.scal);
@@ -2039,14 +2040,33 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         if (vt < TS && tile0 + vt < B) {
-            double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
-            for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
-            double tot = c + g;
             const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
-            if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
-            out[tile0 + vt] = tot;
+            if (out == nullptr) {
+                // split launch: this workgroup owns one band; its sums are in chi_parts / gp_parts already (written by the
+                // tasks, NaN for a bad sample) and em_combine_bands adds the bands.  Only a tripped watchdog is news here.
+                if (isbad) chi_parts[(long)itab[W - 1].o * B + tile0 + vt] = dnan();
+            } else {
+                double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
+                for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
+                double tot = c + g;
+                if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+                out[tile0 + vt] = tot;
+            }
         }
     }
+}
+
+// Sum over observed bands + floor for the split launch of small batches: the arithmetic of em_logl's own epilogue
+// (running sums of the truncated-Gaussian and of the survival-function parts in band order, then their sum; core/base.py:178-182).
+__global__ __launch_bounds__(256) void em_combine_bands(const double* __restrict__ chi, const double* __restrict__ gp, const long B,
+                                                        const int O, const int always_floor, double* __restrict__ out) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double c = 0.0, g = 0.0;
+    for (int o = 0; o < O; ++o) { c += chi[(long)o * B + b]; g += gp[(long)o * B + b]; }
+    double tot = c + g;
+    if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+    out[b] = tot;
 }
 
 // =======================================================================================

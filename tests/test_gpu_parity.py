@@ -8,6 +8,7 @@ reproducible, so coefficients are compared at fp32-rounding level (stated below)
 import numpy as np
 import pytest
 
+from nmma_amd import synthetic as syn
 from tests import cases
 from tests.helpers import engine_from_case, oracle_from_case, rel_err
 
@@ -560,4 +561,36 @@ def test_wide_theta_rows(name, torch_cuda):
     c = eng.loglike(wide)
     eng.check()
     assert np.array_equal(a, b) and np.array_equal(a, c)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "log_grid", "averaging", "c2_dt05_limit", "extinction_p92", "many_points"])
+def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monkeypatch):
+    """Small batches run one workgroup per (tile, observed band) plus a kernel that adds the bands in the fused epilogue's
+    order: bit-identical to the one-workgroup-per-tile launch, for every lean flavour, ragged batch sizes and floored rows."""
+    torch = torch_cuda
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    _, theta = syn.draw_theta(4242, 1100, case["names"])
+    theta[3, 0] = np.nan                                  # a floored row
+    th = torch.as_tensor(theta, device="cuda:0")
+    monkeypatch.setenv("NMMA_EM_SPLIT", "0")
+    eng = engine_from_case(case)
+    want = eng.loglike(th).cpu().numpy()
+    assert eng.last_launch_geometry()["grid_y"] == 1
+    eng.close()
+    monkeypatch.setenv("NMMA_EM_SPLIT", "1")
+    eng = engine_from_case(case)
+    for n in (1, 17, 512, 1100):
+        got = eng.loglike(th[:n]).cpu().numpy()
+        eng.check()
+        assert eng.last_launch_geometry()["grid_y"] == len(case["observed_filters"])
+        assert np.array_equal(got, want[:n]), (name, n)
+    assert want[3] == FLOOR and (want > FLOOR).sum() > 500
+    eng.close()
+    monkeypatch.delenv("NMMA_EM_SPLIT")
+    eng = engine_from_case(case)                          # auto: split while tiles x bands <= 384
+    assert np.array_equal(eng.loglike(th[:512]).cpu().numpy(), want[:512])
+    split_small = eng.last_launch_geometry()["grid_y"] > 1
+    eng.loglike(torch.as_tensor(syn.draw_theta(1, 8192, case["names"])[1], device="cuda:0"))
+    assert split_small and eng.last_launch_geometry()["grid_y"] == 1
     eng.close()
