@@ -70,10 +70,11 @@ class GPUPool:
             return []
         if getattr(func, "__self__", None) is self and getattr(func, "__func__", None) is GPUPool.log_likelihood:
             res = list(self.log_likelihood_many(items))
-        elif hasattr(func, "run_many"):
-            # a lock-step walker (nmma_amd.sampler.LockstepEnsembleWalk) as dynesty's `sample=` object: the queue of
-            # chains advances together, one likelihood launch per MCMC step
-            res = func.run_many(items, self.log_likelihood_many, self.prior_transform_many)
+        elif hasattr(func, "run_many") or hasattr(getattr(func, "__self__", None), "run_many"):
+            # a lock-step walker of nmma_amd.sampler -- the `sample=` object itself (dynesty 2) or its bound `sample` method
+            # (dynesty 3): the queue of chains advances together, one likelihood launch per MCMC step
+            walker = func if hasattr(func, "run_many") else func.__self__
+            res = walker.run_many(items, self.log_likelihood_many, self.prior_transform_many)
         else:
             res = [func(it) for it in items]
         if callback is not None:

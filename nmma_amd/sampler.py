@@ -1,31 +1,82 @@
-"""Sampler-side batching: the pieces that let NMMA's nested-sampling drivers feed the GPU whole batches
-instead of one parameter vector per call (``nmma/core/mpi_setup.py:209-242``,
-``:282-303``, ``:339``; ``nmma/core/base.py:316-329``).
+"""Sampler-side batching: drop-in replacements for the MCMC walk objects NMMA hands to dynesty, written so that a whole
+queue of chains advances in lock-step -- ONE batched prior transform and ONE likelihood launch per MCMC step (SURVEY.md
+section 8f-1).
 
-The reference evolves each live point with an MCMC chain (bilby's ``EnsembleWalkSampler`` /
-``ACTTrackingEnsembleWalk`` passed to dynesty as ``sample=``); dynesty hands ``queue_size`` such chains to
-``pool.map``.  Every chain calls the likelihood once per step -- so a GPU sees one point at a time.
-:class:`LockstepEnsembleWalk` is the same kind of object (callable on one argument record, usable as
-``sample=``), written as a generator that *yields* the point it wants evaluated.  Driven one chain at a
-time it behaves like the reference's walker; given to :meth:`nmma_amd.pool.GPUPool.map` with a whole queue
-it advances all chains in lock-step: one batched prior transform and ONE likelihood launch per MCMC step.
+What they replace.  ``nmma/core/mpi_setup.py:202-245`` builds the ``sample=`` object of the nested sampler from bilby's
+dynesty utilities, by name and with these keyword arguments::
 
-Argument record (the fields of dynesty's ``SamplerArgument`` that an ensemble walk uses): ``u`` (start, unit
-cube), ``loglstar``, ``rseed`` (int or numpy Generator), ``prior_transform``, ``loglikelihood`` and
-``kwargs["live_u"]`` (the current live points, unit cube, the proposal ensemble).  Return value per chain:
-``(u, v, logl, ncall, blob)`` with ``blob = {"accept": ..., "reject": ..., "scale": ...}``.
-dynesty / bilby are not installed in the build image: the protocol is exercised by a fake driver in
-``tests/test_sampler_adapter.py``; INTEGRATION.md shows the wiring into ``mpi_setup.py``.
+    internal_kwargs = dict(ndim=..., nonbounded=None, periodic=..., reflective=..., maxmcmc=maxmcmc)
+    "acceptance-walk": dy_utils.EnsembleWalkSampler(**internal_kwargs, naccept=naccept, walks=walks)        # :222-224
+    "act-walk":        dy_utils.ACTTrackingEnsembleWalk(**internal_kwargs, nact=nact)                        # :209-211
+    "rwalk":           dy_utils.AcceptanceTrackingRWalk(**internal_kwargs, nact=nact)                        # :235-237
+
+and reads ``.naccept``, ``.maxmcmc``, ``.thin``, ``.nact`` back for its log lines (:215-219, :227-231, :240-244).  dynesty then
+calls ``prepare_sampler(...)`` to get one argument record per live point to evolve, maps ``sample`` over the records through
+``pool.map`` (:282-285, :339) and feeds the returned tuning information to ``tune``.  The three classes below have the same
+names, constructor keywords, attributes and methods, so ``import nmma_amd.sampler as dy_utils`` is the whole edit
+(``tests/test_sampler_adapter.py`` drives exactly that with a fake nested sampler; dynesty / bilby are absent from the image, so
+the protocol is restated from bilby's public ``dynesty_utils`` / ``dynesty3_utils`` -- stated, not pinned).
+
+What is different inside.  Every chain is a *coroutine* that yields the unit-cube point it wants evaluated.  Called on one
+record (``sample(args)``: the per-point protocol) a chain is driven alone, as in bilby.  Given to
+:meth:`nmma_amd.pool.GPUPool.map` with the whole queue the chains run as rows of numpy arrays (:meth:`run_many`).  All
+randomness is COUNTER-BASED: the numbers chain ``c`` draws at its step ``n`` are a hash of ``(seed_c, n, k)`` (SplitMix64),
+so a chain sees the same random numbers -- and produces bit-identical results -- whether it runs alone, in a queue of 10 or in a
+queue of 4096, in any order.
+
+Moves and rules (bilby ``dynesty_utils``): differential-evolution proposal ``u' = u + gamma (a - b)`` with ``a, b`` two other live
+points and ``gamma = 2.38 / sqrt(2 ndim) x Gamma(4, 1/4)`` or 1 with probability 1/2; periodic / reflective wrapping, proposals
+outside the unit cube are rejected without an evaluation; accepted when ``logL > loglstar``; a chain that never accepts returns
+a fresh prior draw.  ``EnsembleWalkSampler`` walks ``int(walks)`` steps and ``tune`` steers ``walks`` towards ``naccept`` accepted
+steps per chain; ``AcceptanceTrackingRWalk`` runs until ``nact`` autocorrelation times, estimated from the acceptance ratio
+(``estimate_nmcmc``), have passed; ``ACTTrackingEnsembleWalk`` estimates the autocorrelation time from the chain itself.
 """
 from __future__ import annotations
 
 import numpy as np
 
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_K_STEP = np.uint64(0xD1342543DE82EF95)
+_K_DRAW = np.uint64(0xA0761D6478BD642F)
+N_DRAWS = 8         # uniforms a chain consumes per step
+
+
+def _mix64(x):
+    """SplitMix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    x = (x ^ (x >> np.uint64(30))) * _M1
+    x = (x ^ (x >> np.uint64(27))) * _M2
+    return x ^ (x >> np.uint64(31))
+
+
+def counter_uniforms(seeds, steps, n_draws=N_DRAWS):
+    """``[len(seeds), n_draws]`` uniforms in (0, 1): draw ``k`` of step ``steps[c]`` of the chain with key ``seeds[c]``.
+    A pure function of (seed, step, k): no state, any evaluation order."""
+    with np.errstate(over="ignore"):
+        s = np.asarray(seeds, dtype=np.uint64)[:, None]
+        n = np.asarray(steps, dtype=np.uint64)[:, None]
+        k = np.arange(n_draws, dtype=np.uint64)[None, :]
+        x = _mix64(_mix64(s * _GOLDEN + _GOLDEN) ^ (n * _K_STEP + k * _K_DRAW + _GOLDEN))
+        x = _mix64(x)
+    return ((x >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def chain_key(rseed):
+    """64-bit key of a chain from dynesty's ``rseed`` (an integer, or a numpy Generator / SeedSequence of older versions)."""
+    if isinstance(rseed, (int, np.integer)):
+        return int(rseed) & 0xFFFFFFFFFFFFFFFF
+    if isinstance(rseed, np.random.Generator):
+        return int(rseed.integers(0, 2 ** 63 - 1))
+    if isinstance(rseed, np.random.SeedSequence):
+        return int(rseed.generate_state(1, dtype=np.uint64)[0])
+    return int(np.random.default_rng(rseed).integers(0, 2 ** 63 - 1))
+
 
 class BatchedPriorTransform:
-    """``prior_transform`` for arrays of unit-cube points: ``u[B, D] -> theta[B, D]`` with one vectorised
-    ``rescale`` per parameter (bilby priors' ``rescale`` are numpy ufunc-style; ``priors.rescale(keys, u)``
-    of ``core/mpi_setup.py:682-683`` is the per-point form)."""
+    """``prior_transform`` for arrays of unit-cube points: ``u[B, D] -> theta[B, D]`` with one vectorised ``rescale`` per
+    parameter (bilby priors' ``rescale`` are numpy ufunc-style; ``priors.rescale(keys, u)`` of ``core/mpi_setup.py:679-683`` is
+    the per-point form, and a 1-D ``u`` is answered in that form)."""
 
     def __init__(self, priors, keys):
         self.keys = list(keys)
@@ -41,171 +92,325 @@ class BatchedPriorTransform:
         return out[0] if single else out
 
 
-def _generator(rseed):
-    return rseed if isinstance(rseed, np.random.Generator) else np.random.default_rng(rseed)
+class SamplerArgument:
+    """The record dynesty hands to ``sample``: start point, likelihood bound, seed, the two callables and the walker's kwargs
+    (``live`` = the unit-cube live points the differential-evolution move draws from)."""
+    __slots__ = ("u", "loglstar", "axes", "scale", "rseed", "prior_transform", "loglikelihood", "kwargs")
+
+    def __init__(self, u, loglstar, rseed, prior_transform, loglikelihood, kwargs, axes=None, scale=1.0):
+        self.u, self.loglstar, self.rseed = u, loglstar, rseed
+        self.prior_transform, self.loglikelihood, self.kwargs = prior_transform, loglikelihood, kwargs
+        self.axes, self.scale = axes, scale
 
 
-class LockstepEnsembleWalk:
-    """Differential-evolution ensemble random walk (the move of bilby's ``EnsembleWalkSampler``:
-    ``u' = u + gamma (a - b)`` with ``a, b`` two other live points, ``gamma = 2.38 / sqrt(2 ndim)`` scaled by a
-    log-normal factor, or 1 with probability 0.5 to jump between modes), accepted when the new point is inside
-    the unit cube (after periodic / reflective wrapping) and ``logL > loglstar``.  A chain runs ``walks``
-    steps and continues (up to ``maxmcmc``) until it has accepted at least once."""
+class SamplerReturn(tuple):
+    """``(u, v, logl, ncall, blob)`` -- the tuple of dynesty 2's walkers -- with dynesty 3's field names as attributes."""
+    __slots__ = ()
 
-    def __init__(self, ndim, walks=100, maxmcmc=5000, periodic=None, reflective=None):
-        self.ndim, self.walks, self.maxmcmc = int(ndim), int(walks), int(maxmcmc)
+    def __new__(cls, u, v, logl, ncall, blob):
+        return tuple.__new__(cls, (u, v, logl, ncall, blob))
+
+    u = property(lambda self: self[0])
+    v = property(lambda self: self[1])
+    logl = property(lambda self: self[2])
+    ncalls = property(lambda self: self[3])
+    tuning_info = property(lambda self: self[4])
+
+
+def estimate_nmcmc(accept_ratio, safety=5, tau=None, maxmcmc=5000, old_act=None):
+    """bilby ``dynesty_utils.estimate_nmcmc``: chain length from the acceptance ratio -- autocorrelation time ``2 / a - 1`` of a
+    Metropolis chain, smoothed over ``tau`` calls with the previous estimate."""
+    if tau is None:
+        tau = maxmcmc / safety
+    if accept_ratio == 0.0:
+        n_exact = np.inf if old_act is None else (1 + 1 / tau) * old_act
+    else:
+        n_exact = safety * (2 / accept_ratio - 1)
+        if old_act is not None:
+            n_exact = (1 - 1 / tau) * old_act + n_exact / tau
+    return max(safety, float(min(n_exact, maxmcmc)))
+
+
+def _live_points(args):
+    kw = args.kwargs
+    for key in ("live", "live_u"):
+        if kw.get(key) is not None:
+            return np.asarray(kw[key], dtype=float)
+    raise KeyError("the sampler argument carries no live points (kwargs['live'])")
+
+
+class _LockstepWalk:
+    """Shared machinery: the move, the boundary rules, the per-point protocol, the lock-step driver.  Subclasses define
+    when a chain stops (``_init_state``, ``_continues``)."""
+
+    def __init__(self, ndim=None, nonbounded=None, periodic=None, reflective=None, maxmcmc=5000, **kwargs):
+        self.ndim = None if ndim is None else int(ndim)
+        self.nonbounded = nonbounded
         self.periodic = np.asarray(periodic if periodic is not None else [], dtype=int)
         self.reflective = np.asarray(reflective if reflective is not None else [], dtype=int)
+        self.maxmcmc = int(maxmcmc)
+        self.scale = 1.0
+        self.nlive = None
+        self.sampler_kwargs = dict(ndim=self.ndim, periodic=periodic, reflective=reflective, maxmcmc=self.maxmcmc)
+        self.n_batches = self.n_evals = 0
 
-    # ---- one chain as a coroutine: yields unit-cube proposals, receives (v, logl) -------------------
-    def _wrap(self, u):
-        u = u.copy()
+    # ---- dynesty 3 protocol -------------------------------------------------------------------------------------------
+    def prepare_sampler(self, loglstar=None, points=None, axes=None, seeds=None, prior_transform=None, loglikelihood=None,
+                        nested_sampler=None):
+        """One :class:`SamplerArgument` per live point to evolve (dynesty: ``InternalSampler.prepare_sampler``)."""
+        live = np.asarray(getattr(nested_sampler, "live_u"), dtype=float)
+        self.nlive = len(live)
+        kwargs = dict(self.sampler_kwargs, live=live, walks=getattr(self, "walks", None), nlive=self.nlive)
+        axes = axes if axes is not None else [None] * len(points)
+        return [SamplerArgument(u=p, loglstar=loglstar, rseed=s, prior_transform=prior_transform, loglikelihood=loglikelihood,
+                                kwargs=kwargs, axes=a, scale=self.scale) for p, a, s in zip(points, axes, seeds)]
+
+    def tune(self, tuning_info, update=True):
+        return None
+
+    def sample(self, args):
+        """One chain, driven alone (what ``pool.map`` does when nothing batches): identical, bit for bit, to the same chain
+        inside :meth:`run_many`."""
+        return self.run_many([args], lambda v: np.array([args.loglikelihood(v[0])], dtype=float),
+                             lambda u: np.asarray(args.prior_transform(u[0]), dtype=float)[None, :])[0]
+
+    __call__ = sample           # dynesty 2: the ``sample=`` object is called on the argument record
+
+    # ---- the move -------------------------------------------------------------------------------------------------------
+    def _propose(self, u, live, r):
+        """Differential evolution for the rows of ``u`` with uniforms ``r[:, 0:7]``; returns (proposal, inside-the-cube mask)."""
+        n_live, ndim = live.shape
+        i = np.minimum((r[:, 0] * n_live).astype(int), n_live - 1)
+        j = (i + 1 + np.minimum((r[:, 1] * (n_live - 1)).astype(int), n_live - 2)) % n_live        # a different live point
+        gamma = np.where(r[:, 2] < 0.5, 1.0,
+                         2.38 / np.sqrt(2.0 * ndim) * (-0.25 * np.log(r[:, 3] * r[:, 4] * r[:, 5] * r[:, 6])))   # Gamma(4, 1/4)
+        prop = u + gamma[:, None] * (live[j] - live[i])
         if self.periodic.size:
-            u[self.periodic] = np.mod(u[self.periodic], 1.0)
+            prop[:, self.periodic] = np.mod(prop[:, self.periodic], 1.0)
         if self.reflective.size:
-            r = np.mod(u[self.reflective], 2.0)
-            u[self.reflective] = np.where(r > 1.0, 2.0 - r, r)
-        return u
+            q = np.mod(prop[:, self.reflective], 2.0)
+            prop[:, self.reflective] = np.where(q > 1.0, 2.0 - q, q)
+        return prop, np.all((prop >= 0.0) & (prop <= 1.0), axis=1)
 
-    def chain(self, args):
-        rng = _generator(args.rseed)
-        live = np.asarray(args.kwargs["live_u"], dtype=float)
-        n_live = len(live)
-        u = np.asarray(args.u, dtype=float).copy()
-        v, logl = None, None
-        accept = reject = ncall = 0
-        gamma0 = 2.38 / np.sqrt(2.0 * self.ndim)
-        step = 0
-        while step < self.walks or (accept == 0 and step < self.maxmcmc):
-            step += 1
-            i, j = rng.choice(n_live, size=2, replace=False)
-            gamma = 1.0 if rng.random() < 0.5 else gamma0 * np.exp(0.5 * rng.standard_normal())
-            prop = self._wrap(u + gamma * (live[i] - live[j]))
-            if np.any(prop < 0.0) or np.any(prop > 1.0):
-                reject += 1
-                continue
-            v_prop, logl_prop = yield prop
-            ncall += 1
-            if logl_prop > args.loglstar:
-                u, v, logl = prop, v_prop, logl_prop
-                accept += 1
-            else:
-                reject += 1
-        if v is None:                      # never moved: the start point itself, evaluated through the same channel
-            v, logl = yield u              # (batched with the other chains' requests in lock-step mode)
-            ncall += 1
-        return u, v, logl, ncall, {"accept": accept, "reject": reject, "scale": 1.0}
-
-    # ---- per-point protocol (what dynesty calls through pool.map when nothing batches) -------------
-    def __call__(self, args):
-        gen = self.chain(args)
-        try:
-            prop = next(gen)
-            while True:
-                v = args.prior_transform(prop)
-                prop = gen.send((v, args.loglikelihood(v)))
-        except StopIteration as stop:
-            return stop.value
-
-    # ---- the whole queue in lock-step -----------------------------------------------------------------
-    def run_many_chains(self, args_list, loglike_many, prior_transform_many=None):
-        """Lock-step over the per-chain coroutines: per MCMC step ONE ``prior_transform_many(u[B, D])`` and ONE
-        ``loglike_many(theta[B, D]) -> logL[B]``; every chain keeps its own random stream, so the results equal those of
-        ``__call__`` chain by chain, bit for bit.  The Python work per chain and step (~10 us) bounds it to ~1e5 proposals/s:
-        the reference for :meth:`run_many`, not the fast path."""
-        gens = [self.chain(a) for a in args_list]
-        results = [None] * len(gens)
-        pending = {}
-        for idx, g in enumerate(gens):
-            try:
-                pending[idx] = next(g)
-            except StopIteration as stop:
-                results[idx] = stop.value
-        self.n_batches, self.n_evals = 0, 0
-        while pending:
-            order = list(pending)
-            u = np.stack([pending[i] for i in order])
-            if prior_transform_many is not None:
-                v = np.asarray(prior_transform_many(u))
-            else:
-                v = np.stack([args_list[i].prior_transform(u[q]) for q, i in enumerate(order)])
-            logl = np.asarray(loglike_many(v), dtype=float)
-            self.n_batches += 1
-            self.n_evals += len(order)
-            for q, i in enumerate(order):
-                try:
-                    pending[i] = gens[i].send((v[q], float(logl[q])))
-                except StopIteration as stop:
-                    results[i] = stop.value
-                    del pending[i]
-        return results
-
+    # ---- the whole queue in lock-step -----------------------------------------------------------------------------------
     def run_many(self, args_list, loglike_many, prior_transform_many=None):
-        """The same walk for the whole queue with the chains as rows of numpy arrays: no Python work per chain, one random
-        stream for all chains (seeded from every chain's ``rseed``).  Same move, same acceptance rule, same stopping rule and
-        the same return tuples as :meth:`chain`; only the random numbers a given chain sees differ from its solo run."""
+        """Evolve every chain of the queue: per MCMC step one ``prior_transform_many(u[m, D])`` and one
+        ``loglike_many(theta[m, D]) -> logL[m]`` for the ``m`` chains still running whose proposal fell inside the unit cube."""
         n = len(args_list)
         if n == 0:
             return []
         first = args_list[0]
-        live = np.asarray(first.kwargs["live_u"], dtype=float)
-        if any(a.kwargs["live_u"] is not first.kwargs["live_u"] for a in args_list[1:]):
-            return self.run_many_chains(args_list, loglike_many, prior_transform_many)     # (per-chain ensembles: no common array)
-        n_live, ndim = live.shape
-        seeds = [a.rseed for a in args_list]
-        if all(isinstance(x, (int, np.integer)) for x in seeds):
-            rng = np.random.default_rng(np.random.SeedSequence([int(x) & 0xFFFFFFFF for x in seeds]))
-        else:
-            rng = _generator(seeds[0])
+        live = _live_points(first)
+        shared = all(a.kwargs is first.kwargs or a.kwargs.get("live", a.kwargs.get("live_u")) is
+                     first.kwargs.get("live", first.kwargs.get("live_u")) for a in args_list[1:])
+        if not shared:          # per-chain ensembles: evolve the groups that do share one
+            out = [None] * n
+            groups = {}
+            for q, a in enumerate(args_list):
+                groups.setdefault(id(a.kwargs.get("live", a.kwargs.get("live_u"))), []).append(q)
+            for idx in groups.values():
+                for q, r in zip(idx, self.run_many([args_list[q] for q in idx], loglike_many, prior_transform_many)):
+                    out[q] = r
+            return out
         pt_many = prior_transform_many if prior_transform_many is not None else (
-            lambda uu: np.stack([first.prior_transform(x) for x in uu]))
+            lambda uu: np.stack([np.asarray(first.prior_transform(x), dtype=float) for x in uu]))
+        keys = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
         u = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
         loglstar = np.array([a.loglstar for a in args_list], dtype=float)
-        v = np.full_like(u, np.nan)
-        logl = np.full(n, np.nan)
-        accept = np.zeros(n, dtype=int)
-        reject = np.zeros(n, dtype=int)
-        ncall = np.zeros(n, dtype=int)
-        step = np.zeros(n, dtype=int)
-        gamma0 = 2.38 / np.sqrt(2.0 * self.ndim)
-        self.n_batches, self.n_evals = 0, 0
-        active = np.ones(n, dtype=bool) if (self.walks > 0 or self.maxmcmc > 0) else np.zeros(n, dtype=bool)
+        v, logl = np.full_like(u, np.nan), np.full(n, np.nan)
+        st = dict(accept=np.zeros(n, dtype=int), reject=np.zeros(n, dtype=int), nfail=np.zeros(n, dtype=int),
+                  ncall=np.zeros(n, dtype=int), step=np.zeros(n, dtype=int))
+        self._init_state(st, args_list, u)
+        self.n_batches = self.n_evals = 0
+        active = self._continues(st)
         while active.any():
             idx = np.nonzero(active)[0]
-            m = idx.size
-            step[idx] += 1
-            i = rng.integers(n_live, size=m)
-            j = (i + 1 + rng.integers(n_live - 1, size=m)) % n_live            # two different live points
-            gamma = np.where(rng.random(m) < 0.5, 1.0, gamma0 * np.exp(0.5 * rng.standard_normal(m)))
-            prop = u[idx] + gamma[:, None] * (live[i] - live[j])
-            if self.periodic.size:
-                prop[:, self.periodic] = np.mod(prop[:, self.periodic], 1.0)
-            if self.reflective.size:
-                r = np.mod(prop[:, self.reflective], 2.0)
-                prop[:, self.reflective] = np.where(r > 1.0, 2.0 - r, r)
-            inside = np.all((prop >= 0.0) & (prop <= 1.0), axis=1)
-            reject[idx[~inside]] += 1
+            st["step"][idx] += 1
+            r = counter_uniforms(keys[idx], st["step"][idx])
+            prop, inside = self._propose(u[idx], live, r)
+            st["nfail"][idx[~inside]] += 1
             ev = idx[inside]
             if ev.size:
-                v_prop = np.asarray(pt_many(prop[inside]))
+                v_prop = np.asarray(pt_many(prop[inside]), dtype=float)
                 l_prop = np.asarray(loglike_many(v_prop), dtype=float)
                 self.n_batches += 1
                 self.n_evals += ev.size
-                ncall[ev] += 1
+                st["ncall"][ev] += 1
                 ok = l_prop > loglstar[ev]
                 good = ev[ok]
-                u[good] = prop[inside][ok]
-                v[good] = v_prop[ok]
-                logl[good] = l_prop[ok]
-                accept[good] += 1
-                reject[ev[~ok]] += 1
-            active = (step < self.walks) | ((accept == 0) & (step < self.maxmcmc))
-        still = np.nonzero(accept == 0)[0]          # never moved: the start points themselves, one more batch
-        if still.size:
-            v[still] = np.asarray(pt_many(u[still]))
-            logl[still] = np.asarray(loglike_many(v[still]), dtype=float)
+                u[good], v[good], logl[good] = prop[inside][ok], v_prop[ok], l_prop[ok]
+                st["accept"][good] += 1
+                st["reject"][ev[~ok]] += 1
+            self._after_step(st, idx, u)
+            active = self._continues(st)
+        # a chain that never moved returns a fresh draw from the prior (bilby: "Unable to find a new point using walk")
+        stuck = np.nonzero(self._stuck(st))[0]
+        if stuck.size:
+            u[stuck] = counter_uniforms(keys[stuck], np.zeros(stuck.size, dtype=np.uint64), max(N_DRAWS, u.shape[1]))[:, :u.shape[1]]
+            v[stuck] = np.asarray(pt_many(u[stuck]), dtype=float)
+            logl[stuck] = np.asarray(loglike_many(v[stuck]), dtype=float)
             self.n_batches += 1
-            self.n_evals += still.size
-            ncall[still] += 1
-        return [(u[q], v[q], float(logl[q]), int(ncall[q]), {"accept": int(accept[q]), "reject": int(reject[q]), "scale": 1.0})
-                for q in range(n)]
+            self.n_evals += stuck.size
+            st["ncall"][stuck] += 1
+        self._finish(st)
+        return [SamplerReturn(u[q], v[q], float(logl[q]), int(st["ncall"][q]), self._blob(st, q, args_list[q])) for q in range(n)]
+
+    # ---- hooks ----------------------------------------------------------------------------------------------------------
+    def _init_state(self, st, args_list, u):
+        pass
+
+    def _after_step(self, st, idx, u):
+        pass
+
+    def _stuck(self, st):
+        return st["accept"] == 0
+
+    def _finish(self, st):
+        pass
+
+    def _blob(self, st, q, args):
+        return {"accept": int(st["accept"][q]), "reject": int(st["reject"][q] + st["nfail"][q]), "scale": getattr(args, "scale", 1.0)}
+
+
+class EnsembleWalkSampler(_LockstepWalk):
+    """``sample="acceptance-walk"`` (mpi_setup.py:221-232): ``int(walks)`` differential-evolution steps per chain; ``tune`` moves
+    ``walks`` so that a chain accepts ``naccept`` steps on average (bilby: ``EnsembleWalkSampler.tune``), capped at ``maxmcmc``."""
+
+    def __init__(self, ndim=None, nonbounded=None, periodic=None, reflective=None, maxmcmc=5000, naccept=60, walks=100, **kwargs):
+        super().__init__(ndim=ndim, nonbounded=nonbounded, periodic=periodic, reflective=reflective, maxmcmc=maxmcmc, **kwargs)
+        self.naccept = naccept
+        self.walks = max(2, walks)
+        self.sampler_kwargs["walks"] = self.walks
+
+    def _init_state(self, st, args_list, u):
+        st["walks"] = np.array([int(a.kwargs.get("walks") or self.walks) for a in args_list])
+
+    def _continues(self, st):
+        return st["step"] < st["walks"]
+
+    def _blob(self, st, q, args):
+        # (bilby counts every step that did not accept as a rejection, out-of-cube proposals included)
+        return {"accept": int(st["accept"][q]), "reject": int(st["walks"][q] - st["accept"][q]), "scale": getattr(args, "scale", 1.0),
+                "walks": int(st["walks"][q])}
+
+    def tune(self, tuning_info, update=True):
+        """Steer the walk length towards ``naccept`` accepted steps; ``delay`` averages over about a tenth of the live points.
+        The acceptance probability is taken over the walk length the reporting chain actually used (``tuning_info["walks"]``):
+        a lock-step queue returns hundreds of chains that all ran with the length of the moment they were queued -- bilby's
+        ``accept / self.walks`` is the same number when chains return one at a time."""
+        if not update:
+            return
+        nlive = self.nlive if self.nlive is not None else 0
+        accept_prob = max(0.5, tuning_info["accept"]) / tuning_info.get("walks", self.walks)
+        delay = max(nlive // 10 - 1, 0)
+        self.walks = min((self.walks * delay + self.naccept / accept_prob) / (delay + 1), self.maxmcmc)
+        self.sampler_kwargs["walks"] = self.walks
+
+
+class AcceptanceTrackingRWalk(_LockstepWalk):
+    """``sample="rwalk"`` (mpi_setup.py:234-245): the chain runs until ``nact`` autocorrelation times have passed, the
+    autocorrelation time being estimated from the running acceptance ratio (``estimate_nmcmc`` with ``safety=1``, smoothed over
+    ``nlive`` calls with the estimate the previous chains left behind in ``old_act``), at most ``maxmcmc`` evaluations."""
+    old_act = None
+
+    def __init__(self, ndim=None, nonbounded=None, periodic=None, reflective=None, maxmcmc=5000, nact=40, **kwargs):
+        super().__init__(ndim=ndim, nonbounded=nonbounded, periodic=periodic, reflective=reflective, maxmcmc=maxmcmc, **kwargs)
+        self.nact = nact
+        self.thin = 1
+
+    def _init_state(self, st, args_list, u):
+        st["act"] = np.full(len(args_list), np.inf)
+        st["tau"] = np.array([a.kwargs.get("nlive") or a.kwargs.get("walks") or 100 for a in args_list], dtype=float)
+        st["old_act"] = type(self).old_act        # every chain of the queue starts from the same previous estimate
+
+    def _continues(self, st):
+        done = st["accept"] + st["reject"]
+        return (st["step"] < self.nact * st["act"]) & (done <= self.maxmcmc)
+
+    def _after_step(self, st, idx, u):
+        a, r, f = st["accept"][idx], st["reject"][idx], st["nfail"][idx]
+        upd = (a + r) > self.nact
+        for q in np.nonzero(upd)[0]:
+            st["act"][idx[q]] = estimate_nmcmc(a[q] / (a[q] + r[q] + f[q]), safety=1, tau=st["tau"][idx[q]], maxmcmc=self.maxmcmc,
+                                               old_act=st["old_act"])
+
+    def _stuck(self, st):
+        return ~(np.isfinite(st["act"]) & (st["accept"] > 0))
+
+    def _finish(self, st):
+        fin = st["act"][np.isfinite(st["act"])]
+        if fin.size:
+            type(self).old_act = float(np.median(fin))      # (a queue leaves ONE estimate behind: the median of its chains')
+
+
+def integrated_autocorrelation_time(x, c=5.0):
+    """Integrated autocorrelation time of the columns of ``x[n, D]`` (FFT autocorrelation, Sokal's automatic window
+    ``M >= c tau``); the largest over the columns."""
+    x = np.asarray(x, dtype=float)
+    n = x.shape[0]
+    if n < 8:
+        return np.inf
+    x = x - x.mean(axis=0)
+    size = 1 << (2 * n - 1).bit_length()
+    f = np.fft.rfft(x, n=size, axis=0)
+    acf = np.fft.irfft(f * np.conj(f), n=size, axis=0)[:n]
+    var = acf[0]
+    keep = var > 0
+    if not np.any(keep):
+        return np.inf
+    rho = acf[:, keep] / var[keep]
+    taus = 2.0 * np.cumsum(rho, axis=0) - 1.0
+    m = np.arange(n)[:, None]
+    ok = m >= c * taus
+    first = np.where(ok.any(axis=0), ok.argmax(axis=0), n - 1)
+    return float(np.max(taus[first, np.arange(taus.shape[1])]))
+
+
+class ACTTrackingEnsembleWalk(_LockstepWalk):
+    """``sample="act-walk"`` (mpi_setup.py:209-220): the chain length follows the autocorrelation time MEASURED on the chain:
+    every ``check_interval`` steps the integrated autocorrelation time of the positions visited so far is re-estimated, and the
+    chain stops once it is ``nact`` of them long (at most ``thin x maxmcmc`` steps).  bilby's class additionally caches the
+    thinned remainder of a long chain for later calls; in lock-step every record of the queue gets a chain of its own."""
+    check_interval = 50
+
+    def __init__(self, ndim=None, nonbounded=None, periodic=None, reflective=None, maxmcmc=5000, nact=2, **kwargs):
+        super().__init__(ndim=ndim, nonbounded=nonbounded, periodic=periodic, reflective=reflective, maxmcmc=maxmcmc, **kwargs)
+        self.nact = nact
+        self.thin = nact
+        self.act = 1.0
+
+    def _init_state(self, st, args_list, u):
+        st["act"] = np.full(len(args_list), np.inf)
+        st["hist"] = [[] for _ in args_list]
+
+    def _continues(self, st):
+        return (st["step"] < self.nact * st["act"]) & (st["step"] < self.thin * self.maxmcmc)
+
+    def _after_step(self, st, idx, u):
+        for q in idx:
+            st["hist"][q].append(u[q].copy())
+            if st["step"][q] % self.check_interval == 0 and st["accept"][q] > 0:
+                st["act"][q] = max(1.0, integrated_autocorrelation_time(np.asarray(st["hist"][q])))
+
+    def _finish(self, st):
+        fin = st["act"][np.isfinite(st["act"])]
+        if fin.size:
+            self.act = float(np.median(fin))
+
+
+class LockstepEnsembleWalk(EnsembleWalkSampler):
+    """Round-2 name of the fixed-length ensemble walk (``walks`` steps, continuing up to ``maxmcmc`` until the chain has accepted
+    once); kept for callers that construct it positionally."""
+
+    def __init__(self, ndim, walks=100, maxmcmc=5000, periodic=None, reflective=None):
+        super().__init__(ndim=ndim, periodic=periodic, reflective=reflective, maxmcmc=maxmcmc, walks=walks)
+
+    def _continues(self, st):
+        return (st["step"] < st["walks"]) | ((st["accept"] == 0) & (st["step"] < self.maxmcmc))
+
+    def _blob(self, st, q, args):
+        return {"accept": int(st["accept"][q]), "reject": int(st["reject"][q] + st["nfail"][q]), "scale": 1.0}
+
+    def run_many_chains(self, args_list, loglike_many, prior_transform_many=None):
+        """Every chain driven on its own (queue of one): the reference the lock-step form is bit-identical to."""
+        return [self.run_many([a], loglike_many, prior_transform_many)[0] for a in args_list]
