@@ -13,15 +13,18 @@
 //   gw_source_kernel   one thread per sample: theta row -> GwSource record (all frequency-independent quantities: Table V fits,
 //                      PN coefficients folded with the total mass, connection coefficients, tidal constants, per-detector antenna
 //                      factor and arrival time).  Heavy scalar code, run once per sample.
-//   gw_logl_kernel     the hot loop.  A 256-thread workgroup owns a chunk of GW_CHUNK consecutive bins and a group of GW_GROUP
-//                      samples; lanes map to consecutive bins (coalesced 32-byte loads of the per-bin basis and of the
-//                      pre-weighted data, which stay L2-resident: sample groups are the fast grid index, so the workgroups in
-//                      flight share a handful of chunks), the sample's record is uniform across the workgroup and is read
-//                      through the scalar cache.  Two samples are evaluated per pass over the chunk (the bin loads are shared),
-//                      per-lane partial sums are reduced with DPP and leave through LDS in a fixed order.
+//   gw_logl_kernel    the hot loop.  A 256-thread workgroup owns a chunk of 8192 consecutive bins and a group of 16 samples;
+//                      lanes map to consecutive bins (coalesced 32-byte loads of the per-bin basis and of the pre-weighted
+//                      data, L2-resident: sample groups are the fast grid index, so the workgroups in flight share a handful of
+//                      chunks).  Samples are taken ONE at a time: the chunk's region of phase and amplitude is then a scalar
+//                      decision and the matching instantiation of the bin loop keeps just that region's constants in SGPRs.
+//                      The linear phase exp(-2 pi i f dt) per detector (antenna factor folded in) advances by a complex
+//                      multiplication per pass; one sincos per (bin, sample).  Per-lane sums are reduced with DPP and leave
+//                      through LDS in a fixed order.
 //   gw_finish_kernel   sums the chunk partials in chunk order (the order does not depend on the batch size), applies 4/T,
 //                      the phase marginalisation and the floor.
-// Roofline: fp64 vector FMA (78.6 TFLOP/s); algorithmic flops per (bin, sample) are counted in DESIGN section 3.5.
+// Roofline: fp64 vector FMA (78.6 TFLOP/s); algorithmic flops per (bin, sample) are counted in DESIGN section 3.5, which also
+// lists the three formulations measured on the way (43.0 -> 30.1 ms at config 5's shape).
 //
 // Also here: gw_loglike_ratio_kernel, the HBM-streaming reduction for strain supplied by the caller (round 2).
 #include <hip/hip_runtime.h>
@@ -32,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "em_math.h"
@@ -124,24 +128,22 @@ __global__ __launch_bounds__(GW_THREADS) void gw_loglike_ratio_kernel(
 // =======================================================================================
 constexpr int GWL_THREADS = 256;
 constexpr int GWL_WAVES = GWL_THREADS / 64;
-constexpr int GW_CHUNK_ITERS = 8;                         // passes of 256 bins per chunk
-constexpr int GW_CHUNK = GWL_THREADS * GW_CHUNK_ITERS;    // 2048 bins
-constexpr int GW_GROUP = 16;                              // samples per workgroup
 
 struct GwDev {
     int32_t n_ifo, tidal, mass_mode, phase_marg;
     int64_t n_bins;                // bins k0 .. k0 + n_bins - 1 of the frequency array
     int64_t k0, n_freq;
-    int32_t n_chunks, n_dim;
+    int32_t n_chunks, n_dim;       // chunks of GWL_CHUNK bins
     double df, f_ref, start_time, gmst_ref_time, gmst_ref, gmst_rate, four_over_T;
     const double4* basis;          // [n_bins] {f13, 1/f13, ln f13, f^(-7/6)}
+    const double* basis5;          // [n_bins] f13^5.78
     const double4* dat;            // [n_ifo][n_bins] {w d_re, w d_im, w, 0},  w = mask / S
     gw::GwDetector det[gw::kMaxIfo];
     nmma_slot mass_a, mass_b, chi_1, chi_2, lambda_1, lambda_2, luminosity_distance, theta_jn, phase, ra, dec, psi, geocent_time;
 };
 
 __global__ __launch_bounds__(64) void gw_source_kernel(const GwDev* __restrict__ Pp, const double* __restrict__ theta, const long B,
-                                                       const long ld, gw::GwSource* __restrict__ src) {
+                                                       const long ld, const double stride_hz, gw::GwSource* __restrict__ src) {
     const GwDev& P = *Pp;
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -163,92 +165,168 @@ __global__ __launch_bounds__(64) void gw_source_kernel(const GwDev* __restrict__
     q.ra = apply_slot(P.ra, row); q.dec = apply_slot(P.dec, row); q.psi = apply_slot(P.psi, row);
     q.geocent_time = apply_slot(P.geocent_time, row);
     gw::GwSource S;
-    for (int i = 0; i < gw::kMaxIfo; ++i) { S.k_re[i] = 0.0; S.k_im[i] = 0.0; S.k_sq[i] = 0.0; S.dt[i] = 0.0; }
+    for (int i = 0; i < gw::kMaxIfo; ++i) { S.k_re[i] = 0.0; S.k_im[i] = 0.0; S.k_sq[i] = 0.0; S.dt[i] = 0.0; S.rs_re[i] = 1.0; S.rs_im[i] = 0.0; }
     gw::setup_source(q, P.f_ref, P.tidal != 0, S);
     if (S.valid != 0.0)
-        for (int i = 0; i < P.n_ifo; ++i) gw::project_source(q, P.det[i], i, P.start_time, P.gmst_ref_time, P.gmst_ref, P.gmst_rate, S);
+        for (int i = 0; i < P.n_ifo; ++i) gw::project_source(q, P.det[i], i, P.start_time, P.gmst_ref_time, P.gmst_ref, P.gmst_rate, stride_hz, S);
     src[b] = S;
 }
 
-// One (bin, sample): amplitude and phase of the waveform, then every detector's term.
-//   h_ifo = K A exp(-i pi (ph + 2 f dt)),  <d|h> += w conj(d) h,  <h|h> += w |K|^2 A^2
-template <int NIFO, bool PM>
-__device__ __forceinline__ void gw_bin_sample(const gw::GwSource& S, const gw::GwBin& bin, const double4 (&dat)[NIFO], double& a_re,
-                                              double& a_im, double& a_hh) {
-    double amp, ph;
-    gw::eval_bin(S, bin, amp, ph);
-    double re = 0.0, im = 0.0, hh = 0.0;
+// exp(i pi t) = (re, im) for any finite t of moderate size (|t| < 2^51: phases here stay below 1e7).  Exact reduction to
+// y in [-1/4, 1/4] (t - 2 rint(t / 2) and the quadrant k = rint(2 r) are exact in binary floating point), Taylor polynomials of
+// sin(pi y) / y and cos(pi y) in y^2 (truncation error < 5e-17 on the interval), quadrant fix-up by swap and sign.  31
+// instructions against the 45 of the library's sincospi, which also covers inf / NaN / huge arguments.
+__device__ __forceinline__ void gw_cispi(const double t, double& re, double& im) {
+    const double r = t - 2.0 * rint(0.5 * t);          // [-1, 1]
+    const double kq = rint(2.0 * r);                   // -2 .. 2
+    const double y = r - 0.5 * kq, y2 = y * y;
+    double sp = -2.1915353447830204e-05;
+    sp = fma(sp, y2, 0.00046630280576761234);
+    sp = fma(sp, y2, -0.007370430945714348);
+    sp = fma(sp, y2, 0.08214588661112819);
+    sp = fma(sp, y2, -0.5992645293207919);
+    sp = fma(sp, y2, 2.550164039877345);
+    sp = fma(sp, y2, -5.167712780049969);
+    sp = fma(sp, y2, 3.141592653589793);
+    sp *= y;
+    double cp = 4.303069587032944e-06;
+    cp = fma(cp, y2, -0.00010463810492484565);
+    cp = fma(cp, y2, 0.001929574309403922);
+    cp = fma(cp, y2, -0.02580689139001405);
+    cp = fma(cp, y2, 0.23533063035889312);
+    cp = fma(cp, y2, -1.3352627688545893);
+    cp = fma(cp, y2, 4.058712126416768);
+    cp = fma(cp, y2, -4.934802200544679);
+    cp = fma(cp, y2, 1.0);
+    // pi t = pi y + k pi / 2:  k = 0: (c, s); 1: (-s, c); 2: (-c, -s); -1: (s, -c); -2: (-c, -s)
+    const int k = (int)kq & 3;
+    const double c1 = (k & 1) ? sp : cp, s1 = (k & 1) ? cp : sp;
+    re = (k == 1 || k == 2) ? -c1 : c1;
+    im = (k == 2 || k == 3) ? -s1 : s1;
+}
+
+// ---------------------------------------------------------------------------------------
+// gw_logl: lanes = bins, ONE sample at a time, loops specialised by region.  A 256-thread workgroup owns GWL_ITERS x 256
+// consecutive bins and GWL_GROUP samples.  For each sample the chunk's region of phase and amplitude is a SCALAR decision (the
+// chunk's frequency range against the sample's region boundaries), so the matching instantiation of the bin loop runs with
+// just that region's constants -- few enough to stay in SGPRs for the whole loop (no scalar reloads, no waits) -- while the
+// per-bin records arrive as coalesced vector loads (in-order counter: the next pass's loads are in flight during this one).
+// The linear phase exp(-2 pi i f dt_d), with the antenna factor folded in, advances by one complex multiplication per pass.
+// ---------------------------------------------------------------------------------------
+constexpr int GWL_ITERS = 32;
+constexpr int GWL_CHUNK = GWL_THREADS * GWL_ITERS;        // 8192 bins
+constexpr int GWL_GROUP = 16;
+
+typedef const __attribute__((address_space(4))) double* gw_const_dp;      // constant address space: scalar loads
+typedef double gw_d4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) gw_d4v* gw_gd4p;             // global address space: global_load, in-order vmcnt
+typedef const __attribute__((address_space(1))) double* gw_gdp;
+
+template <int NIFO, bool PM, int PR, int AR, bool PLAIN>
+__device__ __forceinline__ void gw_sample_chunk(const gw_const_dp sp, const gw_gd4p basis, const gw_gdp basis5, const gw_gd4p dat, const long nb, const long bin0, const long k0,
+                                                 const double df, double& a_re, double& a_im, double& a_hh) {
+    // the sample's record through the scalar cache, INSIDE the specialised loop's function: only the fields this instantiation
+    // uses are loaded (the rest of the copy is dead code), few enough to stay in SGPRs for the whole loop
+    gw::GwSource L;
+    {
+        constexpr int NSRC = (int)(sizeof(gw::GwSource) / sizeof(double));
+        double* lp = reinterpret_cast<double*>(&L);
 #pragma unroll
-    for (int i = 0; i < NIFO; ++i) {
-        // theta / pi = -(ph + 2 f dt): reduce to [-1, 1] exactly before sincospi
-        double t = -(ph + 2.0 * bin.f * S.dt[i]);
-        t -= 2.0 * rint(0.5 * t);
-        double sn, cs;
-        sincospi(t, &sn, &cs);
-        const double zr = dat[i].x * cs + dat[i].y * sn;     // conj(w d) e^{i theta}
-        const double zi = dat[i].x * sn - dat[i].y * cs;
-        re += S.k_re[i] * zr - S.k_im[i] * zi;
-        if (PM) im += S.k_re[i] * zi + S.k_im[i] * zr;
-        hh += dat[i].z * S.k_sq[i];
+        for (int q = 0; q < NSRC; ++q) lp[q] = sp[q];
     }
-    a_re += amp * re;
-    if (PM) a_im += amp * im;
-    a_hh += amp * amp * hh;
+    // E_d at this lane's first bin, and the step of GWL_THREADS bins
+    double er[NIFO], ei[NIFO], rsr[NIFO], rsi[NIFO], ksq[NIFO];
+    const double f_first = (double)(k0 + bin0 + threadIdx.x) * df;
+#pragma unroll
+    for (int k = 0; k < NIFO; ++k) {
+        double cr, ci;
+        gw_cispi(-2.0 * f_first * L.dt[k], cr, ci);
+        er[k] = L.k_re[k] * cr - L.k_im[k] * ci;
+        ei[k] = L.k_re[k] * ci + L.k_im[k] * cr;
+        rsr[k] = L.rs_re[k]; rsi[k] = L.rs_im[k]; ksq[k] = L.k_sq[k];
+    }
+#pragma unroll 1
+    for (int j = 0; j < GWL_ITERS; ++j) {
+        const long i = bin0 + (long)j * GWL_THREADS + threadIdx.x;
+        if (i < nb) {
+            const gw_d4v bs = basis[i];
+            gw::GwBin bin;
+            bin.f = (double)(k0 + i) * df;
+            bin.f13 = bs[0]; bin.inv13 = bs[1]; bin.lnf13 = bs[2]; bin.fm76 = bs[3];
+            bin.p578 = basis5[i];
+            double amp, ph;
+            gw::eval_bin_t<PR, AR, PLAIN>(L, bin, amp, ph);
+            double cs, sn;
+            gw_cispi(-ph, cs, sn);
+            double qr = 0.0, qi = 0.0, hh = 0.0;
+#pragma unroll
+            for (int k = 0; k < NIFO; ++k) {
+                const gw_d4v d = dat[(long)k * nb + i];
+                qr += d[0] * er[k] + d[1] * ei[k];               // conj(w d) E
+                qi += d[0] * ei[k] - d[1] * er[k];
+                hh += d[2] * ksq[k];
+            }
+            a_re += amp * (cs * qr - sn * qi);
+            if (PM) a_im += amp * (cs * qi + sn * qr);
+            a_hh += amp * amp * hh;
+        }
+#pragma unroll
+        for (int k = 0; k < NIFO; ++k) {
+            const double t = er[k] * rsr[k] - ei[k] * rsi[k];
+            ei[k] = er[k] * rsi[k] + ei[k] * rsr[k];
+            er[k] = t;
+        }
+    }
 }
 
 template <int NIFO, bool PM>
-__global__ __launch_bounds__(GWL_THREADS) void gw_logl_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
-                                                              const long B, double* __restrict__ partial) {
+__global__ __launch_bounds__(GWL_THREADS, 4) void gw_logl_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                               const long B, double* __restrict__ partial) {
     const GwDev& P = *Pp;
-    __shared__ double red[GW_GROUP][GWL_WAVES][3];
-    const long n_groups = (B + GW_GROUP - 1) / GW_GROUP;
+    __shared__ double red[GWL_GROUP][GWL_WAVES][3];
+    const long n_groups = (B + GWL_GROUP - 1) / GWL_GROUP;
     const long g = (long)blockIdx.x % n_groups;       // sample group: the fast index (workgroups in flight share chunks)
     const long c = (long)blockIdx.x / n_groups;       // chunk
-    const long b0 = g * GW_GROUP;
-    const long bin0 = c * GW_CHUNK;
+    const long b0 = g * GWL_GROUP;
+    const long bin0 = c * GWL_CHUNK;
+    const long nb = P.n_bins, k0 = P.k0;
+    const double df = P.df;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double4* __restrict__ basis = P.basis;
-    const double4* __restrict__ dat = P.dat;
-    const long nb = P.n_bins;
-    for (int s2 = 0; s2 < GW_GROUP; s2 += 2) {
-        // (a sample beyond the batch re-evaluates the last one; nothing of it is stored)
-        const long ba = b0 + s2 < B ? b0 + s2 : B - 1;
-        const long bb = b0 + s2 + 1 < B ? b0 + s2 + 1 : B - 1;
-        const gw::GwSource& Sa = src[ba];
-        const gw::GwSource& Sb = src[bb];
-        double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        const bool va = Sa.valid != 0.0, vb = Sb.valid != 0.0;
-        for (int j = 0; j < GW_CHUNK_ITERS; ++j) {
-            const long i = bin0 + (long)j * GWL_THREADS + threadIdx.x;
-            if (i < nb) {
-                const double4 bs = basis[i];
-                gw::GwBin bin;
-                bin.f = (double)(P.k0 + i) * P.df;
-                bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
-                double4 d[NIFO];
-#pragma unroll
-                for (int k = 0; k < NIFO; ++k) d[k] = dat[(long)k * nb + i];
-                if (va) gw_bin_sample<NIFO, PM>(Sa, bin, d, acc[0][0], acc[0][1], acc[0][2]);
-                if (vb) gw_bin_sample<NIFO, PM>(Sb, bin, d, acc[1][0], acc[1][1], acc[1][2]);
-            }
+    // (global address space: global_load, in-order vmcnt only)
+    const gw_gd4p basis = (gw_gd4p)(uintptr_t)P.basis;
+    const gw_gdp basis5 = (gw_gdp)(uintptr_t)P.basis5;
+    const gw_gd4p dat = (gw_gd4p)(uintptr_t)P.dat;
+    const long i_last = (bin0 + GWL_CHUNK < nb ? bin0 + GWL_CHUNK : nb) - 1;
+    const double f_lo = (double)(k0 + bin0) * df, f_hi = (double)(k0 + i_last) * df;
+    for (int s = 0; s < GWL_GROUP; ++s) {
+        const long b = b0 + s < B ? b0 + s : B - 1;       // (a sample beyond the batch re-evaluates the last one; not stored)
+        const gw_const_dp sp = (gw_const_dp)(uintptr_t)(src + b);
+        const gw::GwSource* const so = nullptr;
+#define GW_FIELD(name) sp[(reinterpret_cast<const char*>(&so->name) - reinterpret_cast<const char*>(so)) / 8]
+        double a_re = 0.0, a_im = 0.0, a_hh = 0.0;
+        if (GW_FIELD(valid) != 0.0) {
+            const double fp1 = GW_FIELD(fp1), fp2 = GW_FIELD(fp2), fa1 = GW_FIELD(fa1), fa3 = GW_FIELD(fa3);
+            const int pr = f_hi < fp1 ? 0 : ((f_lo >= fp1 && f_hi < fp2) ? 1 : -1);
+            const int ar = f_hi < fa1 ? 0 : ((f_lo >= fa1 && f_hi < fa3) ? 1 : -1);
+            const bool plain = (GW_FIELD(has_tides) == 0.0 || f_hi <= GW_FIELD(ft1)) && f_hi <= GW_FIELD(f_cut);
+#undef GW_FIELD
+            const int code = (pr >= 0 && ar >= 0 && plain) ? pr * 2 + ar : -1;
+            if (code == 0) gw_sample_chunk<NIFO, PM, 0, 0, true>(sp, basis, basis5, dat, nb, bin0, k0, df, a_re, a_im, a_hh);
+            else if (code == 1) gw_sample_chunk<NIFO, PM, 0, 1, true>(sp, basis, basis5, dat, nb, bin0, k0, df, a_re, a_im, a_hh);
+            else if (code == 3) gw_sample_chunk<NIFO, PM, 1, 1, true>(sp, basis, basis5, dat, nb, bin0, k0, df, a_re, a_im, a_hh);
+            else gw_sample_chunk<NIFO, PM, -1, -1, false>(sp, basis, basis5, dat, nb, bin0, k0, df, a_re, a_im, a_hh);
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (k == 1 && !PM) continue;
-                const double t = gw_wave_sum(acc[q][k]);
-                if (lane == 63) red[s2 + q][wave][k] = t;
-            }
+        const double t0 = gw_wave_sum(a_re), t2 = gw_wave_sum(a_hh);
+        double t1 = 0.0;
+        if (PM) t1 = gw_wave_sum(a_im);
+        if (lane == 63) { red[s][wave][0] = t0; red[s][wave][1] = t1; red[s][wave][2] = t2; }
     }
     __syncthreads();
-    // partial[(c * 3 + k) * B + b]: waves summed in wave order
-    for (int t = threadIdx.x; t < GW_GROUP * 3; t += GWL_THREADS) {
+    for (int t = threadIdx.x; t < GWL_GROUP * 3; t += GWL_THREADS) {
         const int s = t / 3, k = t - 3 * s;
         if (b0 + s < B) {
             double v = 0.0;
-            if (k != 1 || PM)
-                for (int w = 0; w < GWL_WAVES; ++w) v += red[s][w][k];
+            for (int w = 0; w < GWL_WAVES; ++w) v += red[s][w][k];
             partial[((long)c * 3 + k) * B + b0 + s] = v;
         }
     }
@@ -257,12 +335,12 @@ __global__ __launch_bounds__(GWL_THREADS) void gw_logl_kernel(const GwDev* __res
 // mode 0: log-likelihood ratio (floor for invalid / non-finite); mode 1: the three inner products parts[b][3]
 __global__ __launch_bounds__(256) void gw_finish_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
                                                         const double* __restrict__ partial, const long B, const int mode,
-                                                        double* __restrict__ out) {
+                                                        const int n_chunks, double* __restrict__ out) {
     const GwDev& P = *Pp;
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double re = 0.0, im = 0.0, hh = 0.0;
-    for (int c = 0; c < P.n_chunks; ++c) {
+    for (int c = 0; c < n_chunks; ++c) {
         re += partial[((long)c * 3 + 0) * B + b];
         im += partial[((long)c * 3 + 1) * B + b];
         hh += partial[((long)c * 3 + 2) * B + b];
@@ -297,6 +375,7 @@ __global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict_
     if (in_band) {
         const double4 bs = P.basis[i];
         bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
+        bin.p578 = P.basis5[i];
         gw::eval_bin(S, bin, amp, ph);
     }
 #pragma unroll
@@ -450,7 +529,7 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
     GwDev& P = h->dev;
     P.n_ifo = n_ifo; P.tidal = c->tidal ? 1 : 0; P.mass_mode = c->mass_mode; P.phase_marg = c->phase_marginalization ? 1 : 0;
     P.n_bins = nb; P.k0 = k_lo; P.n_freq = NF; P.n_dim = c->n_dim;
-    P.n_chunks = (int32_t)((nb + GW_CHUNK - 1) / GW_CHUNK);
+    P.n_chunks = (int32_t)((nb + GWL_CHUNK - 1) / GWL_CHUNK);
     P.df = df; P.f_ref = c->reference_frequency; P.start_time = c->start_time;
     P.gmst_ref_time = c->gmst_ref_time; P.gmst_ref = c->gmst_ref; P.gmst_rate = c->gmst_rate;
     P.four_over_T = 4.0 / c->duration;
@@ -461,10 +540,11 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
     P.mass_a = c->mass_a; P.mass_b = c->mass_b; P.chi_1 = c->chi_1; P.chi_2 = c->chi_2; P.lambda_1 = c->lambda_1; P.lambda_2 = c->lambda_2;
     P.luminosity_distance = c->luminosity_distance; P.theta_jn = c->theta_jn; P.phase = c->phase; P.ra = c->ra; P.dec = c->dec;
     P.psi = c->psi; P.geocent_time = c->geocent_time;
-    std::vector<double> basis((size_t)4 * nb), dat((size_t)4 * nb * n_ifo, 0.0);
+    std::vector<double> basis((size_t)4 * nb), basis5((size_t)nb), dat((size_t)4 * nb * n_ifo, 0.0);
     for (int64_t i = 0; i < nb; ++i) {
         const gw::GwBin b = gw::make_bin((double)(k_lo + i) * df);
         basis[4 * i] = b.f13; basis[4 * i + 1] = b.inv13; basis[4 * i + 2] = b.lnf13; basis[4 * i + 3] = b.fm76;
+        basis5[i] = b.p578;
     }
     double noise = 0.0;
     for (int d = 0; d < n_ifo; ++d) {
@@ -495,7 +575,8 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
     };
     void* p = nullptr;
     hipError_t e = up(basis.data(), basis.size() * 8, &p);
-    if (e == hipSuccess) { P.basis = reinterpret_cast<const double4*>(p); e = up(dat.data(), dat.size() * 8, &p); }
+    if (e == hipSuccess) { P.basis = reinterpret_cast<const double4*>(p); e = up(basis5.data(), basis5.size() * 8, &p); }
+    if (e == hipSuccess) { P.basis5 = reinterpret_cast<const double*>(p); e = up(dat.data(), dat.size() * 8, &p); }
     if (e == hipSuccess) { P.dat = reinterpret_cast<const double4*>(p); e = up(&P, sizeof(P), &p); }
     if (e != hipSuccess) { nmma_gw_destroy(h); return fail(std::string("nmma_gw_create: ") + hipGetErrorString(e)); }
     h->dev_d = reinterpret_cast<GwDev*>(p);
@@ -529,9 +610,9 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
     if (gw_reserve(h, B) != 0) return 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const GwDev& P = h->dev;
-    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld, h->src);
-    const long n_groups = (B + GW_GROUP - 1) / GW_GROUP;
-    const dim3 grid((unsigned)(n_groups * P.n_chunks));
+    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld,
+                       (double)GWL_THREADS * h->dev.df, h->src);      // (the step of a lane's bin loop)
+    const dim3 grid((unsigned)(((B + GWL_GROUP - 1) / GWL_GROUP) * P.n_chunks));
     const bool pm = P.phase_marg != 0 || mode == 1;
     const bool prof = h->prof_on && (int)h->ev.size() + 2 <= 2 * h->prof_max;
     if (prof) {
@@ -540,8 +621,8 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
         h->ev.push_back(a); h->ev.push_back(b);
         GW_HIP(hipEventRecord(a, s));
     }
-#define GW_LAUNCH(N)                                                                                                                  \
-    do {                                                                                                                              \
+#define GW_LAUNCH(N)                                                                                                                   \
+    do {                                                                                                                               \
         if (pm) hipLaunchKernelGGL((gw_logl_kernel<N, true>), grid, dim3(GWL_THREADS), 0, s, h->dev_d, h->src, (long)B, h->partial);   \
         else hipLaunchKernelGGL((gw_logl_kernel<N, false>), grid, dim3(GWL_THREADS), 0, s, h->dev_d, h->src, (long)B, h->partial);     \
     } while (0)
@@ -553,7 +634,8 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
     }
 #undef GW_LAUNCH
     if (prof) GW_HIP(hipEventRecord(h->ev.back(), s));
-    hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode, out_dev);
+    hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode,
+                       P.n_chunks, out_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string(what) + " launch failed: " + hipGetErrorString(e));
     return 0;
@@ -575,7 +657,7 @@ int32_t nmma_gw_strain(nmma_gw_handle* h, const double* theta_dev, int64_t B, in
     if (gw_reserve(h, B) != 0) return 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const GwDev& P = h->dev;
-    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld, h->src);
+    hipLaunchKernelGGL(gw_source_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dev_d, theta_dev, (long)B, (long)ld, h->dev.df, h->src);
     const dim3 grid((unsigned)((P.n_freq + 255) / 256), (unsigned)B);
     double2* o = reinterpret_cast<double2*>(strain_dev);
     switch (P.n_ifo) {

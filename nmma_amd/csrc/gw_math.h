@@ -179,10 +179,13 @@ struct GwSource {
     double xa;                    // x^(1/2) = xa * f13 with x = (pi M f)^(2/3)
     double tphase;                // tidal phase / pi = tphase * xh^5 * N(xh) / D(xh)
     double tamp;                  // tidal amplitude bracket = tamp * x^5 * (1 + n1 x + n289 x^2.89) / (1 + d x^4)
-    double ln_xa2;                // ln(xa^2): x^2.89 = exp(2.89 * (ln_xa2 + 2 ln f13))
+    double xa578;                 // xa^5.78: x^2.89 = xa578 * f13^5.78 (the second factor is tabulated per bin)
     double ft1, ft2;              // Hz: Planck taper between the merger frequency and 1.2 x it
     // ---- projection onto each detector: h_ifo = (k_re + i k_im) * A * exp(-i pi (P(f) + 2 f dt))
     double k_re[kMaxIfo], k_im[kMaxIfo], k_sq[kMaxIfo], dt[kMaxIfo];
+    // exp(-2 pi i stride dt) for the frequency stride of the bin loop: the linear part of the phase advances by a complex
+    // multiplication from one of a lane's bins to its next (gw_logl_kernel)
+    double rs_re[kMaxIfo], rs_im[kMaxIfo];
 };
 
 struct GwDetector {
@@ -193,6 +196,7 @@ struct GwDetector {
 // per-bin basis
 struct GwBin {
     double f, f13, inv13, lnf13, fm76;
+    double p578;      // f13^5.78 = f^(2.89 * 2/3): x^2.89 of the tidal amplitude is a per-sample constant times this
 };
 GW_HD GwBin make_bin(double f) {
     GwBin b;
@@ -201,6 +205,7 @@ GW_HD GwBin make_bin(double f) {
     b.inv13 = 1.0 / b.f13;
     b.lnf13 = log(f) / 3.0;
     b.fm76 = 1.0 / (f * sqrt(b.f13));
+    b.p578 = exp(5.78 * b.lnf13);
     return b;
 }
 
@@ -456,7 +461,7 @@ GW_HD_NOINLINE void setup_source(const GwParams& q, double f_ref, bool tidal, Gw
         S.xa = a;
         S.tphase = ipi * (-kappa * 2.4375 / (XA * XB));
         S.tamp = -9.0 * kappa;
-        S.ln_xa2 = 2.0 * ln_a;
+        S.xa578 = exp(5.78 * ln_a);
         const double num = 1.0 + 3.35411203e-2 * kappa + 4.31460284e-5 * kappa * kappa;
         const double den = 1.0 + 7.54224145e-2 * kappa + 2.23626859e-4 * kappa * kappa;
         S.ft1 = 0.3586 / sqrt(m1 / m2) * num / den / M_sec / (2.0 * kPi);
@@ -469,7 +474,7 @@ GW_HD_NOINLINE void setup_source(const GwParams& q, double f_ref, bool tidal, Gw
 //   signal = F+ h+ + Fx hx = (F+ (1 + cos^2 i)/2 - i Fx cos i) h,   shifted by dt = (t_c - start_time) + delay.
 // gmst = gmst_ref + gmst_rate (t_c - gmst_ref_time): the host evaluates LAL's GMST polynomial (leap seconds included) once.
 GW_HD void project_source(const GwParams& q, const GwDetector& D, int i, double start_time, double gmst_ref_time, double gmst_ref,
-                          double gmst_rate, GwSource& S) {
+                          double gmst_rate, double stride_hz, GwSource& S) {
     const double gmst = fmod(gmst_ref + gmst_rate * (q.geocent_time - gmst_ref_time), 2.0 * kPi);
     const double phi = q.ra - gmst, theta = kPi / 2.0 - q.dec;
     const double cphi = cos(phi), sphi = sin(phi), cth = cos(theta), sth = sin(theta), cpsi = cos(q.psi), spsi = sin(q.psi);
@@ -490,21 +495,43 @@ GW_HD void project_source(const GwParams& q, const GwDetector& D, int i, double 
     S.k_im[i] = -fc * ci;
     S.k_sq[i] = S.k_re[i] * S.k_re[i] + S.k_im[i] * S.k_im[i];
     S.dt[i] = (q.geocent_time - start_time) + delay;
+    double turns = stride_hz * S.dt[i];
+    turns -= rint(turns);
+    S.rs_re[i] = cos(2.0 * kPi * turns);
+    S.rs_im[i] = -sin(2.0 * kPi * turns);
+}
+
+// a / b to (nearly) full precision without the IEEE division sequence: hardware reciprocal estimate + two Newton steps
+// (the per-bin loop divides twice per sample; relative error <= 2 ulp, far inside the phase budget)
+GW_HD double fast_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return a * r;
+#else
+    return a / b;
+#endif
 }
 
 // The waveform at one frequency bin: amplitude (strain, before the antenna factor) and phase / pi, such that
 //   h(f) = amp * exp(-i pi phase_over_pi).
 // LAL: IMRPhenDAmplitude, IMRPhenDPhase, SimNRTunedTidesFDTidalPhase_v2, SimNRTunedTidesFDTidalAmplitude, PlanckTaper.
-GW_HD void eval_bin(const GwSource& S, const GwBin& b, double& amp, double& phase_over_pi) {
+// PR / AR: the region of the phase / of the amplitude when the caller knows it for every lane it runs (0 inspiral,
+// 1 intermediate, 2 merger-ringdown; -1: decide per bin); PLAIN: the caller knows that the bin is below the Planck taper and below
+// f_cut, so neither is tested.  The sample-per-lane kernel classifies a whole chunk of bins once and runs the matching
+// instantiation: only that region's constants are live in registers.
+template <int PR, int AR, bool PLAIN>
+GW_HD void eval_bin_t(const GwSource& S, const GwBin& b, double& amp, double& phase_over_pi) {
     const double f = b.f, f13 = b.f13, inv13 = b.inv13;
     const double f23 = f13 * f13;
     // ---- phase
     double ph;
-    if (f < S.fp1) {
+    if (PR == 0 || (PR < 0 && f < S.fp1)) {
         const double inv2 = inv13 * inv13;
         ph = S.pc0 + inv13 * (S.pcm1 + inv13 * (S.pcm2 + inv13 * (S.pcm3 + inv2 * S.pcm5))) + f13 * (S.pc1 + f13 * S.pc2) +
              (S.pl5 + S.pl6 * f13) * b.lnf13 + f * (S.ps1 + f13 * (S.ps2 + f13 * S.ps3) + f * S.ps4);
-    } else if (f < S.fp2) {
+    } else if (PR == 1 || (PR < 0 && f < S.fp2)) {
         const double inv3 = inv13 * inv13 * inv13;
         ph = S.ic0 + S.ic1 * f + S.icm3 * (inv3 * inv3 * inv3) + S.icl * b.lnf13;
     } else {
@@ -513,9 +540,9 @@ GW_HD void eval_bin(const GwSource& S, const GwBin& b, double& amp, double& phas
     ph += S.ho2 * f23;
     // ---- amplitude bracket
     double br;
-    if (f < S.fa1) {
+    if (AR == 0 || (AR < 0 && f < S.fa1)) {
         br = 1.0 + f23 * (S.ai[0] + f13 * (S.ai[1] + f13 * (S.ai[2] + f13 * (S.ai[3] + f13 * (S.ai[4] + f13 * (S.ai[5] + f13 * (S.ai[6] + f13 * S.ai[7])))))));
-    } else if (f < S.fa3) {
+    } else if (AR == 1 || (AR < 0 && f < S.fa3)) {
         const double u = (f - S.fa1) * S.iu_scale;
         br = S.ip[0] + u * (S.ip[1] + u * (S.ip[2] + u * (S.ip[3] + u * S.ip[4])));
     } else {
@@ -527,10 +554,13 @@ GW_HD void eval_bin(const GwSource& S, const GwBin& b, double& amp, double& phas
         const double xh = S.xa * f13, x = xh * xh, x2 = x * x;
         const double num = 1.0 + x * (-12.615214237993088 + xh * 19.0537346970349 + x * (-21.166863146081035 + xh * 90.55082156324926 + x * -60.25357801943598));
         const double den = 1.0 + x * (-15.11120782773667 + xh * 22.195327350624694 + x * 8.064109635305156);
-        ph += S.tphase * (x2 * xh) * num / den;
-        const double x289 = exp(2.89 * (S.ln_xa2 + 2.0 * b.lnf13));
-        br += S.tamp * (x2 * x2 * x) * (1.0 + 4.157407407407407 * x + 2519.111111111111 * x289) / (1.0 + 13477.8073677 * x2 * x2);
-        if (f > S.ft1) {
+        // one reciprocal for the two rational functions: N/D = N Q r, P/Q = P D r with r = 1 / (D Q)
+        const double x289 = S.xa578 * b.p578;
+        const double pnum = 1.0 + 4.157407407407407 * x + 2519.111111111111 * x289, pden = 1.0 + 13477.8073677 * x2 * x2;
+        const double r = fast_div(1.0, den * pden);
+        ph += S.tphase * (x2 * xh) * (num * pden * r);
+        br += S.tamp * (x2 * x2 * x) * (pnum * den * r);
+        if (!PLAIN && f > S.ft1) {
             if (f >= S.ft2) taper = 0.0;
             else {
                 const double w = S.ft2 - S.ft1;
@@ -538,8 +568,13 @@ GW_HD void eval_bin(const GwSource& S, const GwBin& b, double& amp, double& phas
             }
         }
     }
-    amp = (f > S.f_cut || taper == 0.0) ? 0.0 : S.amp_scale * b.fm76 * br * taper;
+    if (PLAIN) amp = S.amp_scale * b.fm76 * br;
+    else amp = (f > S.f_cut || taper == 0.0) ? 0.0 : S.amp_scale * b.fm76 * br * taper;
     phase_over_pi = ph;
+}
+
+GW_HD void eval_bin(const GwSource& S, const GwBin& b, double& amp, double& phase_over_pi) {
+    eval_bin_t<-1, -1, false>(S, b, amp, phase_over_pi);
 }
 
 // ln I0(x) for x >= 0 (phase marginalisation: bilby's ln_i0 = log(ive(0, x)) + x): power series below 15, the asymptotic

@@ -25,7 +25,7 @@ void hc_gw_setup(const double* params, double f_ref, int tidal, const double* de
         GwDetector D;
         for (int k = 0; k < 9; ++k) D.tensor[k] = det[12 * i + k];
         for (int k = 0; k < 3; ++k) D.vertex[k] = det[12 * i + 9 + k];
-        project_source(q, D, i, start_time, gmst_ref_time, gmst_ref, gmst_rate, S);
+        project_source(q, D, i, start_time, gmst_ref_time, gmst_ref, gmst_rate, 2.0, S);
     }
     const double* s = reinterpret_cast<const double*>(&S);
     for (int k = 0; k < hc_gw_source_doubles(); ++k) out[k] = s[k];
