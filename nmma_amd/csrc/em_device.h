@@ -14,13 +14,6 @@ namespace nmma {
 // One record feeds (1 or 2) + 4 MFMAs per 16-sample row block; a wave streams its
 // records linearly with 16-byte loads (no LDS staging: every wave owns its hidden slice).
 __host__ __device__ constexpr int rec_floats(int kp) { return 256 + 64 * kp + 16; }
-// Split record of the role-split likelihood kernel (em_logl): layer 2 runs on v_mfma_f32_16x16x32_bf16 with an exact
-// three-way bf16 split of both operands (fp32 = 3 x 8 significant bits).  Per record (16 hidden units), in dwords:
-//   [0, 256)            lane l: (w1a, w1b, w2a, w2b)   each dword = two bf16: rows (0,1) / (2,3) of the lane group's four
-//   [256, 384)          lane l: (w3a, w3b)             hidden rows 4(l/16)+i, coefficient l%16; w = w1 + w2 + w3 exactly
-//   [384, 384+64 kp)    W1 fragment (fp32, as in the fp32 record)
-//   [.., +16)           b1 (fp32)
-__host__ __device__ constexpr int rec2_words(int kp) { return 384 + 64 * kp + 16; }
 
 enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2, MODE_LC_ABS = 3 };
 
@@ -46,8 +39,6 @@ struct EmDev {
     // surrogate
     const float* wrec;        // [M][HB + NPAD_REC][rec_floats(KP)]   (zero records: branch-free prefetch)
     int32_t wrec_bytes;
-    int32_t wrec2_bytes;
-    const uint32_t* wrec2;    // [M][HB + NPAD_REC][rec2_words(KP)]   split records of em_logl (see rec2_words)
     int32_t prio_valu, prio_mfma;   // s_setprio of the two roles of em_logl (NMMA_EM_PRIO="v,m"; default 3,0)
     int* watchdog;            // [4] device words: {tripped, code, workgroup*64+wave, value*65536+target} (em_logl hand-off waits)
     int32_t helpers;          // MFMA-role waves join the likelihood workers after their stream (NMMA_EM_HELPERS, default 1)
@@ -100,7 +91,6 @@ struct EmDev {
     int32_t lean_x, p92_tab;          // p92_tab: the P92 extinction magnitudes come from ext_tab (pre-pass kernel) -- lean task           // lean task extras needed (a filter with more than 32 points, a sampled em_syserr): em_logl<.., 3>
     int32_t tab_off_s1inv, any_two;   // 1 / s1dx (lean two-stage task); some item's sample_times differ from the SVD grid
     const ItemDesc* item_desc;   // [n_items]
-    const int32_t* iw_items;     // [n_items][8] compact copy for em_logl_iw: d0, nf, jlo, jhi, o, has_ul, m, record byte base
     int32_t lc_nf_max, model_kind;   // widest observed filter; enum nmma_model_kind
     const double* nu0;           // [M] filter frequencies (Hz) for analytic blackbody models
     // work items of em_logl: (observed filter, source index, model filter, n sources) x n_items

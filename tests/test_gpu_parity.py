@@ -47,40 +47,6 @@ def test_logl_matches_reference_golden(name, torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["c2_default", "fixed_distance", "fast_single_filter", "small_hidden", "edges", "conversions"])
-def test_in_wave_kernel_matches_golden(name, torch_cuda, monkeypatch):
-    """em_logl_iw (opt-in, NMMA_EM_IW=1): every wave owns an MLP slice and two samples.  Same goldens, same tolerance;
-    configurations it does not take (small hidden layer, upper-limit-only filters with > 32 points, transcendental
-    slot conversions ...) silently keep the role-split kernel -- the block size tells which one ran."""
-    torch = torch_cuda
-    monkeypatch.setenv("NMMA_EM_IW", "1")
-    case = cases.CASES[name]()
-    gold = cases.load_golden(name)
-    eng = engine_from_case(case)
-    th = torch.as_tensor(case["theta"], device="cuda:0")
-    got = eng.loglike(th).cpu().numpy()
-    eng.check()
-    block = eng.last_launch_geometry()["block"]
-    want = gold["logl"]
-    floor = want == FLOOR
-    assert np.array_equal(got == FLOOR, floor)
-    err = rel_err(got[~floor], want[~floor])
-    print(f"{name}: block {block}, max rel err {err.max() if err.size else 0:.3e}")
-    assert err.size == 0 or err.max() <= LOGL_RTOL
-    if name in ("c2_default", "fixed_distance", "fast_single_filter"):
-        assert block == 512, "the in-wave kernel should have taken this configuration"
-    # per-filter parts through the same kernel
-    chi, gp = (x.cpu().numpy() for x in eng.loglike_parts(th))
-    tot = chi.sum(axis=0) + gp.sum(axis=0)
-    ok = ~floor & np.isfinite(tot)
-    assert rel_err(tot[ok], want[ok]).max() <= LOGL_RTOL
-    # ragged batch sizes (partial last tile)
-    for n in (1, 17, 33):
-        sub = eng.loglike(th[:n]).cpu().numpy()
-        assert np.array_equal(sub, got[:n])
-    eng.close()
-
-
 @pytest.mark.parametrize("name", ["c2_default", "c2_dt05_limit", "c4_shape", "real_nets", "ncoeff7"])
 def test_coefficients_and_lightcurves(name, torch_cuda):
     torch = torch_cuda

@@ -20,9 +20,6 @@ unset NMMA_EM_NO_LEAN_LIM
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 tools/perf_gw.py 2048 > $o/stats_gw.log 2>&1
-export NMMA_EM_IW=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_iw -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_iw.log 2>&1
-unset NMMA_EM_IW
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_$c.log 2>&1
 done
