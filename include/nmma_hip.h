@@ -124,6 +124,13 @@ typedef struct nmma_em_config {
     nmma_slot redshift;                     /* used when redshift_mode == NMMA_Z_SLOT      */
     nmma_slot timeshift;                    /* default 0 (model.py:297)                    */
     nmma_slot ebv;                          /* default 0 (model.py:290)                    */
+    /* A sampled Hubble constant (core/base.py:161-164 -> core/conversion.py:57-101: every sample gets the redshift of ITS
+     * cosmology): with NMMA_Z_GRID the grid is looked up at d_L * H0 / hubble_reference -- in a flat universe d_L scales
+     * as c / H0 at fixed z, so one grid tabulated for hubble_reference serves every H0 (the h^2 dependence of the radiation
+     * density is ignored: <= 3e-6 relative on z below z = 0.05); the library interpolates z / d_L, which is nearly constant,
+     * instead of z.  hubble_reference = 0: no such scaling. */
+    nmma_slot hubble_constant;
+    double hubble_reference;
 
     /* ---- extinction, applied when Ebv != 0 (get_extinction_mags, model.py:323-350):
      *      NMMA_EXT_LINEAR      ext_mag[m] = ebv_coeff[m] * Ebv; coefficients are an input (any law that

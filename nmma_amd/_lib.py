@@ -71,6 +71,7 @@ class EmConfig(C.Structure):
         ("n_dim", C.c_int32),
         ("model_param", Slot * MAX_PARAMS),
         ("luminosity_distance", Slot), ("redshift", Slot), ("timeshift", Slot), ("ebv", Slot),
+        ("hubble_constant", Slot), ("hubble_reference", C.c_double),
         ("ebv_coeff", _pd), ("extinction_law", C.c_int32),
         ("n_obs_filters", C.c_int32), ("data_offsets", _pi),
         ("data_times", _pd), ("data_mags", _pd), ("data_sigmas", _pd),

@@ -66,6 +66,9 @@ struct EmDev {
     // theta mapping
     nmma_slot model_param[NMMA_MAX_PARAMS];
     nmma_slot lumdist, redshift, timeshift, ebv;
+    nmma_slot hubble;         // sampled Hubble constant: the z(d_L) grid is read at d_L * H0 * inv_h0_ref (has_h0)
+    double inv_h0_ref;
+    int32_t has_h0, pad_h0;
     // photometry (CSR over observed filters)
     const int32_t* doff;      // [O+1]
     const double* dt;         // [N]

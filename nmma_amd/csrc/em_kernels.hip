@@ -481,7 +481,12 @@ __device__ __forceinline__ void sample_scalars(const EmDev& P, const double* row
     if (P.redshift_mode == NMMA_Z_SLOT) {
         z = apply_slot(P.redshift, row);
     } else if (P.redshift_mode == NMMA_Z_GRID) {
-        z = interp_np(d_l, dist_grid, z_grid, P.n_cosmo, z_grid[0], z_grid[P.n_cosmo - 1]);
+        // (a sampled Hubble constant: the grid belongs to the reference H0, distances scale as 1 / H0)
+        // (with has_h0 the table holds z / d_L, a nearly constant function: linear interpolation of it is exact to ~1e-11
+        //  where interpolating z itself on 256 nodes is off by 1e-7 -- log L moves by 1e4 per unit redshift)
+        const double d_eff = P.has_h0 ? d_l * apply_slot(P.hubble, row) * P.inv_h0_ref : d_l;
+        z = interp_np(d_eff, dist_grid, z_grid, P.n_cosmo, z_grid[0], z_grid[P.n_cosmo - 1]);
+        if (P.has_h0) z *= d_eff;
     }
     scal[S_ZP1] = 1 + z;
     scal[S_IZP1] = 1.0 / (1 + z);   // only seeds the bracket guess (exactly re-checked)
@@ -698,7 +703,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     const double d_l = apply_slot(P.lumdist, row);
                     double z = 0.0;
                     if (P.redshift_mode == NMMA_Z_SLOT) z = apply_slot(P.redshift, row);
-                    else if (P.redshift_mode == NMMA_Z_GRID) z = interp_np(d_l, dgl_l, zgl_l, P.n_cosmo, zgl_l[0], zgl_l[P.n_cosmo - 1]);
+                    else if (P.redshift_mode == NMMA_Z_GRID) {
+                        const double d_eff = P.has_h0 ? d_l * apply_slot(P.hubble, row) * P.inv_h0_ref : d_l;
+                        z = interp_np(d_eff, dgl_l, zgl_l, P.n_cosmo, zgl_l[0], zgl_l[P.n_cosmo - 1]);
+                        if (P.has_h0) z *= d_eff;
+                    }
                     sc[S_ZP1] = 1 + z;
                     sc[S_IZP1] = 1.0 / (1 + z);
                     sc[S_RC] = redshift_correction(z);
@@ -2407,8 +2416,11 @@ __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, c
     const double kappa_r = pow(10.0, apply_slot(P.model_param[3], row));
     double z = 0.0;
     if (P.redshift_mode == NMMA_Z_SLOT) z = apply_slot(P.redshift, row);
-    else if (P.redshift_mode == NMMA_Z_GRID)
-        z = interp_np(apply_slot(P.lumdist, row), P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
+    else if (P.redshift_mode == NMMA_Z_GRID) {
+        const double d_eff = apply_slot(P.lumdist, row) * (P.has_h0 ? apply_slot(P.hubble, row) * P.inv_h0_ref : 1.0);
+        z = interp_np(d_eff, P.dist_grid, P.z_grid, P.n_cosmo, P.z_grid[0], P.z_grid[P.n_cosmo - 1]);
+        if (P.has_h0) z *= d_eff;
+    }
 
     // per-node time factors (thermalisation efficiency, Barnes+16 eq. 34)
     for (int j = lane; j < NS; j += 64) {

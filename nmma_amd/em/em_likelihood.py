@@ -68,14 +68,12 @@ class MultiFilterTransient:
         if names is None:
             names = self._names or self.sampling_layout()[0]
         names = list(names)
-        per_sample_cosmology = [n for n in names if n in ("Hubble_constant", "Omega_matter")]
-        if per_sample_cosmology:
-            # the device maps d_L -> z through ONE tabulated cosmology; a cosmology per sample would need
-            # cosmology_to_distance (a root-find per row) ahead of every launch
+        if "Omega_matter" in names:
+            # the device scales distances with a sampled H0 (one grid serves every H0 in a flat universe); a sampled matter
+            # density changes the shape of z(d_L) and would need a grid per sample
             from .. import _lib as L
-            raise L.NMMAHipError(f"sampled {per_sample_cosmology} need a redshift per sample under a varying "
-                                 "cosmology, which the device path does not compute: sample 'redshift' "
-                                 "(with or without 'luminosity_distance') instead, or fix the cosmology")
+            raise L.NMMAHipError("a sampled Omega_matter needs a z(d_L) relation per sample, which the device path does not "
+                                 "tabulate: sample 'redshift' instead, or fix Omega_matter")
         if self._engine is None or names != self._names:
             if self._engine is not None:
                 self._engine.close()

@@ -69,9 +69,20 @@ class LightCurveModelContainer:
             pr = priors["luminosity_distance"]
             lo, hi = getattr(pr, "minimum", None), getattr(pr, "maximum", None)
             if lo is not None and hi is not None and self.cosmo_grid is None and np.isfinite([lo, hi]).all():
-                # hi == lo (a DeltaFunction): a constant grid, np.interp then returns z(d_L) -- the engine
-                # applies that redshift as a constant (never z = 0 for a fixed distance)
-                self.cosmo_grid = get_cosmo_grids(lo, hi, getattr(pr, "cosmology", None))
+                cosmology = getattr(pr, "cosmology", None)
+                h0 = priors["Hubble_constant"] if "Hubble_constant" in priors else None
+                h_lo, h_hi = getattr(h0, "minimum", None), getattr(h0, "maximum", None)
+                if h0 is not None and h_lo is not None and h_hi is not None and h_hi > h_lo:
+                    # a sampled Hubble constant: one finer grid for the reference H0, wide enough for d_L * H0 / H0_ref over the
+                    # whole prior box (the device scales the distance per sample; 256 nodes = what the kernel stages in LDS)
+                    from ..core.conversion import native_cosmology
+                    self.hubble_reference = float(native_cosmology(cosmology).H0)
+                    self.cosmo_grid = get_cosmo_grids(lo * h_lo / self.hubble_reference, hi * h_hi / self.hubble_reference,
+                                                      cosmology, n=256)
+                else:
+                    # hi == lo (a DeltaFunction): a constant grid, np.interp then returns z(d_L) -- the engine
+                    # applies that redshift as a constant (never z = 0 for a fixed distance)
+                    self.cosmo_grid = get_cosmo_grids(lo, hi, cosmology)
 
     def sanity_checks(self, parameters):
         self.good_parameters = True
@@ -176,7 +187,7 @@ class SVDLightCurveModel(LightCurveModelContainer):
                   model_parameters=self.model_parameters,
                   sample_times=None if self._default_times() else self.model_times,
                   cosmo_grid=self.cosmo_grid, ebv_coeff=self.ebv_coeff, device=self.device,
-                  n_coeff=self.mag_ncoeff)
+                  n_coeff=self.mag_ncoeff, hubble_reference=getattr(self, "hubble_reference", None))
         # extinction (get_extinction_mags, model.py:323-342): caller-supplied linear coefficients win; else the
         # default host-frame SMC law is evaluated natively when the filter frequencies are known
         if self.ebv_coeff is None and self.extinction_law == "P92_SMC_host" and self.filter_nu0 is not None:

@@ -104,7 +104,7 @@ class EMEngine:
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
-                 model_kind="svd", filter_nu0=None, extinction_law=None):
+                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None):
         self._handle = None
         lib = L.load_library()
         fixed = dict(fixed or {})
@@ -179,6 +179,19 @@ class EMEngine:
         if "redshift" in names or "redshift" in fixed:
             cfg.redshift_mode = L.Z_SLOT
             cfg.redshift = _plain_slot("redshift", names, fixed, 0.0)
+        elif "Hubble_constant" in names and ("luminosity_distance" in names or "luminosity_distance" in fixed):
+            # every sample carries its own cosmology (core/base.py:161-164, core/conversion.py:57-101): the grid is tabulated for
+            # `hubble_reference` and read at d_L * H0 / hubble_reference (flat universe: d_L scales as c / H0 at fixed z)
+            if cosmo_grid is None or not hubble_reference:
+                raise L.NMMAHipError("Hubble_constant is sampled: pass the z(d_L) grid of a reference H0 as cosmo_grid together with "
+                                     "hubble_reference (SVDLightCurveModel.check_vs_priors builds both from the priors)")
+            dg, zg = _f64(cosmo_grid[0]), _f64(cosmo_grid[1])
+            keep += [dg, zg]
+            cfg.redshift_mode, cfg.n_cosmo = L.Z_GRID, len(dg)
+            cfg.dist_grid, cfg.z_grid = _ptr(dg, C.c_double), _ptr(zg, C.c_double)
+            cfg.redshift = L.Slot.constant(0.0)
+            cfg.hubble_constant = L.Slot.column(names.index("Hubble_constant"))
+            cfg.hubble_reference = float(hubble_reference)
         elif "luminosity_distance" in fixed and "luminosity_distance" not in names:
             # a FIXED distance still carries its redshift: the reference's get_cosmo_grids(d, d) is a constant
             # grid, so np.interp returns z(d_L) (model.py:255-267, conversion.py:49-55)
@@ -330,7 +343,7 @@ class EMEngine:
                    detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
                    filter_nu0=case.get("filter_nu0"),
                    extinction_law="P92_SMC_host" if case.get("filter_nu0") is not None else None,
-                   device=device)
+                   hubble_reference=case.get("hubble_reference"), device=device)
 
     # ------------------------------------------------------------------ calls
     def _dev_theta(self, theta):

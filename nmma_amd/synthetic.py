@@ -160,6 +160,8 @@ def draw_theta(seed, batch, names=None):
             cols.append(rng.uniform(0.1, 2.0, batch))
         elif n == "Ebv":
             cols.append(rng.uniform(0.0, 0.5, batch))
+        elif n == "Hubble_constant":                      # priors/Bu2019lm_Hubble.prior
+            cols.append(rng.uniform(50.0, 90.0, batch))
         elif n == "theta_jn":                             # isotropic viewing angle on [0, pi]: folded by the conversion
             cols.append(np.arccos(rng.uniform(-1.0, 1.0, batch)))
         elif n == "cos_theta_jn":

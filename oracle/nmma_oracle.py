@@ -92,6 +92,12 @@ def redshift_from_parameters(parameters, cosmo_grid=None, z_of_dl=None):
     """
     if "redshift" in parameters:
         return parameters["redshift"]
+    if "luminosity_distance" in parameters and "Hubble_constant" in parameters:
+        # core/base.py:161-164 -> cosmology_to_distance (core/conversion.py:57-101): the redshift of the sample's own cosmology,
+        # root-found per sample; ``z_of_dl(d_L, H0)`` stands in for the astropy call
+        if z_of_dl is None:
+            raise ValueError("oracle: a sampled Hubble_constant needs z_of_dl(d_L, H0)")
+        return z_of_dl(parameters["luminosity_distance"], parameters["Hubble_constant"])
     if "luminosity_distance" in parameters:
         if cosmo_grid is not None:
             dist_grid, z_grid = cosmo_grid
@@ -252,7 +258,8 @@ class OracleSVDModel:
     """
 
     def __init__(self, model_parameters, svd_model, filters=None, sample_times=None,
-                 mag_ncoeff=None, cosmo_grid=None, ext_mag_func=None, mlp_mode="f32"):
+                 mag_ncoeff=None, cosmo_grid=None, ext_mag_func=None, mlp_mode="f32", z_of_dl=None):
+        self.z_of_dl = z_of_dl          # (d_L, H0) -> z for a sampled Hubble constant (stands in for the astropy root-find)
         self.model_parameters = list(model_parameters)
         self.svd_mag_model = svd_model
         self.filters = list(filters) if filters is not None else list(svd_model.keys())
@@ -274,7 +281,7 @@ class OracleSVDModel:
         self.luminosity_distance = parameters.get("luminosity_distance", 1e-5)
         self.distmod = distance_modulus_nmma(self.luminosity_distance)
         self.timeshift = parameters.get("timeshift", 0.0)
-        self.redshift = redshift_from_parameters(parameters, self.cosmo_grid)
+        self.redshift = redshift_from_parameters(parameters, self.cosmo_grid, self.z_of_dl)
         return [parameters[k] for k in self.model_parameters]
 
     def generate_lightcurve(self, sample_times, parameters):
@@ -627,6 +634,6 @@ def likelihood_from_case(case, use_scipy=True, mlp_mode="f32"):
         ext = lambda redshift, ebv: extinction_mags_p92_smc(nu0, redshift, ebv)      # noqa: E731
     model = OracleSVDModel(case["model_parameters"], case["svd"], filters=case["model_filters"],
                                sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
-                               ext_mag_func=ext, mlp_mode=mlp_mode)
+                               ext_mag_func=ext, mlp_mode=mlp_mode, z_of_dl=case.get("z_of_dl"))
     return OracleLikelihood(model, case["data"], case["systematics"], case["observed_filters"],
                                 detection_limit=case["detection_limit"], use_scipy=use_scipy)

@@ -422,6 +422,33 @@ def case_extinction_p92():
     return c
 
 
+def case_hubble_sampled():
+    """A sampled Hubble constant (priors/Bu2019lm_Hubble.prior: H0 in [50, 90], d_L in [1, 200] Mpc): every sample's redshift
+    comes from ITS cosmology (core/base.py:161-164 -> conversion.py:57-101, a root-find per sample in the reference).  The
+    device reads ONE 256-node grid, tabulated for H0 = 67.66, at d_L * H0 / 67.66; the oracle root-finds per sample in the
+    same matter + Lambda cosmology the grid was made with (astropy is absent: the cosmology itself is an input)."""
+    names = ["luminosity_distance", "Hubble_constant", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"]
+    c = _base(seed=9954, batch=48, names=[n for n in names if n != "Hubble_constant"])
+    rng = np.random.default_rng(9955)
+    h0 = rng.uniform(50.0, 90.0, 48)
+    c["theta"] = np.insert(c["theta"], 1, h0, axis=1)
+    c["names"] = names
+    h_ref, om0 = 67.66, 0.30966
+    c["hubble_reference"] = h_ref
+    c["cosmo_grid"] = syn.flat_lcdm_grid(1.0 * 50.0 / h_ref, 200.0 * 90.0 / h_ref, n=256, H0=h_ref, Om0=om0)
+
+    def z_of_dl(d, h):
+        lo, hi = 0.0, 1.0
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            zz = np.linspace(0.0, mid, 2049)
+            dl = (1 + mid) * 299792.458 / h * np.trapezoid(1.0 / np.sqrt(om0 * (1 + zz) ** 3 + (1 - om0)), zz)
+            lo, hi = (mid, hi) if dl < d else (lo, mid)
+        return 0.5 * (lo + hi)
+    c["z_of_dl"] = z_of_dl
+    return c
+
+
 def case_log_grid():
     """The CLI's default grid when --em-tmin/--em-tmax are given (150 log-spaced sample times,
     em/utils.py:87-88): two-stage interpolation on a non-uniform grid (bisection instead of an index guess)."""
@@ -451,6 +478,7 @@ SHAPE_CASES = {
     "extinction_p92": case_extinction_p92,
     "log_grid": case_log_grid,
     "nonuniform_tt": case_nonuniform_tt,
+    "hubble_sampled": case_hubble_sampled,
 }
-ORACLE_ONLY_CASES = ("extinction_limit", "extinction_linear", "extinction_p92")
+ORACLE_ONLY_CASES = ("extinction_limit", "extinction_linear", "extinction_p92", "hubble_sampled")
 CASES.update({k: v for k, v in SHAPE_CASES.items() if k not in ORACLE_ONLY_CASES})

@@ -68,6 +68,49 @@ def test_at2017gfo_real_photometry_through_build_em_likelihood():
         build_em_likelihood(model, cases.at2017gfo_raw_photometry(), case["trigger_time"], priors, error_budget=None)
 
 
+def test_sampled_hubble_constant_through_the_plugin():
+    """priors/Bu2019lm_Hubble.prior: H0 sampled next to d_L.  check_vs_priors tabulates one 256-node z(d_L) grid for the native
+    cosmology's own H0 and the device scales every sample's distance by H0 / H0_ref; the oracle root-finds every sample's
+    redshift in its own cloned cosmology (radiation density included, which does NOT scale with H0: the stated <= 3e-6
+    deviation on z shows up as ~1e-8 on log L)."""
+    from nmma_amd import synthetic as syn
+    from nmma_amd.core.conversion import native_cosmology
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    from oracle import nmma_oracle as orc
+    from tests.helpers import SimplePrior
+    case = cases.case_hubble_sampled()
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    priors["luminosity_distance"], priors["Hubble_constant"] = SimplePrior(1.0, 200.0), SimplePrior(50.0, 90.0)
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"],
+                               model_parameters=case["model_parameters"], sample_times=case["sample_times"])
+    model.check_vs_priors(priors)
+    assert len(model.cosmo_grid[0]) == 256 and model.hubble_reference == pytest.approx(67.66)
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(case["observed_filters"], systematics_file=None, error_budget=1.0, light_curve_times=times)
+    lik = EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, priors, filters=case["observed_filters"])
+    got = lik.log_likelihood_batch(case["theta"], case["names"])
+    base = native_cosmology(None)
+    # the device's definition of "the sample's cosmology": the reference cosmology's expansion history E(z) with the sample's H0,
+    # i.e. z(d_L; H0) = z_ref(d_L H0 / H0_ref) -- exact for matter + Lambda
+    case["z_of_dl"] = lambda d, h: base.z_at_luminosity_distance(float(d) * float(h) / base.H0)
+    want = orc.log_likelihood_batch(orc.likelihood_from_case(case, use_scipy=False), case["names"], case["theta"])
+    assert np.all(want > FLOOR)
+    err = rel_err(got, want)
+    # ... against astropy-style clone(H0=...), whose photon / neutrino densities scale as 1 / h^2 (DESIGN section 8): z moves by
+    # <= 3e-6 relative, log L -- which changes by ~1e4 per unit redshift -- by a few 1e-5 relative
+    case["z_of_dl"] = lambda d, h: base.clone(H0=float(h)).z_at_luminosity_distance(float(d))
+    clone = orc.log_likelihood_batch(orc.likelihood_from_case(case, use_scipy=False), case["names"], case["theta"])
+    print(f"sampled H0: max rel err {err.max():.2e}; against per-sample clones with rescaled radiation {rel_err(got, clone).max():.2e}")
+    assert err.max() <= 1e-6 and rel_err(got, clone).max() <= 2e-4
+    # per-sample reference API: the conversion chain adds the redshift on the host, the device uses it as given
+    p = dict(zip(case["names"], (float(v) for v in case["theta"][5])))
+    assert lik.log_likelihood(p) == pytest.approx(want[5], rel=1e-6)
+    with pytest.raises(Exception, match="Omega_matter"):
+        lik.sub_model.engine(case["names"] + ["Omega_matter"])
+
+
 def test_gen_detector_lc_matches_golden():
     case = cases.case_c2_dt05_limit()
     gold = cases.load_golden("c2_dt05_limit")

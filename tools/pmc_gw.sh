@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: SQ instruction-mix / busy counters of gw_logl_kernel at a reduced config-5 shape (B = 2048).
-o=gpurun_out/pmc_gw_${1:-x}
+o=gpurun_out/${1:-x}/pmc_gw
 export TMPDIR=/tmp
 rm -rf $o; mkdir -p $o
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS --kernel-trace --output-format csv -d $o/a -- python3 tools/perf_gw_fused.py --batch 2048 --reps 2 > $o/a.log 2>&1

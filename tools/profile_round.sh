@@ -7,7 +7,7 @@
 #                                               em_fused outputs), bench with the opt-in in-wave kernel, gw (inner products)
 #   rocprofv3 --pmc (separate passes)        -> <tag>/pmc_<set>/      for the bench command
 # Under rocprofv3 the program goes directly after `--` (no env / bash -c hops).
-tag=${1:-r02}
+tag=${1:-r03}
 o=gpurun_out/$tag
 rm -rf $o; mkdir -p $o
 export TMPDIR=/tmp
@@ -20,6 +20,18 @@ unset NMMA_EM_NO_LEAN_LIM
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 tools/perf_gw.py 2048 > $o/stats_gw.log 2>&1
+# the GW leg from parameters at config 5's shape (16 384 samples x 259 585 bins x 3 detectors), with and without phase marginalisation
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw_fused -- python3 tools/perf_gw_fused.py --batch 16384 --reps 5 > $o/stats_gw_fused.log 2>&1
+python3 tools/perf_gw_fused.py --batch 16384 --reps 5 --pm > $o/gw_fused_pm.log 2>&1
+python3 tools/perf_gw_fused.py --batch 2048 --reps 5 > $o/gw_fused_2048.log 2>&1
+bash tools/pmc_gw.sh $tag > $o/pmc_gw.log 2>&1
+# the real AT2017gfo photometry (9 filters, CLI grid, sampled em_syserr)
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_at2017gfo -- python3 tools/perf_case.py at2017gfo 4096 > $o/stats_at2017gfo.log 2>&1
+# small batches: kernel time against the batch size with and without the band split; bench lines at 512 rows and at one row
+python3 tools/perf_small_batch.py > $o/small_batch.log 2>&1
+python3 bench.py --steps 200 --warmup 20 --batch 512 --no-cpu-baseline > $o/bench_line_b512.json 2> $o/bench_b512.err
+python3 bench.py --steps 200 --warmup 20 --batch 1 --no-cpu-baseline > $o/bench_line_b1.json 2> $o/bench_b1.err
+python3 tools/perf_table.py > $o/perf_table.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_$c.log 2>&1
 done

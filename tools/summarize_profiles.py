@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -67,8 +67,15 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(dst, f"{tag}_bench_line.json"))
-for name in ("stats_models.log", "stats_dt05.log", "stats_dt05ext.log", "stats_c4.log", "stats_gw.log"):
+for name in ("bench_line_b512.json", "bench_line_b1.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
+for name in ("stats_models.log", "stats_dt05.log", "stats_dt05ext.log", "stats_c4.log", "stats_gw.log", "stats_gw_fused.log", "gw_fused_pm.log",
+             "gw_fused_2048.log", "pmc_gw.log", "stats_at2017gfo.log", "small_batch.log", "perf_table.log"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        # (keep the result lines, not rocprofv3's chatter)
+        keep = [ln for ln in open(f, errors="replace") if not ln.startswith(("W2026", "E2026", "I2026")) and "amdgpu.ids" not in ln]
+        open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)
 print(json.dumps({k: v["mean"] for k, v in pmc.items() if isinstance(v, dict)}, indent=1))
