@@ -411,8 +411,9 @@ def test_hubble_constant_conversion_and_device_refusal():
     assert lik.post_process_bestfit(None, bestfit_params={"luminosity_distance": 40.0, "Hubble_constant": 70.0}) is None
     mft = MultiFilterTransient.__new__(MultiFilterTransient)
     mft._engine = mft._names = None
-    with pytest.raises(L.NMMAHipError, match="Hubble_constant"):
-        mft.engine(["luminosity_distance", "Hubble_constant", "log10_mej"])
+    # (a sampled Hubble constant runs on the device since round 3: tests/test_gpu_plugin.py; a sampled matter density does not)
+    with pytest.raises(L.NMMAHipError, match="Omega_matter"):
+        mft.engine(["luminosity_distance", "Hubble_constant", "Omega_matter", "log10_mej"])
 
 
 def test_kernel_register_budget():
