@@ -482,7 +482,9 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
                 val = external_lc[m.model]
                 if isinstance(val, (tuple, list)):
                     val, ok = val
-                    bad = ~torch.as_tensor(np.asarray(ok, dtype=bool))
+                    # (the mask may be a CUDA tensor, the natural companion of a CUDA light-curve tensor)
+                    bad = ~(ok.to(torch.bool) if isinstance(ok, torch.Tensor) else torch.as_tensor(np.asarray(ok, dtype=bool)))
+                    bad = bad.to(f"cuda:{self.device}")
                     failed = bad if failed is None else (failed | bad)
                 lc = torch.as_tensor(val).to(f"cuda:{self.device}")
             else:

@@ -77,18 +77,26 @@ class GWStrainLikelihood:
             raise L.NMMAHipError(f"strain must be complex128, got {strain.dtype}")
         if strain.dim() != 3 or tuple(strain.shape[1:]) != (self.n_ifo, self.n_freq):
             raise L.NMMAHipError(f"strain must be [B, {self.n_ifo}, {self.n_freq}], got {tuple(strain.shape)}")
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if s.device.index != self.device:
+            raise L.NMMAHipError(f"stream belongs to cuda:{s.device.index}, the likelihood to cuda:{self.device}")
+        # staging (host-to-device copy, .contiguous(), the output allocation) runs on torch's current stream: the launch stream has
+        # to wait for it when it is a different one
         strain = strain.to(dev).contiguous()
         n = strain.shape[0]
         if out is None:
             out = torch.empty(n, dtype=torch.float64, device=dev)
         elif (out.dtype != torch.float64 or out.device != dev or out.numel() < n or not out.is_contiguous()):
             raise L.NMMAHipError(f"out must be a contiguous float64 tensor on {dev} with >= {n} elements")
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        if s.cuda_stream != cur.cuda_stream:
+            s.wait_stream(cur)
         real = torch.view_as_real(strain)
-        L.check(self._lib.nmma_gw_loglike_ratio(C.c_void_p(real.data_ptr()), C.c_void_p(self._data.data_ptr()),
-                                                C.c_void_p(self._weight.data_ptr()), n, self.n_ifo, self.n_freq,
-                                                self.duration, C.c_void_p(out.data_ptr()), self.device,
-                                                C.c_void_p(s.cuda_stream)), "nmma_gw_loglike_ratio")
+        if n:
+            L.check(self._lib.nmma_gw_loglike_ratio(C.c_void_p(real.data_ptr()), C.c_void_p(self._data.data_ptr()),
+                                                    C.c_void_p(self._weight.data_ptr()), n, self.n_ifo, self.n_freq,
+                                                    self.duration, C.c_void_p(out.data_ptr()), self.device,
+                                                    C.c_void_p(s.cuda_stream)), "nmma_gw_loglike_ratio")
         return out[:n]
 
     def log_likelihood_batch(self, strain, out=None, stream=None):
