@@ -24,7 +24,7 @@
 //   gw_finish_kernel   sums the chunk partials in chunk order (the order does not depend on the batch size), applies 4/T,
 //                      the phase marginalisation and the floor.
 // Roofline: fp64 vector FMA (78.6 TFLOP/s); algorithmic flops per (bin, sample) are counted in DESIGN section 3.5, which also
-// lists the three formulations measured on the way (43.0 -> 30.1 ms at config 5's shape).
+// lists the three formulations measured on the way (43.0 -> 28.9 ms at config 5's shape).
 //
 // Also here: gw_loglike_ratio_kernel, the HBM-streaming reduction for strain supplied by the caller (round 2).
 #include <hip/hip_runtime.h>
@@ -245,7 +245,8 @@ __device__ __forceinline__ void gw_sample_chunk(const gw_const_dp sp, const gw_g
         ei[k] = L.k_re[k] * ci + L.k_im[k] * cr;
         rsr[k] = L.rs_re[k]; rsi[k] = L.rs_im[k]; ksq[k] = L.k_sq[k];
     }
-#pragma unroll 1
+    // (two passes per trip: two independent dependency chains per lane; four were slower under the 128-VGPR cap)
+#pragma unroll 2
     for (int j = 0; j < GWL_ITERS; ++j) {
         const long i = bin0 + (long)j * GWL_THREADS + threadIdx.x;
         if (i < nb) {
