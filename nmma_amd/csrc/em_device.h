@@ -68,7 +68,8 @@ struct EmDev {
     nmma_slot lumdist, redshift, timeshift, ebv;
     nmma_slot hubble;         // sampled Hubble constant: the z(d_L) grid is read at d_L * H0 * inv_h0_ref (has_h0)
     double inv_h0_ref;
-    int32_t has_h0, pad_h0;
+    int32_t has_h0;
+    int32_t n_bands;       // > 1 only in the per-band copies of the split launch of small batches (grid.y = n_bands)
     // photometry (CSR over observed filters)
     const int32_t* doff;      // [O+1]
     const double* dt;         // [N]

@@ -259,6 +259,7 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 // fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
 constexpr int TMAP_MAX = 512;
+constexpr int SPLIT_COUNTER_BYTES = 64 * 1024;    // split launch: one arrival counter per tile, in front of the band workspace
 // fast mode: most photometry points (all filters) staged in LDS as [t | m | 1/sigma | log sigma]
 constexpr int DAT_MAX = 2560;
 // most points of one filter the lean task takes (passes of 32 per group of 16 lanes; beyond this the extended task's wider
@@ -581,6 +582,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
+    constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2;    // small batches: one band per workgroup (launch_logl_one)
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
@@ -748,28 +750,38 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
         }
-        for (int j = vt; j < W * TS; j += NV) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
-        for (int j = vt; j < NS; j += NV) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? 1.0 / (P.st[j + 1] - P.st[j]) : 0.0; }
+        // The table copies below do not depend on the per-sample chains above: with the staged prologue the chains occupy
+        // likelihood waves 0-3 only, so waves 4-7 take ALL the copies and the two run side by side (a band's workgroup of the
+        // split launch has nothing to hide its prologue behind, so the prologue costs the longer of the two instead of their sum)
+        const bool two_lane_prologue = staged && NVW == 8;
+        const int cvt = two_lane_prologue ? vt - 256 : vt;
+        const int cnv = two_lane_prologue ? NV - 256 : NV;
+        if (cvt >= 0) {
+        // (slots: one per work item; some task flavours file a band's sums under its observed-filter index instead, which in a
+        //  band's own workgroup of the split launch can lie beyond its item count -- the layout always holds P.O slots)
+        for (int j = cvt; j < (W > P.O ? W : P.O) * TS; j += cnv) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
+        for (int j = cvt; j < NS; j += cnv) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? 1.0 / (P.st[j + 1] - P.st[j]) : 0.0; }
         if constexpr (FAST) {
             int* tmap = reinterpret_cast<int*>(smem + L.tmap);
             gci32p src = as_global(P.task_map[R - 1]);
-            for (int j = vt; j < P.n_tasks[R - 1] && j < TMAP_MAX; j += NV) tmap[j] = src[j];
+            for (int j = cvt; j < P.n_tasks[R - 1] && j < TMAP_MAX; j += cnv) tmap[j] = src[j];
             if (L.dat >= 0) {
                 double* dat = reinterpret_cast<double*>(smem + L.dat);
                 const int nd = P.n_data;
                 if constexpr (!EXT) {      // lean task: one {t, m, 1/sigma, ln sigma} record per datum
                     gcf64p src4 = as_global(P.dat4);
-                    for (int j = vt; j < 4 * nd; j += NV) dat[j] = src4[j];
+                    for (int j = cvt; j < 4 * nd; j += cnv) dat[j] = src4[j];
                 } else {
                     gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
-                    for (int j = vt; j < nd; j += NV) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
+                    for (int j = cvt; j < nd; j += cnv) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
                 }
             }
         }
         {
             gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
             int* dst = reinterpret_cast<int*>(smem + L.itab);
-            for (int j = vt; j < W * ITEM_WORDS; j += NV) dst[j] = src[j];
+            for (int j = cvt; j < W * ITEM_WORDS; j += cnv) dst[j] = src[j];
+        }
         }
 
         // Static tables of a model filter (basis rows, span, mins, stage-1 lerp tables) are
@@ -1936,34 +1948,51 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // ---- sum over filters + floor (core/base.py:178-182)
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
+        const int nb = SPLITTABLE ? P.n_bands : 1;
         if (vt < TS && tile0 + vt < B) {
             const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
-            if (out == nullptr) {
-                // split launch: this workgroup owns one band; its sums are in chi_parts / gp_parts already (written by the
-                // tasks, NaN for a bad sample) and em_combine_bands adds the bands.  Only a tripped watchdog is news here.
-                if (isbad) chi_parts[(long)itab[W - 1].o * B + tile0 + vt] = dnan();
-            } else {
+            if (!SPLITTABLE || nb <= 1) {
                 double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
                 for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
                 double tot = c + g;
                 if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
                 out[tile0 + vt] = tot;
+            } else {
+                // split launch: this workgroup owns ONE band, whose sums sit in the slot of its last item or in the slot of its
+                // observed filter (by task flavour; the other one holds zeros, and 0 + x is exact).  They are parked in the
+                // workspace [2][bands][B] that gp_parts points at; NaN marks a bad sample
+                const int o = itab[W - 1].o;
+                double c = chi_tot[(W - 1) * TS + vt], g = gp_tot[(W - 1) * TS + vt];
+                if (o != W - 1) { c += chi_tot[o * TS + vt]; g += gp_tot[o * TS + vt]; }
+                gp_parts[(long)blockIdx.y * B + tile0 + vt] = isbad ? dnan() : c;
+                gp_parts[((long)nb + blockIdx.y) * B + tile0 + vt] = g;
+            }
+        }
+        if (SPLITTABLE && nb > 1) {
+            // The band that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused
+            // epilogue above, bit for bit -- and re-arms the counter for the next launch.  (Counters: the 64 KiB in front of the
+            // workspace, zeroed when it is allocated.  Release / acquire at agent scope: the bands of a tile run on any XCD.)
+            unsigned* cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(gp_parts) - SPLIT_COUNTER_BYTES) + blockIdx.x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            unsigned prev = 0;
+            if (vt == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev == (unsigned)(nb - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (vt == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (vt < TS && tile0 + vt < B) {
+                    double c = 0.0, g = 0.0;
+                    for (int y = 0; y < nb; ++y) {
+                        c += gp_parts[(long)y * B + tile0 + vt];
+                        g += gp_parts[((long)nb + y) * B + tile0 + vt];
+                    }
+                    double tot = c + g;
+                    if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+                    out[tile0 + vt] = tot;
+                }
             }
         }
     }
-}
-
-// Sum over observed bands + floor for the split launch of small batches: the arithmetic of em_logl's own epilogue
-// (running sums of the truncated-Gaussian and of the survival-function parts in band order, then their sum; core/base.py:178-182).
-__global__ __launch_bounds__(256) void em_combine_bands(const double* __restrict__ chi, const double* __restrict__ gp, const long B,
-                                                        const int O, const int always_floor, double* __restrict__ out) {
-    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double c = 0.0, g = 0.0;
-    for (int o = 0; o < O; ++o) { c += chi[(long)o * B + b]; g += gp[(long)o * B + b]; }
-    double tot = c + g;
-    if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
-    out[b] = tot;
 }
 
 // =======================================================================================

@@ -106,6 +106,7 @@ class EMEngine:
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
                  model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None):
         self._handle = None
+        self._host_out = {}
         lib = L.load_library()
         fixed = dict(fixed or {})
         names = list(parameter_names)
@@ -382,11 +383,16 @@ class EMEngine:
             th = _f64(theta)
             if th.ndim != 2 or th.shape[1] < len(self.parameter_names):
                 raise L.NMMAHipError(f"theta must be [B, >={len(self.parameter_names)}], got {th.shape}")
-            res = np.empty(th.shape[0])
-            L.check(self._lib.nmma_em_loglike_host(self._handle, _ptr(th, C.c_double), th.shape[0],
-                                                   th.shape[1], _ptr(res, C.c_double)),
+            # (a reusable result buffer per batch size, with its address: the per-call Python overhead is kept to ~2 us)
+            slot = self._host_out.get(th.shape[0])
+            if slot is None:
+                if len(self._host_out) >= 16:
+                    self._host_out.clear()
+                res = np.empty(th.shape[0])
+                slot = self._host_out[th.shape[0]] = (res, res.ctypes.data)
+            L.check(self._lib.nmma_em_loglike_host(self._handle, th.ctypes.data, th.shape[0], th.shape[1], slot[1]),
                     "nmma_em_loglike_host")
-            return res
+            return slot[0].copy()
         t = self._dev_theta(theta)
         if out is None:
             out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
