@@ -192,8 +192,8 @@ def main():
         # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
         # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
         # by the dispatch latency behind the start event); with a collective between launches, single launches.
-        os.environ["NMMA_PROFILE_GROUP"] = "8" if world == 1 else "1"
-        os.environ["NMMA_PROFILE_STRIDE"] = "2" if world == 1 else "4"
+        os.environ["NMMA_PROFILE_GROUP"] = os.environ.get("NMMA_BENCH_EVENT_GROUP", "8" if world == 1 else "1")
+        os.environ["NMMA_PROFILE_STRIDE"] = os.environ.get("NMMA_BENCH_EVENT_STRIDE", "2" if world == 1 else "4")
         eng.profile_begin(args.steps)
         t0 = time.perf_counter()
         for i in range(args.steps):

@@ -1322,6 +1322,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         bool inside_[NSL], valid_[NSL];
         int lo_[NSL];
         lds_c2p D_[NSL];
+        // The kernels that take further passes over a filter with more than 32 points (both slots of a lane then belong to ONE
+        // sample) keep that sample's scalars and window in registers across the passes: 12 fewer VALU instructions per pass.
+        constexpr bool HOIST = LEANX && !TYPEB;
+        double h_zp1 = 0.0, h_tsh = 0.0, h_izp1 = 0.0, h_tlo = 0.0, h_thi = 0.0, h_dmrc = 0.0, h_izdt = 0.0, h_guess0 = 0.0;
+        if constexpr (HOIST) {
+            const lds_cdp sc = (lds_cdp)(scal + s_[0] * 8);
+            h_zp1 = sc[S_ZP1]; h_tsh = sc[S_TS]; h_izp1 = sc[S_IZP1];
+            h_tlo = st_lo * h_zp1 + h_tsh; h_thi = st_hi * h_zp1 + h_tsh;
+            h_dmrc = sc[S_DMOD] + sc[S_RC];
+            h_izdt = h_izp1 * inv_dt;
+            h_guess0 = -((h_tsh * h_izp1 + st0) * inv_dt);
+        }
         // (filters with 17 .. 32 points take one pass over the lane's two slots; more points further passes of 32: `pp`)
         auto stage_p = [&](const int pp) {
 #pragma unroll
@@ -1331,8 +1343,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             D_[u] = dat4 + 2 * (d0 + (valid_[u] ? dd : 0));
             const double t = D_[u][0][0];
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
-            const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
-            const double t_lo = st_lo * zp1 + tsh, t_hi = st_hi * zp1 + tsh;
+            const double zp1 = HOIST ? h_zp1 : sc[S_ZP1], tsh = HOIST ? h_tsh : sc[S_TS], izp1 = HOIST ? h_izp1 : sc[S_IZP1];
+            const double t_lo = HOIST ? h_tlo : st_lo * zp1 + tsh, t_hi = HOIST ? h_thi : st_hi * zp1 + tsh;
             inside_[u] = range_ok & (t >= t_lo) & (t <= t_hi);
             int lo;
             if constexpr (NONUNI) {
@@ -1347,7 +1359,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 }
                 lo = lo > jhi - 1 ? jhi - 1 : lo;
             } else {
-                lo = (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
+                // (HOIST: the same guess from one FMA on per-sample constants -- it may differ from the unfused form only for an
+                //  epoch within rounding of a node, where both brackets give the same value)
+                lo = HOIST ? (int)floor(fma(t, h_izdt, h_guess0)) : (int)floor(((t - tsh) * izp1 - st0) * inv_dt);
                 lo = lo > jhi - 1 ? jhi - 1 : lo;
                 lo = lo < jlo ? jlo : lo;
             }
@@ -1467,14 +1481,23 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int u = 0; u < NSL; ++u) {
             const f64x2 tm = D_[u][0], sl = D_[u][1];       // {t, m}, {1/sigma, ln sigma}
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
-            const double dmrc = sc[S_DMOD] + sc[S_RC], izdt = sc[S_IZP1] * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
+            const double dmrc = HOIST ? h_dmrc : sc[S_DMOD] + sc[S_RC];
+            const double izdt = (HOIST && !NONUNI) ? h_izdt : (HOIST ? h_izp1 : sc[S_IZP1]) * (NONUNI ? stl_l[NS + lo_[u]] : inv_dt);
             double y0 = ynode_[0][u], y1 = ynode_[1][u];
-            if constexpr (LEANX) {       // extinction magnitude of this sample and item (filled by the prologue, model.py:323-342)
-                const double ext = ext_l[s_[u]];       // (no branch here: 0 when there is no extinction)
-                y0 = y0 + ext; y1 = y1 + ext;
+            double est;
+            if constexpr (HOIST) {
+                // the sample's offsets (extinction of this item + distance modulus + K-correction) added once, to the left node:
+                // the slope is the difference of the node magnitudes themselves
+                const double yl = (y0 + ext_l[s_[0]]) + dmrc;
+                est = ((y1 - y0) * izdt) * dtx_[u] + yl;
+            } else {
+                if constexpr (LEANX) {       // extinction magnitude of this sample and item (filled by the prologue, model.py:323-342)
+                    const double ext = ext_l[s_[u]];       // (no branch here: 0 when there is no extinction)
+                    y0 = y0 + ext; y1 = y1 + ext;
+                }
+                y0 = y0 + dmrc; y1 = y1 + dmrc;
+                est = ((y1 - y0) * izdt) * dtx_[u] + y0;
             }
-            y0 = y0 + dmrc; y1 = y1 + dmrc;
-            const double est = ((y1 - y0) * izdt) * dtx_[u] + y0;
             double isig = sl[0], lsig = sl[1];
             bool sig_bad = false;
             if constexpr (SYS) {

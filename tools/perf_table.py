@@ -15,15 +15,19 @@ from tests.helpers import engine_from_case, plugin_from_case  # noqa: E402
 
 
 def timed(fn, n=30, warm=5):
+    import gc
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    gc.collect()          # (a full collection takes ~75 ms with torch imported and would otherwise fire inside a timed loop now and then)
+    gc.disable()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
         fn()
     e1.record()
     torch.cuda.synchronize()
+    gc.enable()
     return e0.elapsed_time(e1) / n * 1e3
 
 
