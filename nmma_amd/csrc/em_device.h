@@ -23,7 +23,8 @@ struct ItemDesc {
     int32_t o, ks, m, nsrc;
     int32_t G, d0, nf, kind;
     int32_t jlo, jhi, identity, same_grid;
-    double lim, e_const, ebvc, pad;
+    double lim, e_const, ebvc;
+    int32_t tabi, pad_i;      // item-staged photometry (EmDev::dat_in_tab): this item's table in EmDev::tabi (survives the band split's re-indexing)
     int32_t fast, has_ul;
     int32_t ntask[2];         // fast modes: tasks of this item per tile of 16 / 32 samples (index R - 1)
 };
@@ -110,6 +111,11 @@ struct EmDev {
     const double* sys_ndx;    // [N]  node spacing
     const double* sys_noff;   // [N]  t - node time
     const int32_t* d_item;    // [N] first work item of each datum's observed filter (em_lc_loglike's flat pass over the photometry)
+    // Item-staged photometry (lean task with so much photometry that staging ALL of it leaves room for one ring slot only,
+    // BASELINE config 4): LDS then holds the epochs of all points (stage P) and each ring slot the {t, m, 1/sigma, ln sigma}
+    // records of its own item behind the basis rows -- tabi[k] = [first tab_off_dat bytes of tab[m_k] | records of item k].
+    const unsigned char* tabi;
+    int32_t tabi_bytes, dat_in_tab, tab_off_dat, pad_tabi;
     int32_t lean_gen, pad_gen;        // general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
 };
 

@@ -517,7 +517,8 @@ struct LdsW {
 constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
 
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
-                                         int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0) {
+                                         int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0,
+                                         int dat_point_bytes = 32) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -532,7 +533,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
-    if (L.dat >= 0) off = align16(off + 4 * n_data * 8);
+    if (L.dat >= 0) off = align16(off + n_data * dat_point_bytes);     // (8: the epochs only -- item-staged photometry, EmDev::dat_in_tab)
     L.epar = off;  off = align16(off + (all_fast ? n_sys_slots * TS * 8 : 0));        // fast modes: sysv[slot][sample]
     L.exttab = off; off = align16(off + ext_rows * TS * 8);          // lean task with extinction: ext_mag[item][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
@@ -553,7 +554,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // (ring_max: NMMA_EM_RING=<n>, read at nmma_em_create -- an upper bound on the ring depth: a shallower ring leaves LDS to kernels
 //  that share the CUs, e.g. RCCL's while a collective overlaps the likelihood)
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4) {
+                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4, int dat_point_bytes = 32) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     if (want > ring_max) want = ring_max < 1 ? 1 : ring_max;
@@ -561,7 +562,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
             // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
@@ -769,8 +770,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 double* dat = reinterpret_cast<double*>(smem + L.dat);
                 const int nd = P.n_data;
                 if constexpr (!EXT) {      // lean task: one {t, m, 1/sigma, ln sigma} record per datum
-                    gcf64p src4 = as_global(P.dat4);
-                    for (int j = cvt; j < 4 * nd; j += cnv) dat[j] = src4[j];
+                    if (LEANX && P.dat_in_tab) {      // item-staged photometry: the epochs only, the records come with the item's rows
+                        gcf64p sdt = as_global(P.dt);
+                        for (int j = cvt; j < nd; j += cnv) dat[j] = sdt[j];
+                    } else {
+                        gcf64p src4 = as_global(P.dat4);
+                        for (int j = cvt; j < 4 * nd; j += cnv) dat[j] = src4[j];
+                    }
                 } else {
                     gcf64p sdt = as_global(P.dt), sdm = as_global(P.dm), sis = as_global(P.dinvsig), sls = as_global(P.dlogsig);
                     for (int j = cvt; j < nd; j += cnv) { dat[j] = sdt[j]; dat[nd + j] = sdm[j]; dat[2 * nd + j] = sis[j]; dat[3 * nd + j] = sls[j]; }
@@ -1288,7 +1294,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), itab[k - NBUF].ntask[R - 1], P.watchdog, 800 + k);
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
             typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
-            gbyte_p src = (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
+            // (item-staged photometry: the item's own table, its records behind the filter's rows)
+            gbyte_p src = (LEANX && P.dat_in_tab) ? (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes)
+                                                  : (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
             lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
             for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
                 __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
@@ -1306,7 +1314,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cdp stl_l = (lds_cdp)stl;
         typedef __attribute__((ext_vector_type(2))) double f64x2;
         typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
-        const lds_c2p dat4 = (lds_c2p)(smem + L.dat);
+        // photometry: records {t, m | 1/sigma, ln sigma} of all points in LDS -- or, item-staged (EmDev::dat_in_tab), the epochs of
+        // all points there (stage P) and the item's records in its ring slot (stage Q)
+        const bool item_dat = LEANX && __builtin_amdgcn_readfirstlane(P.dat_in_tab) != 0;
+        const lds_cdp tdat = (lds_cdp)(smem + L.dat);
+        const int tstride = item_dat ? 1 : 4;                                   // doubles between the epochs of consecutive points
+        const lds_c2p dat4 = item_dat ? (lds_c2p)(tabl + (k % NBUF) * P.tab_fast_bytes + P.tab_off_dat) : (lds_c2p)(smem + L.dat);
+        const int dbase = item_dat ? 0 : d0;
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
         const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
         const bool range_ok = jhi > jlo;
@@ -1340,8 +1354,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int u = 0; u < NSL; ++u) {
             const int dd = TYPEB ? gi : gi + 16 * u + 32 * pp;
             valid_[u] = dd < nf;
-            D_[u] = dat4 + 2 * (d0 + (valid_[u] ? dd : 0));
-            const double t = D_[u][0][0];
+            const int dix = valid_[u] ? dd : 0;
+            D_[u] = dat4 + 2 * (dbase + dix);
+            const double t = LEANX ? tdat[(d0 + dix) * tstride] : D_[u][0][0];
             const lds_cdp sc = (lds_cdp)(scal + s_[u] * 8);
             const double zp1 = HOIST ? h_zp1 : sc[S_ZP1], tsh = HOIST ? h_tsh : sc[S_TS], izp1 = HOIST ? h_izp1 : sc[S_IZP1];
             const double t_lo = HOIST ? h_tlo : st_lo * zp1 + tsh, t_hi = HOIST ? h_thi : st_hi * zp1 + tsh;

@@ -532,8 +532,8 @@ def test_wide_theta_rows(name, torch_cuda):
 
 @pytest.mark.parametrize("name", ["c2_default", "syserr_param", "log_grid", "averaging", "c2_dt05_limit", "extinction_p92", "many_points"])
 def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monkeypatch):
-    """Small batches run one workgroup per (tile, observed band) plus a kernel that adds the bands in the fused epilogue's
-    order: bit-identical to the one-workgroup-per-tile launch, for every lean flavour, ragged batch sizes and floored rows."""
+    """Small batches run one workgroup per (tile, observed band); the band that finishes a tile last adds the bands in the fused
+    epilogue's order: bit-identical to the one-workgroup-per-tile launch, for every lean flavour, ragged batch sizes and floored rows."""
     torch = torch_cuda
     case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
     _, theta = syn.draw_theta(4242, 1100, case["names"])
@@ -559,4 +559,31 @@ def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monke
     split_small = eng.last_launch_geometry()["grid_y"] > 1
     eng.loglike(torch.as_tensor(syn.draw_theta(1, 8192, case["names"])[1], device="cuda:0"))
     assert split_small and eng.last_launch_geometry()["grid_y"] == 1
+    eng.close()
+
+
+def test_item_staged_photometry_gives_the_same_bits(torch_cuda, monkeypatch):
+    """BASELINE config 4's shape (12 x 200 points): the records of all points next to the ring leave room for ONE ring slot, so the
+    lean task stages each item's records with its basis rows instead (EmDev::dat_in_tab) -- same arithmetic, same bits, for
+    16- and 32-sample tiles and for the band split of small batches."""
+    torch = torch_cuda
+    case = cases.case_c4_shape()
+    _, theta = syn.draw_theta(777, 4200, case["names"])
+    theta[5, 1] = np.nan
+    th = torch.as_tensor(theta, device="cuda:0")
+    monkeypatch.setenv("NMMA_EM_NO_ITEM_DAT", "1")
+    eng = engine_from_case(case)
+    want = eng.loglike(th).cpu().numpy()
+    lds_all = eng.last_launch_geometry()["lds_bytes"]
+    eng.close()
+    monkeypatch.delenv("NMMA_EM_NO_ITEM_DAT")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    geo = eng.last_launch_geometry()
+    assert geo["tile_samples"] == 32 and geo["lds_bytes"] != lds_all, "item-staged photometry not engaged"
+    assert np.array_equal(got, want)
+    for n in (1, 33, 700, 4096):                           # split launch (<= 384 workgroups), 16-sample tiles, ragged tail
+        assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), want[:n]), n
+    assert want[5] == FLOOR and (want > FLOOR).sum() > 3000
     eng.close()
