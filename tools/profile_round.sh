@@ -25,6 +25,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw_fused -- pyt
 python3 tools/perf_gw_fused.py --batch 16384 --reps 5 --pm > $o/gw_fused_pm.log 2>&1
 python3 tools/perf_gw_fused.py --batch 2048 --reps 5 > $o/gw_fused_2048.log 2>&1
 bash tools/pmc_gw.sh $tag > $o/pmc_gw.log 2>&1
+bash tools/pmc_c4.sh $tag > $o/pmc_c4.log 2>&1
 # the real AT2017gfo photometry (9 filters, CLI grid, sampled em_syserr)
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_at2017gfo -- python3 tools/perf_case.py at2017gfo 4096 > $o/stats_at2017gfo.log 2>&1
 # small batches: kernel time against the batch size with and without the band split; bench lines at 512 rows and at one row
