@@ -115,7 +115,11 @@ struct EmDev {
     // BASELINE config 4): LDS then holds the epochs of all points (stage P) and each ring slot the {t, m, 1/sigma, ln sigma}
     // records of its own item behind the basis rows -- tabi[k] = [first tab_off_dat bytes of tab[m_k] | records of item k].
     const unsigned char* tabi;
-    int32_t tabi_bytes, dat_in_tab, tab_off_dat, pad_tabi;
+    int32_t tabi_bytes, dat_in_tab, tab_off_dat;
+    const double* dva;        // dense lean task: [M][ceil(NT/16)][3][64] MFMA A operands, A[node lane % 16][k = 4 step + lane / 16] of
+                              // [VA o span | mins | 0] (the constant-1 "coefficient" NC adds mins)
+    int32_t dense;            // dense lean task (em_logl<.., 6>): every filter has so many points that reconstructing ALL nodes of
+                              // (item, 16 samples) on the fp64 matrix cores beats two basis rows per datum; implies dat_in_tab
     int32_t lean_gen, pad_gen;        // general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
 };
 

@@ -259,6 +259,7 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 // fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
 constexpr int TMAP_MAX = 512;
+constexpr int DENSE_NBUF = 2, DENSE_STRIDE = 17;   // dense lean task: node-magnitude buffers of 16 samples, row stride in doubles (odd: bank spread)
 constexpr int SPLIT_COUNTER_BYTES = 64 * 1024;    // split launch: one arrival counter per tile, in front of the band workspace
 // fast mode: most photometry points (all filters) staged in LDS as [t | m | 1/sigma | log sigma]
 constexpr int DAT_MAX = 2560;
@@ -507,6 +508,7 @@ constexpr int logl_threads(int NMW, int NVW) { return 64 * (NMW + NVW); }
 
 struct LdsW {
     int32_t praw, scal, stl, part, chi, gp, bad, cdl, itab, est, tab, sync, xn, stage, tmap, dat, epar, exttab, total;
+    int32_t nodes;      // dense lean task (em_logl<.., 6>): DENSE_NBUF buffers of [dense_rows][DENSE_STRIDE] fp64 node magnitudes of 16 samples
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
 };
@@ -518,7 +520,7 @@ constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
 
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
                                          int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0,
-                                         int dat_point_bytes = 32) {
+                                         int dat_point_bytes = 32, int dense_rows = 0) {
     const int TS = 16 * R;
     LdsW L{};
     int off = 0;
@@ -529,7 +531,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + (3 * n_items + 4) * 4);
+    L.sync = off; off = align16(off + (3 * n_items + 4 + 4 * n_items) * 4);      // (+ produced / consumed counters per (item, 16 samples): dense task)
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
@@ -538,7 +540,8 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.exttab = off; off = align16(off + ext_rows * TS * 8);          // lean task with extinction: ext_mag[item][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
     L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
-    L.cdl = off;  off = align16(off + 16 * 2 * 4 * 16 * 8);          // per wave (any role): 2 x 4 slots x 16 coefficients
+    L.cdl = off;  off = align16(off + (dense_rows ? 0 : 16 * 2 * 4 * 16 * 8));      // per wave (any role): 2 x 4 slots x 16 coefficients (the dense task has none)
+    L.nodes = off; off = align16(off + DENSE_NBUF * dense_rows * DENSE_STRIDE * 8);
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);     // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
@@ -554,7 +557,8 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 // (ring_max: NMMA_EM_RING=<n>, read at nmma_em_create -- an upper bound on the ring depth: a shallower ring leaves LDS to kernels
 //  that share the CUs, e.g. RCCL's while a collective overlaps the likelihood)
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
-                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4, int dat_point_bytes = 32) {
+                                     int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4, int dat_point_bytes = 32,
+                                     int dense_rows = 0) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     if (want > ring_max) want = ring_max < 1 ? 1 : ring_max;
@@ -562,7 +566,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
             // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes, dense_rows);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
     constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2;    // small batches: one band per workgroup (launch_logl_one)
+    constexpr bool DENSE = FASTM == 6;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
-    for (int j = tid; j < 3 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
+    for (int j = tid; j < 7 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
     if (tid == 0) g_wd_trip = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
@@ -1295,7 +1300,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
             typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
             // (item-staged photometry: the item's own table, its records behind the filter's rows)
-            gbyte_p src = (LEANX && P.dat_in_tab) ? (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes)
+            // (dense: [b2 | records] only -- the basis rows are the A operands of the reconstruction, read from global memory)
+            gbyte_p src = (LEANX && P.dat_in_tab) ? (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes + (DENSE ? P.tab_off_b2 : 0))
                                                   : (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
             lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
             for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
@@ -1319,7 +1325,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const bool item_dat = LEANX && __builtin_amdgcn_readfirstlane(P.dat_in_tab) != 0;
         const lds_cdp tdat = (lds_cdp)(smem + L.dat);
         const int tstride = item_dat ? 1 : 4;                                   // doubles between the epochs of consecutive points
-        const lds_c2p dat4 = item_dat ? (lds_c2p)(tabl + (k % NBUF) * P.tab_fast_bytes + P.tab_off_dat) : (lds_c2p)(smem + L.dat);
+        const lds_c2p dat4 = item_dat ? (lds_c2p)(tabl + (k % NBUF) * P.tab_fast_bytes + P.tab_off_dat - (DENSE ? P.tab_off_b2 : 0))
+                                      : (lds_c2p)(smem + L.dat);
         const int dbase = item_dat ? 0 : d0;
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
         const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
@@ -1386,6 +1393,19 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         };
         stage_p(0);
+        // dense: the A operands of this task's node tiles -- rows of [VA o span | mins | 0] pre-swizzled per filter at create
+        // (EmDev::dva, one coalesced 512-byte load per MFMA) -- requested before the waits for the surrogate and the node buffer
+        const int dn_tt = (NT + 15) >> 4;
+        double dav[DENSE ? 4 : 1][3];
+        if constexpr (DENSE) {
+            gcf64p dva = as_global(P.dva) + (size_t)it.m * dn_tt * 3 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (c & 3) + 4 * q;
+#pragma unroll
+                for (int step = 0; step < 3; ++step) dav[q][step] = tt < dn_tt ? dva[(tt * 3 + step) * 64] : 0.0;
+            }
+        }
         NM_TS(2);
         // ---- stage Q (needs the coefficients of item k)
         if (c == 0) {
@@ -1399,12 +1419,55 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         NM_TS(5);
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
-        const lds_cfp b2l = (lds_cfp)(tbl + P.tab_off_b2);
+        const lds_cfp b2l = (lds_cfp)(tbl + (DENSE ? 0 : P.tab_off_b2));
         const float b2v = b2l[gi];
         constexpr int NCC = TYPEB ? 2 : 1;
         lds_c2p cc_[NCC];          // the sample's 10 coefficients (fp64) in this wave's LDS slots: [wave][q][g][16]
+        // ---- dense: the four tasks of (item k, 16 samples) reconstruct ALL nodes of those samples together,
+        //      mag[node][sample] = (VA[node, :] . c[sample, :]) span[node] + mins[node], 16 nodes x 16 samples per
+        //      v_mfma_f64_16x16x4_f64 (K = NC in three steps, zero-padded; operand layout as in em_fused) into one of
+        //      DENSE_NBUF LDS buffers; a datum then READS its two node magnitudes instead of reconstructing two rows.
+        lds_cdp nodes_l = nullptr;
+        int* unit_done = nullptr;
+        if constexpr (DENSE) {
+            const int h = c >> 2;                                 // 4 samples per task: tasks 4h .. 4h + 3 share the 16 samples of half h
+            const int unit = R * k + h;
+            int* const unit_prod = sync + 3 * W + 4 + unit;
+            unit_done = sync + 3 * W + 4 + R * W + unit;
+            const lds_dp nb = (lds_dp)(smem + L.nodes) + (unit % DENSE_NBUF) * (((NT + 15) & ~15) * DENSE_STRIDE);
+            nodes_l = (lds_cdp)nb;
+            // B operands: coefficient 4 step + lane / 16 of sample 16 h + lane % 16 (slice sums in the fixed order, + b2, as fp64);
+            // "coefficient" NC is the constant 1 that multiplies the mins column of the A table
+            const int sj = 16 * h + (lane & 15), kq = lane >> 4;
+            double bq[3];
 #pragma unroll
-        for (int q = 0; q < NCC; ++q) {
+            for (int step = 0; step < 3; ++step) {
+                const int kc = 4 * step + kq;
+                const lds_cfp pp = pbuf + ((sj >> 4) * 16 + (sj & 15)) * PSTR + (kc < 16 ? kc : 0);
+                float cm = pp[0];
+#pragma unroll
+                for (int w = 1; w < NSLICE; ++w) cm += pp[w * (R * 16 * PSTR)];
+                cm += b2l[kc < 16 ? kc : 0];
+                bq[step] = kc < NC ? (double)cm : (kc == NC ? 1.0 : 0.0);
+            }
+            // the buffer's previous unit has been consumed by all four of its tasks
+            if (unit >= DENSE_NBUF) sync_wait(unit_done - DENSE_NBUF, 4, P.watchdog, 360 + k);
+            typedef double f64x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (c & 3) + 4 * q;                  // this task's node tiles (uniform)
+                if (tt >= dn_tt) break;
+                f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int step = 0; step < 3; ++step) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dav[q][step], bq[step], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nb[(16 * tt + 4 * r + kq) * DENSE_STRIDE + (lane & 15)] = acc[r];
+            }
+            sync_signal(unit_prod, lane);
+            sync_wait(unit_prod, 4, P.watchdog, 370 + k);        // all node tiles of the unit are in LDS
+        }
+#pragma unroll
+        for (int q = 0; q < (DENSE ? 0 : NCC); ++q) {
             // slice reduction (fixed order) + bias of the second Dense: lane gi owns coefficient gi of its sample
             const int s = s_[q];
             const lds_cfp pp = pbuf + ((s >> 4) * 16 + (s & 15)) * PSTR + gi;
@@ -1428,8 +1491,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cdp ext_l = (lds_cdp)(smem + L.exttab) + (P.has_ebv ? k : 0) * TS;
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
+        if constexpr (DENSE) {
 #pragma unroll
-        for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
+            for (int u = 0; u < NSL; ++u) {
+                const lds_cdp nd = nodes_l + lo_[u] * DENSE_STRIDE + (s_[0] & 15);
+                ynode_[0][u] = nd[0]; ynode_[1][u] = nd[DENSE_STRIDE];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < (DENSE ? 0 : (TWO ? 2 : 1)); ++pass) {
             lds_c2p ra_[NSL], rb_[NSL];
 #pragma unroll
             for (int u = 0; u < NSL; ++u) {
@@ -1586,6 +1656,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
         NM_TS(6);
+        if constexpr (DENSE) sync_signal(unit_done, lane);      // this task no longer reads the unit's node buffer
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
 #undef NM_TS
     };
@@ -1960,11 +2031,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
+                    } else if constexpr (FASTM == 6) {   // dense: sample_times = the SVD grid, more than 16 points in every filter (host)
+                        if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t);
                     } else {
                         if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     }
                 };
-                if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
+                if constexpr (FASTM == 6) run(std::false_type{});
+                else if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
             }
 #else
             sync_wait(sync + k, NMW); sync_signal(sync + W + 2 + k, lane);

@@ -565,12 +565,13 @@ def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monke
 def test_item_staged_photometry_gives_the_same_bits(torch_cuda, monkeypatch):
     """BASELINE config 4's shape (12 x 200 points): the records of all points next to the ring leave room for ONE ring slot, so the
     lean task stages each item's records with its basis rows instead (EmDev::dat_in_tab) -- same arithmetic, same bits, for
-    16- and 32-sample tiles and for the band split of small batches."""
+    16- and 32-sample tiles and for the band split of small batches.  (The dense task, which builds on it, is switched off here.)"""
     torch = torch_cuda
     case = cases.case_c4_shape()
     _, theta = syn.draw_theta(777, 4200, case["names"])
     theta[5, 1] = np.nan
     th = torch.as_tensor(theta, device="cuda:0")
+    monkeypatch.setenv("NMMA_EM_NO_DENSE", "1")
     monkeypatch.setenv("NMMA_EM_NO_ITEM_DAT", "1")
     eng = engine_from_case(case)
     want = eng.loglike(th).cpu().numpy()
@@ -586,4 +587,38 @@ def test_item_staged_photometry_gives_the_same_bits(torch_cuda, monkeypatch):
     for n in (1, 33, 700, 4096):                           # split launch (<= 384 workgroups), 16-sample tiles, ragged tail
         assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), want[:n]), n
     assert want[5] == FLOOR and (want > FLOOR).sum() > 3000
+    eng.close()
+
+
+@pytest.mark.parametrize("sampled_sys", [False, True])
+def test_dense_lean_task_matches_the_row_form(sampled_sys, torch_cuda, monkeypatch):
+    """Config 4's shape on the dense lean task (em_logl<.., 6>: all nodes of (item, 16 samples) reconstructed on the fp64 matrix
+    cores, a datum reads its two node magnitudes) against the lean task that reconstructs two rows per datum: the same numbers to
+    fp64 rounding (the matrix cores sum the ten products in another order), the same floor pattern, and bit-identical to itself
+    across batch sizes, tile sizes and the band split."""
+    torch = torch_cuda
+    case = cases.case_c4_shape()
+    if sampled_sys:                                          # one sampled em_syserr shared by all filters (the lean task's SYS variant)
+        case = cases._base(seed=7234, model="Bu2022Ye", filters=[f"band{i:02d}" for i in range(12)], counts=200, batch=16,
+                           names=case["names"] + ["em_syserr"], upper_limit_filter="band03")
+        case["systematics"] = dict(mode="param", name="em_syserr")
+    _, theta = syn.draw_theta(778, 4200, case["names"])
+    theta[7, 2] = np.nan
+    th = torch.as_tensor(theta, device="cuda:0")
+    monkeypatch.setenv("NMMA_EM_NO_DENSE", "1")
+    eng = engine_from_case(case)
+    want = eng.loglike(th).cpu().numpy()
+    lds_rows = eng.last_launch_geometry()["lds_bytes"]
+    eng.close()
+    monkeypatch.delenv("NMMA_EM_NO_DENSE")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    if not sampled_sys:       # (with the sampled parameter's LDS table the node buffers no longer fit at 32-sample tiles: row form)
+        assert eng.last_launch_geometry()["lds_bytes"] != lds_rows, "dense task not engaged"
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and floor[7] and (~floor).sum() > 3000
+    assert rel_err(got[~floor], want[~floor]).max() < 1e-11
+    for n in (1, 33, 700, 4096):
+        assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), got[:n]), n
     eng.close()

@@ -417,7 +417,7 @@ def test_hubble_constant_conversion_and_device_refusal():
 
 
 def test_kernel_register_budget():
-    """Code-object metadata of the built library: the lean kernels (em_logl<.., 1>, <.., 3>, <.., 4>, <.., 5>) must not spill -- a change
+    """Code-object metadata of the built library: the lean kernels (em_logl<.., 1>, <.., 3>, <.., 4>, <.., 5>, <.., 6>) must not spill -- a change
     that made hipcc spill 2 600 registers in one of them went unnoticed by the parity tests and cost 50 % of its speed --
     and no kernel may use more than a few words of scratch."""
     import re
@@ -446,10 +446,10 @@ def test_kernel_register_budget():
             if m and name:
                 kernels[name][key] = int(m.group(1))
     logl = {k: v for k, v in kernels.items() if "7em_loglI" in k}
-    assert len(logl) >= 24, sorted(kernels)
+    assert len(logl) >= 28, sorted(kernels)
     for k, v in logl.items():
         fastm = int(re.search(r"Li8ELi(\d)EE", k).group(1)) if re.search(r"Li8ELi(\d)EE", k) else 0
-        if fastm in (1, 3, 4):
+        if fastm in (1, 3, 4, 6):
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
         if fastm == 5:      # (the general lean task with its detection-limit call: two registers)
             assert v["vgpr_spill_count"] <= 4, (k, v)
