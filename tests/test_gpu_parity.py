@@ -614,8 +614,7 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, torch_cuda, monkeypat
     eng = engine_from_case(case)
     got = eng.loglike(th).cpu().numpy()
     eng.check()
-    if not sampled_sys:       # (with the sampled parameter's LDS table the node buffers no longer fit at 32-sample tiles: row form)
-        assert eng.last_launch_geometry()["lds_bytes"] != lds_rows, "dense task not engaged"
+    assert eng.last_launch_geometry()["lds_bytes"] != lds_rows, "dense task not engaged"
     floor = want == FLOOR
     assert np.array_equal(got == FLOOR, floor) and floor[7] and (~floor).sum() > 3000
     assert rel_err(got[~floor], want[~floor]).max() < 1e-11
