@@ -243,6 +243,37 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
 }
 
 // ---------------------------------------------------------------------------------------
+// sigma_tot per (datum, sample) of the lean tasks with a sampled systematic: 1 / sigma and ln sigma from s2 = sigma_data^2 + e^2
+// without the library's sqrt, division and log (~120 VALU instructions per datum in the task loop, most of them the
+// double-double arithmetic of a correctly rounded log): v_rsq_f64 + two Newton steps (<= 2 ulp), and the classic
+// argument reduction x = m 2^k, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m - 1)/(m + 1)) with the degree-14 minimax polynomial
+// in s^2 of Sun's fdlibm e_log.c (< 1 ulp; the reference's numpy uses the same family).  Inputs that are not positive and finite
+// give garbage that every caller masks (upper limits, non-finite sigma).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_pos(const double s2) {
+    double y = __builtin_amdgcn_rsq(s2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const double c = (s2 * y) * y; y = y * fma(c, -0.5, 1.5); }
+    return y;
+}
+__device__ __forceinline__ double log_pos(const double x) {
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);                 // x = m 2^k, m in [1/2, 1)
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m; k = lo ? k - 1 : k;
+    const double f = m - 1.0, dk = (double)k, d = 2.0 + f;
+    double rc = __builtin_amdgcn_rcp(d);
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    const double sq = f * rc, z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + (t2 + t1)) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// ---------------------------------------------------------------------------------------
 // MFMA role of em_logl: ONE continuous stream of weight records over all work items.
 // Wave `wave` of NMW owns NSL = NSLICE/NMW hidden slices of every item; its records of
 // consecutive items are chained into a single prefetch ring (the refills issued during the
@@ -1589,11 +1620,16 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const double sd = sl[0];                      // sigma_data
                 const double e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
                 esys_[u] = e_sys;
-                const double sig = sqrt(sd * sd + e_sys * e_sys);
-                const bool fin = (sig - sig == 0.0);
-                isig = fin ? 1.0 / sig : 0.0;                 // infinite data error: upper limit
-                lsig = log(sig);
-                sig_bad = (fin & !(sig > 0)) | (sig != sig);
+                // (1 / sigma_tot and ln sigma_tot without the library's sqrt, division and log: rsqrt_pos / log_pos above.  The exact
+                //  shape of these five lines matters to hipcc: taking the log of sigma^2 instead, or the finite test from sqrt(s2),
+                //  made the lean kernels spill ~770 registers)
+                const double s2 = sd * sd + e_sys * e_sys;    // sigma_tot^2
+                const double rs = rsqrt_pos(s2);
+                const double sig = s2 * rs;
+                const bool fin = (s2 - s2 == 0.0);
+                isig = fin ? rs : 0.0;                        // infinite data error: upper limit
+                lsig = log_pos(sig);
+                sig_bad = (fin & !(s2 > 0)) | (s2 != s2);
             }
             const double x = (tm[1] - est) * isig;
             double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
@@ -1898,11 +1934,16 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const double e0 = ep[i0 * TS], e1 = ep[i1 * TS];
                 const double e_sys = (e1 - e0) * fr + e0;     // (a single parameter: i0 = i1 = 0, fr = 0 -- exactly e0)
                 esys_[u] = e_sys;
-                const double sig = sqrt(sd * sd + e_sys * e_sys);
-                const bool fin = (sig - sig == 0.0);
-                isig = fin ? 1.0 / sig : 0.0;                 // infinite data error: upper limit
-                lsig = log(sig);
-                sig_bad = (fin & !(sig > 0)) | (sig != sig);
+                // (1 / sigma_tot and ln sigma_tot without the library's sqrt, division and log: rsqrt_pos / log_pos above.  The exact
+                //  shape of these five lines matters to hipcc: taking the log of sigma^2 instead, or the finite test from sqrt(s2),
+                //  made the lean kernels spill ~770 registers)
+                const double s2 = sd * sd + e_sys * e_sys;    // sigma_tot^2
+                const double rs = rsqrt_pos(s2);
+                const double sig = s2 * rs;
+                const bool fin = (s2 - s2 == 0.0);
+                isig = fin ? rs : 0.0;                        // infinite data error: upper limit
+                lsig = log_pos(sig);
+                sig_bad = (fin & !(s2 > 0)) | (s2 != s2);
             }
             const double x = (tm[1] - est) * isig;
             double v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
