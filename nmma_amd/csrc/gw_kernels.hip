@@ -281,7 +281,12 @@ __device__ __forceinline__ void gw_sample_chunk(const gw_const_dp sp, const gw_g
 }
 
 template <int NIFO, bool PM>
-__global__ __launch_bounds__(GWL_THREADS, 4) void gw_logl_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+// (4 waves per SIMD = 128 VGPRs: the kernel then spills ~50 registers outside its bin loops and is still the fastest form --
+//  measured at config 5's shape: 29.2 ms against 30.1 ms with 3 waves / 168 VGPRs / 16 spilled and 36.0 ms with 2 / 188 / none)
+#ifndef GWL_MIN_WAVES
+#define GWL_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(GWL_THREADS, GWL_MIN_WAVES) void gw_logl_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
                                                                const long B, double* __restrict__ partial) {
     const GwDev& P = *Pp;
     __shared__ double red[GWL_GROUP][GWL_WAVES][3];
