@@ -176,6 +176,19 @@ def case_c4_shape():
     return c
 
 
+def case_c4_syserr():
+    """BASELINE config 4's shape with ONE sampled systematic shared by all filters (em_syserr, the default of current NMMA
+    priors) and 130 epochs per filter: the dense lean task's sampled-sigma variant on item-staged photometry."""
+    filters = [f"band{i:02d}" for i in range(12)]
+    names = ["luminosity_distance", "inclination_EM", "timeshift", "log10_mej_dyn", "vej_dyn",
+             "Yedyn", "log10_mej_wind", "vej_wind", "em_syserr"]
+    c = _base(seed=7334, model="Bu2022Ye", filters=filters, counts=130, batch=16, names=names,
+              upper_limit_filter="band07")
+    c["systematics"] = dict(mode="param", name="em_syserr")
+    c["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    return c
+
+
 def case_fixed_distance():
     """luminosity_distance FIXED by its prior (DeltaFunction): the reference's constant z(d_L) grid still applies
     the redshift of that distance (model.py:255-267 with get_cosmo_grids(d, d)) -- time stretch and K-correction."""
@@ -313,6 +326,7 @@ CASES = {
     "averaging_nodes_grid": case_averaging_nodes_grid,
     "edges": case_edges,
     "c4_shape": case_c4_shape,
+    "c4_syserr": case_c4_syserr,
     "small_hidden": case_small_hidden,
     "fixed_distance": case_fixed_distance,
     "real_nets": case_real_nets,
