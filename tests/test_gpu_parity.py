@@ -562,12 +562,15 @@ def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monke
     eng.close()
 
 
-def test_item_staged_photometry_gives_the_same_bits(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("grid", ["svd_grid", "dt05", "log_grid"])
+def test_item_staged_photometry_gives_the_same_bits(grid, torch_cuda, monkeypatch):
     """BASELINE config 4's shape (12 x 200 points): the records of all points next to the ring leave room for ONE ring slot, so the
     lean task stages each item's records with its basis rows instead (EmDev::dat_in_tab) -- same arithmetic, same bits, for
     16- and 32-sample tiles and for the band split of small batches.  (The dense task, which builds on it, is switched off here.)"""
     torch = torch_cuda
     case = cases.case_c4_shape()
+    if grid != "svd_grid":       # two-stage grids (the ring slot then carries the stage-1 tables too), equally spaced or not
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150) if grid == "log_grid" else np.arange(0.1, 20.5, 0.5)
     _, theta = syn.draw_theta(777, 4200, case["names"])
     theta[5, 1] = np.nan
     th = torch.as_tensor(theta, device="cuda:0")
@@ -583,7 +586,14 @@ def test_item_staged_photometry_gives_the_same_bits(torch_cuda, monkeypatch):
     eng.check()
     geo = eng.last_launch_geometry()
     assert geo["tile_samples"] == 32 and geo["lds_bytes"] != lds_all, "item-staged photometry not engaged"
-    assert np.array_equal(got, want)
+    if grid == "log_grid":
+        # (with the stage-1 tables in the slot, all records + one slot do not fit at 32-sample tiles: without item staging this
+        #  configuration runs on the EXTENDED task, whose divisions differ from the lean task's reciprocals in the last bits)
+        fin = want != FLOOR
+        assert np.array_equal(got != FLOOR, fin) and rel_err(got[fin], want[fin]).max() < 1e-9
+        want = got
+    else:
+        assert np.array_equal(got, want)
     for n in (1, 33, 700, 4096):                           # split launch (<= 384 workgroups), 16-sample tiles, ragged tail
         assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), want[:n]), n
     assert want[5] == FLOOR and (want > FLOOR).sum() > 3000
