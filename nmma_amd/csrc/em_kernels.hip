@@ -1424,9 +1424,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         };
         stage_p(0);
-        // dense: the A operands of this task's node tiles -- rows of [VA o span | mins | 0] pre-swizzled per filter at create
+        // dense: the A operands of this task's node tiles -- rows of [VA o span | mins | 0] on the sample grid (the stage-1 lerp
+        // between SVD nodes folded in), pre-swizzled per filter at create
         // (EmDev::dva, one coalesced 512-byte load per MFMA) -- requested before the waits for the surrogate and the node buffer
-        const int dn_tt = (NT + 15) >> 4;
+        const int dn_tt = (NS + 15) >> 4;          // node tiles of the SAMPLE grid (<= 16: four per task, checked at create)
         double dav[DENSE ? 4 : 1][3];
         if constexpr (DENSE) {
             gcf64p dva = as_global(P.dva) + (size_t)it.m * dn_tt * 3 * 64 + lane;
@@ -1465,7 +1466,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const int unit = R * k + h;
             int* const unit_prod = sync + 3 * W + 4 + unit;
             unit_done = sync + 3 * W + 4 + R * W + unit;
-            const lds_dp nb = (lds_dp)(smem + L.nodes) + (unit % DENSE_NBUF) * (((NT + 15) & ~15) * DENSE_STRIDE);
+            const lds_dp nb = (lds_dp)(smem + L.nodes) + (unit % DENSE_NBUF) * (((NS + 15) & ~15) * DENSE_STRIDE);
             nodes_l = (lds_cdp)nb;
             // B operands: coefficient 4 step + lane / 16 of sample 16 h + lane % 16 (slice sums in the fixed order, + b2, as fp64);
             // "coefficient" NC is the constant 1 that multiplies the mins column of the A table
@@ -2072,7 +2073,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
-                    } else if constexpr (FASTM == 6) {   // dense: sample_times = the SVD grid, more than 16 points in every filter (host)
+                    } else if constexpr (FASTM == 6) {   // dense: equally spaced sample_times, more than 16 points in every filter (host)
                         if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t);
                     } else {
                         if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);

@@ -189,6 +189,17 @@ def case_c4_syserr():
     return c
 
 
+def case_c4_dt05():
+    """12 filters x 120 epochs on the documented CLI grid (--tmin .1 --tmax 20 --dt .5: 41 sample nodes, each a stage-1 lerp
+    between two SVD nodes): the dense lean task with the lerp folded into its matrix-core operands."""
+    filters = [f"band{i:02d}" for i in range(12)]
+    names = ["luminosity_distance", "inclination_EM", "timeshift", "log10_mej_dyn", "vej_dyn",
+             "Yedyn", "log10_mej_wind", "vej_wind"]
+    c = _base(seed=7434, model="Bu2022Ye", filters=filters, counts=120, batch=16, names=names,
+              upper_limit_filter="band05", sample_times=np.arange(0.1, 20.5, 0.5))
+    return c
+
+
 def case_fixed_distance():
     """luminosity_distance FIXED by its prior (DeltaFunction): the reference's constant z(d_L) grid still applies
     the redshift of that distance (model.py:255-267 with get_cosmo_grids(d, d)) -- time stretch and K-correction."""
@@ -327,6 +338,7 @@ CASES = {
     "edges": case_edges,
     "c4_shape": case_c4_shape,
     "c4_syserr": case_c4_syserr,
+    "c4_dt05": case_c4_dt05,
     "small_hidden": case_small_hidden,
     "fixed_distance": case_fixed_distance,
     "real_nets": case_real_nets,

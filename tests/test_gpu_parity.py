@@ -600,8 +600,9 @@ def test_item_staged_photometry_gives_the_same_bits(grid, torch_cuda, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("grid", ["svd_grid", "dt05"])
 @pytest.mark.parametrize("sampled_sys", [False, True])
-def test_dense_lean_task_matches_the_row_form(sampled_sys, torch_cuda, monkeypatch):
+def test_dense_lean_task_matches_the_row_form(sampled_sys, grid, torch_cuda, monkeypatch):
     """Config 4's shape on the dense lean task (em_logl<.., 6>: all nodes of (item, 16 samples) reconstructed on the fp64 matrix
     cores, a datum reads its two node magnitudes) against the lean task that reconstructs two rows per datum: the same numbers to
     fp64 rounding (the matrix cores sum the ten products in another order), the same floor pattern, and bit-identical to itself
@@ -612,6 +613,8 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, torch_cuda, monkeypat
         case = cases._base(seed=7234, model="Bu2022Ye", filters=[f"band{i:02d}" for i in range(12)], counts=200, batch=16,
                            names=case["names"] + ["em_syserr"], upper_limit_filter="band03")
         case["systematics"] = dict(mode="param", name="em_syserr")
+    if grid == "dt05":        # the documented CLI grid: 41 sample nodes, each a stage-1 lerp between two SVD nodes (folded into the A operands)
+        case["sample_times"] = np.arange(0.1, 20.5, 0.5)
     _, theta = syn.draw_theta(778, 4200, case["names"])
     theta[7, 2] = np.nan
     th = torch.as_tensor(theta, device="cuda:0")
@@ -627,7 +630,7 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, torch_cuda, monkeypat
     assert eng.last_launch_geometry()["lds_bytes"] != lds_rows, "dense task not engaged"
     floor = want == FLOOR
     assert np.array_equal(got == FLOOR, floor) and floor[7] and (~floor).sum() > 3000
-    assert rel_err(got[~floor], want[~floor]).max() < 1e-11
+    assert rel_err(got[~floor], want[~floor]).max() < 1e-10
     for n in (1, 33, 700, 4096):
         assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), got[:n]), n
     eng.close()
