@@ -2073,8 +2073,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     } else if constexpr (FASTM == 3) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
-                    } else if constexpr (FASTM == 6) {   // dense: equally spaced sample_times, more than 16 points in every filter (host)
-                        if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t);
+                    } else if constexpr (FASTM == 6) {   // dense: more than 16 points in every filter (host); any sample grid -- the
+                        // stage-1 lerp lives in the A operands, an unequally spaced grid only changes how a datum finds its bracket
+                        if (P.st_uniform) { if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t); }
+                        else { if (sysp) lean_task(F{}, F{}, T{}, T{}, k, t); else lean_task(F{}, F{}, F{}, T{}, k, t); }
                     } else {
                         if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     }

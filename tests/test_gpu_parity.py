@@ -600,7 +600,7 @@ def test_item_staged_photometry_gives_the_same_bits(grid, torch_cuda, monkeypatc
     eng.close()
 
 
-@pytest.mark.parametrize("grid", ["svd_grid", "dt05"])
+@pytest.mark.parametrize("grid", ["svd_grid", "dt05", "log_grid"])
 @pytest.mark.parametrize("sampled_sys", [False, True])
 def test_dense_lean_task_matches_the_row_form(sampled_sys, grid, torch_cuda, monkeypatch):
     """Config 4's shape on the dense lean task (em_logl<.., 6>: all nodes of (item, 16 samples) reconstructed on the fp64 matrix
@@ -615,6 +615,8 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, grid, torch_cuda, mon
         case["systematics"] = dict(mode="param", name="em_syserr")
     if grid == "dt05":        # the documented CLI grid: 41 sample nodes, each a stage-1 lerp between two SVD nodes (folded into the A operands)
         case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    if grid == "log_grid":    # the CLI's default: 150 log-spaced nodes (bracket by bisection)
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150)
     _, theta = syn.draw_theta(778, 4200, case["names"])
     theta[7, 2] = np.nan
     th = torch.as_tensor(theta, device="cuda:0")

@@ -12,7 +12,7 @@ if shape == "c4":
     case = cases._base(seed=7234, model="Bu2022Ye", filters=filters, counts=counts, batch=16, names=names, upper_limit_filter="band03")
 else:
     case = cases._base(seed=5234, counts=counts, batch=16)
-case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+case["sample_times"] = np.geomspace(0.2, 20.0, 150) if os.environ.get("PROBE_LOG_GRID") else np.arange(0.1, 20.5, 0.5)
 for mode in ("1", ""):
     if mode: os.environ["NMMA_EM_NO_DENSE"] = mode
     else: os.environ.pop("NMMA_EM_NO_DENSE", None)
