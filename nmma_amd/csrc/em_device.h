@@ -19,6 +19,8 @@ enum EmMode : int32_t { MODE_LOGL = 0, MODE_COEFF = 1, MODE_LC = 2, MODE_LC_ABS 
 
 // One work item of em_logl: (observed filter o, its ks-th source model filter m), with
 // everything the downstream phase needs about it (copied to LDS once per workgroup).
+constexpr int BG_CELLS = 256;
+
 struct ItemDesc {
     int32_t o, ks, m, nsrc;
     int32_t G, d0, nf, kind;
@@ -120,6 +122,12 @@ struct EmDev {
                               // [VA o span | mins | 0] (the constant-1 "coefficient" NC adds mins)
     int32_t dense;            // dense lean task (em_logl<.., 6>): every filter has so many points that reconstructing ALL nodes of
                               // (item, 16 samples) on the fp64 matrix cores beats two basis rows per datum; implies dat_in_tab
+    // Unequally spaced sample_times: a coarse lookup over BG_CELLS equal cells of [st[0], st[NS-1]] narrows a datum's bracket
+    // before the bisection -- bguess[q] = last node at or before the left edge of cell q (bguess[BG_CELLS] = NS - 1) --
+    // so that the lean tasks bisect bg_nbis times (3 for the CLI's 150 log-spaced nodes) instead of ceil(log2 NS) = 8.
+    const int32_t* bguess;
+    double bg_inv_h;
+    int32_t bg_nbis, pad_bg;
     int32_t lean_gen, pad_gen;        // general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
 };
 

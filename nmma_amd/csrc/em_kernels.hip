@@ -553,12 +553,14 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
                                          int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0,
                                          int dat_point_bytes = 32, int dense_rows = 0) {
     const int TS = 16 * R;
+    const bool bracket_lookup = NS < 0;        // (NS < 0: unequally spaced sample_times -- the lean tasks' lookup table sits behind the grid)
+    NS = NS < 0 ? -NS : NS;
     LdsW L{};
     int off = 0;
     L.nbuf = nbuf;
     L.praw = off; off = align16(off + TS * 8 * 8);
     L.scal = off; off = align16(off + TS * 8 * 8);
-    L.stl = off;  off = align16(off + 2 * NS * 8);                   // sample times | 1 / (t[j+1] - t[j])
+    L.stl = off;  off = align16(off + 2 * NS * 8 + (bracket_lookup ? (BG_CELLS + 1) * 4 : 0));   // sample times | 1 / (t[j+1] - t[j]) | bracket lookup
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
@@ -798,6 +800,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         //  band's own workgroup of the split launch can lie beyond its item count -- the layout always holds P.O slots)
         for (int j = cvt; j < (W > P.O ? W : P.O) * TS; j += cnv) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
         for (int j = cvt; j < NS; j += cnv) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? 1.0 / (P.st[j + 1] - P.st[j]) : 0.0; }
+        if (!P.st_uniform && P.bguess != nullptr) {
+            int* bgl = reinterpret_cast<int*>(stl + 2 * NS);
+            gci32p bgs = as_global(P.bguess);
+            for (int j = cvt; j <= BG_CELLS; j += cnv) bgl[j] = bgs[j];
+        }
         if constexpr (FAST) {
             int* tmap = reinterpret_cast<int*>(smem + L.tmap);
             gci32p src = as_global(P.task_map[R - 1]);
@@ -1360,7 +1367,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                                       : (lds_c2p)(smem + L.dat);
         const int dbase = item_dat ? 0 : d0;
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
-        const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
+        const int nbis = NONUNI ? __builtin_amdgcn_readfirstlane(P.bg_nbis) : 0;
+        const double bg_inv_h = NONUNI ? P.bg_inv_h : 0.0;
         const bool range_ok = jhi > jlo;
         constexpr int NSL = 2;
         int s_[NSL];
@@ -1402,9 +1410,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             int lo;
             if constexpr (NONUNI) {
                 // largest node index in [jlo, jhi - 1] whose observer-frame time is <= t (np.interp's bracket)
-                lo = jlo;
-                int hi = jhi;
-                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count: ceil(log2(NS))
+                // (narrowed first by the lookup over equal cells of the source-frame grid, one node of slack on either side for the
+                //  rounding of the source-frame time: bg_nbis steps instead of ceil(log2 NS))
+                typedef const __attribute__((address_space(3))) int* lds_cip_bg;
+                const lds_cip_bg bgl = (lds_cip_bg)(stl_l + 2 * NS);
+                int cq = (int)(((t - tsh) * izp1 - st0) * bg_inv_h);
+                cq = cq < 0 ? 0 : (cq > BG_CELLS - 1 ? BG_CELLS - 1 : cq);
+                lo = bgl[cq] - 1;
+                int hi = bgl[cq + 1] + 2;
+                lo = lo < jlo ? jlo : lo;
+                hi = hi > jhi ? jhi : hi;
+                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count
                     const int mid = (lo + hi) >> 1;
                     const bool le = (stl_l[mid] * zp1 + tsh) <= t;
                     lo = le ? mid : lo;
@@ -1752,7 +1768,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
         const lds_c2p dat4 = (lds_c2p)(smem + L.dat);
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
-        const int nbis = NONUNI ? 32 - __builtin_clz((unsigned)(NS > 1 ? NS - 1 : 1)) : 0;
+        const int nbis = NONUNI ? __builtin_amdgcn_readfirstlane(P.bg_nbis) : 0;
+        const double bg_inv_h = NONUNI ? P.bg_inv_h : 0.0;
         const bool range_ok = jhi > jlo;
         constexpr int NSL = 2;
         int s_[NSL];
@@ -1781,9 +1798,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             int lo;
             if constexpr (NONUNI) {
                 // largest node index in [jlo, jhi - 1] whose observer-frame time is <= t (np.interp's bracket)
-                lo = jlo;
-                int hi = jhi;
-                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count: ceil(log2(NS))
+                // (narrowed first by the lookup over equal cells of the source-frame grid, one node of slack on either side for the
+                //  rounding of the source-frame time: bg_nbis steps instead of ceil(log2 NS))
+                typedef const __attribute__((address_space(3))) int* lds_cip_bg;
+                const lds_cip_bg bgl = (lds_cip_bg)(stl_l + 2 * NS);
+                int cq = (int)(((t - tsh) * izp1 - st0) * bg_inv_h);
+                cq = cq < 0 ? 0 : (cq > BG_CELLS - 1 ? BG_CELLS - 1 : cq);
+                lo = bgl[cq] - 1;
+                int hi = bgl[cq + 1] + 2;
+                lo = lo < jlo ? jlo : lo;
+                hi = hi > jhi ? jhi : hi;
+                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count
                     const int mid = (lo + hi) >> 1;
                     const bool le = (stl_l[mid] * zp1 + tsh) <= t;
                     lo = le ? mid : lo;
