@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 3
+#define NMMA_ABI_VERSION 4
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -278,6 +278,16 @@ typedef struct nmma_gw_config {
     int32_t mass_mode;            /* enum nmma_gw_mass_mode */
     int32_t n_dim;                /* columns of theta */
     nmma_slot mass_a, mass_b, chi_1, chi_2, lambda_1, lambda_2, luminosity_distance, theta_jn, phase, ra, dec, psi, geocent_time;
+    /* Distance marginalisation (bilby GravitationalWaveTransient(distance_marginalization=True), gw_likelihood.py:174-178):
+     * n_distance > 0 replaces the likelihood ratio by log sum_j w_j exp(x(d_j)) over the grid, with
+     * x(d) = Re<d|h>(d) - <h|h>(d)/2 (ln I0(|<d|h>(d)|) - <h|h>(d)/2 with phase marginalisation), <d|h> ~ 1/d, <h|h> ~ 1/d^2 rescaled
+     * from the row's own luminosity_distance (fix it at any value inside the prior, as bilby does with its reference distance), and
+     * distance_log_weight[j] = ln(prior(d_j) * delta_d) (-inf outside the prior's support).  bilby tabulates the same sum over
+     * (<d|h>, <h|h>) and interpolates; the device evaluates it per row. */
+    int32_t n_distance;
+    int32_t pad_distance;
+    const double* distance_grid;        /* [n_distance] Mpc */
+    const double* distance_log_weight;  /* [n_distance] */
 } nmma_gw_config;
 
 typedef struct nmma_gw_handle nmma_gw_handle;

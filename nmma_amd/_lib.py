@@ -20,7 +20,7 @@ SOURCES = ("em_kernels.hip", "gw_kernels.hip")
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
 UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -94,6 +94,7 @@ class GwConfig(C.Structure):
         ("mass_a", Slot), ("mass_b", Slot), ("chi_1", Slot), ("chi_2", Slot), ("lambda_1", Slot), ("lambda_2", Slot),
         ("luminosity_distance", Slot), ("theta_jn", Slot), ("phase", Slot), ("ra", Slot), ("dec", Slot), ("psi", Slot),
         ("geocent_time", Slot),
+        ("n_distance", C.c_int32), ("pad_distance", C.c_int32), ("distance_grid", _pd), ("distance_log_weight", _pd),
     ]
 
 

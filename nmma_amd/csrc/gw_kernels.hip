@@ -131,6 +131,9 @@ constexpr int GWL_WAVES = GWL_THREADS / 64;
 
 struct GwDev {
     int32_t n_ifo, tidal, mass_mode, phase_marg;
+    int32_t n_dist, pad_dist;      // distance marginalisation: grid points (0: off)
+    const double* dist_grid;       // [n_dist] Mpc
+    const double* dist_logw;       // [n_dist] ln(prior(d_j) delta_d)
     int64_t n_bins;                // bins k0 .. k0 + n_bins - 1 of the frequency array
     int64_t k0, n_freq;
     int32_t n_chunks, n_dim;       // chunks of GWL_CHUNK bins
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(64) void gw_source_kernel(const GwDev* __restrict__
     gw::GwSource S;
     for (int i = 0; i < gw::kMaxIfo; ++i) { S.k_re[i] = 0.0; S.k_im[i] = 0.0; S.k_sq[i] = 0.0; S.dt[i] = 0.0; S.rs_re[i] = 1.0; S.rs_im[i] = 0.0; }
     gw::setup_source(q, P.f_ref, P.tidal != 0, S);
+    S.distance = q.luminosity_distance;
     if (S.valid != 0.0)
         for (int i = 0; i < P.n_ifo; ++i) gw::project_source(q, P.det[i], i, P.start_time, P.gmst_ref_time, P.gmst_ref, P.gmst_rate, stride_hz, S);
     src[b] = S;
@@ -360,7 +364,24 @@ __global__ __launch_bounds__(256) void gw_finish_kernel(const GwDev* __restrict_
         return;
     }
     double r;
-    if (P.phase_marg) r = gw::ln_bessel_i0(sqrt(re * re + im * im)) - hh / 2.0;      // bilby: ln_i0(abs(d_inner_h)) - optimal_snr_squared / 2
+    if (P.n_dist > 0) {
+        // distance marginalisation: log sum_j w_j exp(x(d_j)); <d|h> ~ 1/d and <h|h> ~ 1/d^2 rescaled from the row's own distance
+        // (bilby/gw/likelihood/base.py: distance_marginalized_likelihood + _create_lookup_table, evaluated here instead of tabulated)
+        const double dh = P.phase_marg ? sqrt(re * re + im * im) : re;
+        const double ds = src[b].distance;
+        double mx = -dinf();
+        for (int pass = 0; pass < 2; ++pass) {
+            double acc = 0.0;
+            for (int j = 0; j < P.n_dist; ++j) {
+                const double lw = P.dist_logw[j];
+                if (!(lw > -dinf())) continue;
+                const double sc = ds / P.dist_grid[j];
+                const double x = (P.phase_marg ? gw::ln_bessel_i0(dh * sc) : dh * sc) - hh * sc * sc / 2.0 + lw;
+                if (pass == 0) mx = x > mx ? x : mx; else acc += exp(x - mx);
+            }
+            if (pass == 1) r = mx + log(acc);
+        }
+    } else if (P.phase_marg) r = gw::ln_bessel_i0(sqrt(re * re + im * im)) - hh / 2.0;      // bilby: ln_i0(abs(d_inner_h)) - optimal_snr_squared / 2
     else r = re - hh / 2.0;
     out[b] = (valid && isfinite(r)) ? r : NMMA_LOGL_FLOOR;                            // core/base.py:82, :181
 }
@@ -583,7 +604,17 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
     hipError_t e = up(basis.data(), basis.size() * 8, &p);
     if (e == hipSuccess) { P.basis = reinterpret_cast<const double4*>(p); e = up(basis5.data(), basis5.size() * 8, &p); }
     if (e == hipSuccess) { P.basis5 = reinterpret_cast<const double*>(p); e = up(dat.data(), dat.size() * 8, &p); }
-    if (e == hipSuccess) { P.dat = reinterpret_cast<const double4*>(p); e = up(&P, sizeof(P), &p); }
+    if (e == hipSuccess) P.dat = reinterpret_cast<const double4*>(p);
+    P.n_dist = 0; P.dist_grid = nullptr; P.dist_logw = nullptr;
+    if (e == hipSuccess && c->n_distance > 0) {        // distance marginalisation: the grid and ln(prior x step) per node
+        if (!c->distance_grid || !c->distance_log_weight) { nmma_gw_destroy(h); return fail("nmma_gw_create: null distance grid"); }
+        for (int j = 0; j < c->n_distance; ++j)
+            if (!(c->distance_grid[j] > 0)) { nmma_gw_destroy(h); return fail("nmma_gw_create: distance grid must be positive"); }
+        e = up(c->distance_grid, (size_t)c->n_distance * 8, &p);
+        if (e == hipSuccess) { P.dist_grid = reinterpret_cast<const double*>(p); e = up(c->distance_log_weight, (size_t)c->n_distance * 8, &p); }
+        if (e == hipSuccess) { P.dist_logw = reinterpret_cast<const double*>(p); P.n_dist = c->n_distance; }
+    }
+    if (e == hipSuccess) e = up(&P, sizeof(P), &p);
     if (e != hipSuccess) { nmma_gw_destroy(h); return fail(std::string("nmma_gw_create: ") + hipGetErrorString(e)); }
     h->dev_d = reinterpret_cast<GwDev*>(p);
     *out = h;

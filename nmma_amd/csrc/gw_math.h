@@ -157,6 +157,7 @@ struct GwParams {
 // phases in units of pi.  Plain doubles only: the kernels read it through the scalar cache.
 struct GwSource {
     double valid;                 // 0: a non-finite or unphysical input -> the sample gets the floor
+    double distance;              // Mpc: the luminosity distance the amplitude was scaled with (distance marginalisation rescales from it)
     // ---- amplitude: A(f) = amp_scale * f^(-7/6) * (bracket(f) + tidal bracket) * taper
     double amp_scale;
     double fa1, fa3;              // Hz: inspiral | intermediate | merger-ringdown boundaries of the amplitude

@@ -139,7 +139,7 @@ class GWEngine:
     ``chi_1`` / ``chi_2``; inclination: ``theta_jn`` or ``cos_theta_jn``.  No CPU fallback."""
 
     def __init__(self, interferometers, parameter_names, fixed=None, waveform_arguments=None, phase_marginalization=False,
-                 gmst_reference_time=None, device=0):
+                 gmst_reference_time=None, device=0, distance_marginalization=None):
         import torch  # noqa: F401  (device buffers / stream)
         self._handle = None
         self._lib = L.load_library()
@@ -206,13 +206,26 @@ class GWEngine:
         cfg.waveform_maximum_frequency = float(wa.get("maximum_frequency", np.inf))
         cfg.phase_marginalization = 1 if phase_marginalization else 0
         cfg.n_dim = len(names)
-        keep = (data, psd, mask, tensor, vertex)        # alive until create returns (the library copies)
+        dist = None
+        if distance_marginalization is not None:
+            # (grid[n] in Mpc, ln(prior(d_j) * delta_d)[n]) -- see distance_marginalization_grid
+            dgrid = np.ascontiguousarray(distance_marginalization[0], dtype=np.float64)
+            dlogw = np.ascontiguousarray(distance_marginalization[1], dtype=np.float64)
+            if dgrid.ndim != 1 or dgrid.shape != dlogw.shape or dgrid.size < 2:
+                raise L.NMMAHipError("distance_marginalization needs (grid[n], log_weight[n]) with n >= 2")
+            if "luminosity_distance" in names:
+                raise L.NMMAHipError("luminosity_distance is marginalised: it must not be a sampled column")
+            cfg.n_distance = dgrid.size
+            cfg.distance_grid, cfg.distance_log_weight = dgrid.ctypes.data_as(L._pd), dlogw.ctypes.data_as(L._pd)
+            dist = (dgrid, dlogw)
+        keep = (data, psd, mask, tensor, vertex, dist)        # alive until create returns (the library copies)
         h = C.c_void_p()
         L.check(self._lib.nmma_gw_create(C.byref(cfg), C.byref(h)), "nmma_gw_create")
         del keep
         self._handle = h
         self.n_bins = int(self._lib.nmma_gw_n_bins(h))
         self.phase_marginalization = bool(phase_marginalization)
+        self.distance_marginalization = distance_marginalization is not None
         self._noise = float(self._lib.nmma_gw_noise_log_likelihood(h))
 
     # ---- lifetime
@@ -300,15 +313,37 @@ def _noise_log_likelihood_host(interferometers):
     return total
 
 
+def distance_marginalization_grid(prior, n=10000):
+    """What bilby's ``GravitationalWaveTransient._setup_distance_marginalization`` tabulates from the luminosity-distance
+    prior: ``linspace(prior.minimum, prior.maximum, n)`` and ``prior.prob`` on it times the step (bilby/gw/likelihood/base.py) --
+    returned as (grid, ln(prob x step)) for ``GWEngine(distance_marginalization=...)``, plus bilby's reference distance
+    ``prior.rescale(0.5)`` at which the waveform is evaluated (any distance gives the same marginal: the device rescales)."""
+    grid = np.linspace(float(prior.minimum), float(prior.maximum), int(n))
+    prob = np.asarray(prior.prob(grid), dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        logw = np.log(prob * (grid[1] - grid[0]))
+    ref = float(prior.rescale(0.5)) if hasattr(prior, "rescale") else float(0.5 * (grid[0] + grid[-1]))
+    return grid, logw, ref
+
+
 class GravitationalWaveTransient:
     """What ``GravitationalWaveTransientLikelihood.sub_model`` exposes of ``bilby.gw.likelihood.GravitationalWaveTransient``:
     the objects it was built from, the marginalisation flags, ``noise_log_likelihood`` and the evaluation -- per sample
     (``log_likelihood(parameters)``, a batch of one) and batched (``log_likelihood_ratio_batch``).  The GPU handle is created
     lazily per process and dropped on pickling, like the EM likelihood's."""
 
-    def __init__(self, interferometers, waveform_generator, priors=None, phase_marginalization=False, device=0):
+    def __init__(self, interferometers, waveform_generator, priors=None, phase_marginalization=False, device=0,
+                 distance_marginalization=False):
         self.interferometers, self.waveform_generator, self.priors = list(interferometers), waveform_generator, priors
-        self.phase_marginalization, self.distance_marginalization, self.time_marginalization = bool(phase_marginalization), False, False
+        self.phase_marginalization, self.time_marginalization = bool(phase_marginalization), False
+        self.distance_marginalization = bool(distance_marginalization)
+        self._distance = None
+        if self.distance_marginalization:
+            try:
+                prior = priors["luminosity_distance"]
+                self._distance = distance_marginalization_grid(prior)
+            except (KeyError, TypeError, AttributeError) as exc:
+                raise L.NMMAHipError("distance marginalisation needs priors['luminosity_distance'] with minimum, maximum and prob()") from exc
         self.device = int(device)
         self._noise = _noise_log_likelihood_host(self.interferometers)
         self._engine, self._names = None, None
@@ -327,18 +362,23 @@ class GravitationalWaveTransient:
                 fixed[key] = val
         if self.phase_marginalization:
             fixed["phase"] = 0.0        # bilby: the phase prior becomes a delta function at 0
+        if self.distance_marginalization:
+            fixed["luminosity_distance"] = self._distance[2]      # bilby: ... and the distance prior one at the reference distance
         return fixed
 
     def engine(self, names):
         names = [n for n in names]
         if self.phase_marginalization and "phase" in names:
             raise L.NMMAHipError("phase is marginalised: it must not be a sampled column")
+        if self.distance_marginalization and "luminosity_distance" in names:
+            raise L.NMMAHipError("luminosity_distance is marginalised: it must not be a sampled column")
         if self._engine is None or self._names != names:
             if self._engine is not None:
                 self._engine.close()
             self._engine = GWEngine(self.interferometers, names, fixed=self.fixed_parameters(names),
                                     waveform_arguments=self.waveform_generator.waveform_arguments,
-                                    phase_marginalization=self.phase_marginalization, device=self.device)
+                                    phase_marginalization=self.phase_marginalization, device=self.device,
+                                    distance_marginalization=self._distance[:2] if self.distance_marginalization else None)
             self._names = names
         return self._engine
 
@@ -367,10 +407,10 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
     conversion chosen from the source model's name, :207-210), with the arithmetic bilby + lalsimulation do per sample
     moved to the GPU for a whole batch (``log_likelihood_batch``).
 
-    Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` on or off,
-    sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
+    Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` and
+    ``distance_marginalization`` on or off (the distance sum evaluated per row instead of bilby's lookup table), sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
     Refused at construction (never approximated): the ROQ / relative-binning / multibanded likelihood classes (they need
-    bilby's basis files and fiducial waveforms), time and distance marginalisation (:174-178), other reference frames."""
+    bilby's basis files and fiducial waveforms), time marginalisation (:174-178), other reference frames."""
 
     def __init__(self, priors, interferometers, waveform_generator, gw_likelihood_type="GravitationalWaveTransient",
                  time_marginalization=False, distance_marginalization=False, phase_marginalization=False,
@@ -384,12 +424,15 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
             raise ValueError("Unknown GW Likelihood class {}")                            # :205 (sic)
         if gw_likelihood_type != "GravitationalWaveTransient":
             raise L.NMMAHipError(f"{gw_likelihood_type} is not built on the device path (it needs bilby's basis / fiducial data)")
-        if time_marginalization or distance_marginalization:
-            raise L.NMMAHipError("time and distance marginalisation are not built on the device path")
+        if time_marginalization:
+            raise L.NMMAHipError("time marginalisation is not built on the device path")
+        if distance_marginalization and distance_marginalization_lookup_table is not None:
+            pass        # (bilby caches its (d_inner_h, h_inner_h) table there; the device evaluates the sum per row and needs none)
         if reference_frame != "sky" or time_reference not in ("geocent", "geocenter"):
             raise L.NMMAHipError("only reference_frame='sky' and time_reference='geocenter' are built on the device path")
         sub_model = GravitationalWaveTransient(interferometers, waveform_generator, priors=priors,
-                                               phase_marginalization=phase_marginalization, device=device)
+                                               phase_marginalization=phase_marginalization, device=device,
+                                               distance_marginalization=distance_marginalization)
         super().__init__(sub_model, priors)
         from ..core import conversion
         name = getattr(waveform_generator.frequency_domain_source_model, "__name__", "")

@@ -590,8 +590,12 @@ def ln_i0(x):
     return math.log(ive(0, x)) + abs(x)
 
 
-def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalization=False, tidal=True, f_max_waveform=np.inf):
-    """``ifos``: list of dicts with name, frequency_array, data, psd, mask, start_time, duration."""
+def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalization=False, tidal=True, f_max_waveform=np.inf,
+                         distance_marginalization=None):
+    """``ifos``: list of dicts with name, frequency_array, data, psd, mask, start_time, duration.
+    ``distance_marginalization`` = (grid, ln(prior x step)): bilby's distance-marginalised likelihood
+    (bilby/gw/likelihood/base.py: ``distance_marginalized_likelihood`` with the sum of ``_create_lookup_table`` evaluated
+    directly instead of tabulated over (d_inner_h, h_inner_h) and interpolated)."""
     d_inner_h, opt = 0.0 + 0.0j, 0.0
     for ifo in ifos:
         m = ifo["mask"]
@@ -599,6 +603,16 @@ def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalizat
         h = detector_strain(params, ifo["name"], fa, ifo["start_time"], f_ref, f_min_waveform, f_max_waveform, tidal)
         d_inner_h += 4.0 / ifo["duration"] * np.sum(np.conj(ifo["data"][m]) * h[m] / ifo["psd"][m])
         opt += (4.0 / ifo["duration"] * np.sum(np.conj(h[m]) * h[m] / ifo["psd"][m])).real
+    if distance_marginalization is not None:
+        from scipy.special import logsumexp
+        grid, logw = (np.asarray(a, dtype=np.float64) for a in distance_marginalization)
+        keep = np.isfinite(logw)
+        scale = float(params["luminosity_distance"]) / grid[keep]      # <d|h> ~ 1/d, <h|h> ~ 1/d^2
+        if phase_marginalization:
+            x = np.array([ln_i0(abs(d_inner_h) * s) for s in scale]) - opt * scale ** 2 / 2.0
+        else:
+            x = d_inner_h.real * scale - opt * scale ** 2 / 2.0
+        return float(logsumexp(x + logw[keep]))
     if phase_marginalization:
         return ln_i0(abs(d_inner_h)) - opt / 2.0
     return d_inner_h.real - opt / 2.0

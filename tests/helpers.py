@@ -26,6 +26,25 @@ class SimplePrior:
             self.peak = peak
 
 
+class PowerLawPrior(SimplePrior):
+    """bilby.core.prior.PowerLaw(alpha, minimum, maximum): p(x) ~ x^alpha (alpha = 2: uniform in volume, bilby's usual
+    luminosity-distance prior) -- ``prob`` and ``rescale`` as bilby defines them (bilby/core/prior/analytical.py)."""
+
+    def __init__(self, alpha, minimum, maximum):
+        super().__init__(minimum, maximum)
+        self.alpha = alpha
+
+    def prob(self, val):
+        val = np.asarray(val, dtype=np.float64)
+        a1 = 1 + self.alpha
+        inside = (val >= self.minimum) & (val <= self.maximum)
+        return np.where(inside, val ** self.alpha * a1 / (self.maximum ** a1 - self.minimum ** a1), 0.0)
+
+    def rescale(self, val):
+        a1 = 1 + self.alpha
+        return (self.minimum ** a1 + val * (self.maximum ** a1 - self.minimum ** a1)) ** (1.0 / a1)
+
+
 def plugin_from_case(case, device=0, verbose=False):
     """The reference-shaped objects (model, systematics handler, likelihood) for a case."""
     from nmma_amd.em.em_likelihood import EMTransientLikelihood

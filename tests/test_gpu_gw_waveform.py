@@ -62,13 +62,21 @@ def test_projected_strain_matches_oracle(approximant, torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", ["bns", "phase_marginalised", "component_masses_cos", "two_ifos", "one_ifo_bbh"])
+@pytest.mark.parametrize("variant", ["bns", "phase_marginalised", "distance_marginalised", "distance_phase_marginalised",
+                                     "component_masses_cos", "two_ifos", "one_ifo_bbh"])
 def test_loglike_ratio_matches_oracle(variant, torch_cuda):
     from nmma_amd.gw import GWEngine
-    kw, names, fixed, pm = {}, list(syn.GW_NAMES), {}, False
-    if variant == "phase_marginalised":
+    from nmma_amd.gw.gw_likelihood import distance_marginalization_grid
+    from tests.helpers import PowerLawPrior
+    kw, names, fixed, pm, dm = {}, list(syn.GW_NAMES), {}, False, None
+    if variant in ("phase_marginalised", "distance_phase_marginalised"):
         names.remove("phase")
         pm = True
+    if variant in ("distance_marginalised", "distance_phase_marginalised"):
+        # bilby's usual prior, uniform in volume; the waveform is evaluated at bilby's reference distance prior.rescale(0.5)
+        grid, logw, ref = distance_marginalization_grid(PowerLawPrior(2.0, 10.0, 250.0), n=2000)
+        names.remove("luminosity_distance")
+        fixed, dm = dict(luminosity_distance=ref), (grid, logw)
     if variant == "two_ifos":
         kw = dict(ifo_names=("H1", "L1"), duration=8.0, sampling_frequency=2048.0)
     if variant == "one_ifo_bbh":
@@ -87,9 +95,10 @@ def test_loglike_ratio_matches_oracle(variant, torch_cuda):
         fixed = dict(phase=0.4, psi=1.1)
     names, theta = syn.draw_gw_theta(21, 40, centre=centre, names=names, width=0.5 if variant != "one_ifo_bbh" else 0.2)
     theta[0] = [centre[n] for n in names]                       # the injection itself: the likelihood peak
-    eng = GWEngine(case["ifos"], names, fixed=fixed, waveform_arguments=case["waveform_arguments"], phase_marginalization=pm)
+    eng = GWEngine(case["ifos"], names, fixed=fixed, waveform_arguments=case["waveform_arguments"], phase_marginalization=pm,
+                   distance_marginalization=dm)
     got = eng.loglike_ratio(theta).cpu().numpy()
-    want = oracle_loglike_ratio(case, names, theta, fixed, phase_marginalization=pm)
+    want = oracle_loglike_ratio(case, names, theta, fixed, phase_marginalization=pm, distance_marginalization=dm)
     err = _rel(got, want)
     print(f"{variant}: logL ratio in [{want.min():.2f}, {want.max():.2f}], max rel err {err.max():.3e}")
     assert np.all(np.isfinite(want)) and want.max() > 10.0      # the data do hold a signal
@@ -158,12 +167,44 @@ def test_unsupported_configurations_are_refused(torch_cuda):
         GWEngine(case["ifos"], ["chirp_mass"], waveform_arguments=case["waveform_arguments"])
     wg = WaveformGenerator(case["duration"], 2048.0, waveform_arguments=case["waveform_arguments"])
     priors = {n: None for n in syn.GW_NAMES}
-    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True), dict(gw_likelihood_type="ROQGravitationalWaveTransient"),
-               dict(reference_frame="H1L1")):
+    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True),      # (no distance prior to marginalise over)
+               dict(gw_likelihood_type="ROQGravitationalWaveTransient"), dict(reference_frame="H1L1")):
         with pytest.raises(L.NMMAHipError):
             GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, **kw)
     with pytest.raises(ValueError):
         GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, gw_likelihood_type="Nonsense")
+
+
+def test_reference_constructor_with_distance_and_phase_marginalisation(torch_cuda):
+    """``GravitationalWaveTransientLikelihood(..., distance_marginalization=True, phase_marginalization=True)`` as
+    gw_likelihood.py:174-178 builds it: the grid comes from ``priors['luminosity_distance']`` (10^4 nodes, as bilby), the
+    distance and phase columns disappear from the sampled parameters, and the value agrees with the oracle's direct sum."""
+    torch = torch_cuda
+    from nmma_amd import _lib as L
+    from nmma_amd.gw import GravitationalWaveTransientLikelihood, WaveformGenerator
+    from nmma_amd.gw.gw_likelihood import distance_marginalization_grid
+    from tests.helpers import PowerLawPrior, SimplePrior
+    case = make_case(duration=8.0, sampling_frequency=2048.0, ifo_names=("H1", "L1"))
+    names = [n for n in syn.GW_NAMES if n not in ("phase", "luminosity_distance")]
+    priors = {n: SimplePrior(0.0, 1.0) for n in names}
+    priors["luminosity_distance"] = PowerLawPrior(2.0, 10.0, 250.0)
+    priors["phase"] = SimplePrior(0.0, 2 * np.pi)
+    wg = WaveformGenerator(case["duration"], 2048.0, waveform_arguments=case["waveform_arguments"])
+    gw = GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, distance_marginalization=True, phase_marginalization=True)
+    assert gw.sub_model.distance_marginalization and gw.sub_model.phase_marginalization
+    _, theta = syn.draw_gw_theta(41, 12, centre=case["injection"], names=names)
+    got = gw.log_likelihood_batch(torch.as_tensor(theta, device="cuda:0"), names).cpu().numpy()
+    grid, logw, ref = distance_marginalization_grid(priors["luminosity_distance"])
+    assert grid.size == 10000
+    want = oracle_loglike_ratio(case, names, theta, dict(luminosity_distance=ref), phase_marginalization=True,
+                                distance_marginalization=(grid, logw)) + gw.noise_log_likelihood()
+    assert _rel(got, want).max() <= GW_RTOL
+    # the marginal does not depend on where the waveform was evaluated
+    p = dict(zip(names, theta[0]))
+    one = gw.log_likelihood(p)
+    assert abs(one - got[0]) <= 1e-9 * abs(got[0])
+    with pytest.raises(L.NMMAHipError):
+        gw.log_likelihood_batch(torch.as_tensor(np.c_[theta, np.full(len(theta), 40.0)], device="cuda:0"), names + ["luminosity_distance"])
 
 
 def test_reference_shaped_likelihood_and_joint_sum(torch_cuda):
