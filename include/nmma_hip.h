@@ -288,6 +288,13 @@ typedef struct nmma_gw_config {
     int32_t pad_distance;
     const double* distance_grid;        /* [n_distance] Mpc */
     const double* distance_log_weight;  /* [n_distance] */
+    /* Time marginalisation (bilby GravitationalWaveTransient(time_marginalization=True), gw_likelihood.py:174-178):
+     * time_log_weight != NULL replaces the likelihood ratio by log sum_j w_j exp(x_j) over the n_freq - 1 coalescence times
+     * t_j = start_time + j * duration / (n_freq - 1), x_j = Re F_j - <h|h>/2 (ln I0(|F_j|) - <h|h>/2 with phase marginalisation),
+     * F = 4/T * FFT_k( sum_ifo conj(d_k) h_k / S_k ), k = 0 .. n_freq - 2 (bilby/gw/likelihood/base.py: calculate_snrs,
+     * time_marginalized_likelihood), with the row's geocent_time fixed at start_time as bilby does, and
+     * time_log_weight[j] = ln(prior(t_j) * delta_t) (-inf outside the prior's support).  Not combined with distance marginalisation. */
+    const double* time_log_weight;      /* [n_freq - 1] or NULL */
 } nmma_gw_config;
 
 typedef struct nmma_gw_handle nmma_gw_handle;

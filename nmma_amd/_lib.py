@@ -95,6 +95,7 @@ class GwConfig(C.Structure):
         ("luminosity_distance", Slot), ("theta_jn", Slot), ("phase", Slot), ("ra", Slot), ("dec", Slot), ("psi", Slot),
         ("geocent_time", Slot),
         ("n_distance", C.c_int32), ("pad_distance", C.c_int32), ("distance_grid", _pd), ("distance_log_weight", _pd),
+        ("time_log_weight", _pd),
     ]
 
 

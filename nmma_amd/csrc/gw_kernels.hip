@@ -134,6 +134,8 @@ struct GwDev {
     int32_t n_dist, pad_dist;      // distance marginalisation: grid points (0: off)
     const double* dist_grid;       // [n_dist] Mpc
     const double* dist_logw;       // [n_dist] ln(prior(d_j) delta_d)
+    const double* time_logw;       // time marginalisation: [n_freq - 1] ln(prior(t_j) delta_t), or null
+    int64_t tm_lo, tm_hi;          // first / one past the last time index with a finite weight
     int64_t n_bins;                // bins k0 .. k0 + n_bins - 1 of the frequency array
     int64_t k0, n_freq;
     int32_t n_chunks, n_dim;       // chunks of GWL_CHUNK bins
@@ -422,6 +424,135 @@ __global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict_
 }
 
 // =======================================================================================
+// Time marginalisation (bilby/gw/likelihood/base.py: calculate_snrs + time_marginalized_likelihood)
+// gw_integrand_kernel: I[b][k] = sum_ifo conj(d_k) h_k / S_k for k = 0 .. n_freq - 2 (zero outside the evaluated band), the
+//   array whose forward FFT is <d|h> as a function of the coalescence-time shift j * duration / (n_freq - 1);
+// gw_time_marg_kernel: log sum_j w_j exp(x_j) over the support of the time prior, one workgroup per sample.
+// =======================================================================================
+template <int NIFO>
+__global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src, const long b0,
+                                                           const long nb, double2* __restrict__ out) {
+    const GwDev& P = *Pp;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long bl = blockIdx.y;
+    const long N = P.n_freq - 1;
+    if (k >= N) return;
+    double2 acc = make_double2(0.0, 0.0);
+    const long i = k - P.k0;
+    if (bl < nb && i >= 0 && i < P.n_bins) {
+        const gw::GwSource& S = src[b0 + bl];
+        if (S.valid != 0.0) {
+            gw::GwBin bin;
+            bin.f = (double)k * P.df;
+            const double4 bs = P.basis[i];
+            bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
+            bin.p578 = P.basis5[i];
+            double amp = 0.0, ph = 0.0;
+            gw::eval_bin(S, bin, amp, ph);
+#pragma unroll
+            for (int d = 0; d < NIFO; ++d) {
+                const double4 wd = P.dat[(long)d * P.n_bins + i];      // {w d_re, w d_im, w, 0}
+                double t = -(ph + 2.0 * bin.f * S.dt[d]);
+                t -= 2.0 * rint(0.5 * t);
+                double sn, cs;
+                sincospi(t, &sn, &cs);
+                const double hr = amp * (S.k_re[d] * cs - S.k_im[d] * sn), hi = amp * (S.k_re[d] * sn + S.k_im[d] * cs);
+                acc.x += wd.x * hr + wd.y * hi;                        // conj(d) h w
+                acc.y += wd.x * hi - wd.y * hr;
+            }
+        }
+    }
+    out[bl * N + k] = acc;
+}
+
+// First stage of the N = GW_TM_N1 x N2 decomposition (k = N2 k1 + k2, j = j1 + GW_TM_N1 j2): one workgroup per (k2, row) gathers
+// the row's integrand at k = N2 k1 + k2, does the GW_TM_N1-point FFT over k1 in LDS (radix 2, decimation in time), applies the twiddle
+// exp(-2 pi i j1 k2 / N) and stores G[row][k2][j1].  The second stage is pruned: gw_time_marg_kernel sums over k2 only for the shifts
+// j the time prior supports (a few hundred of the 2.6e5 of config 5).
+constexpr int GW_TM_N1 = 1024;
+__global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restrict__ I, const long N, const int N2, double2* __restrict__ G) {
+    __shared__ double2 x[GW_TM_N1];
+    const int k2 = blockIdx.x;
+    const long bl = blockIdx.y;
+    const double2* Ib = I + bl * N;
+    for (int t = threadIdx.x; t < GW_TM_N1; t += 256) x[__brev((unsigned)t) >> 22] = Ib[(long)N2 * t + k2];      // bit-reversed (10 bits)
+    __syncthreads();
+    for (int len = 2; len <= GW_TM_N1; len <<= 1) {
+        const int half = len >> 1;
+        for (int t = threadIdx.x; t < GW_TM_N1 / 2; t += 256) {
+            const int grp = t / half, pos = t - grp * half;
+            const int i0 = grp * len + pos, i1 = i0 + half;
+            double sn, cs;
+            sincospi(-2.0 * (double)pos / (double)len, &sn, &cs);
+            const double2 a = x[i0], c = x[i1];
+            const double2 w = make_double2(c.x * cs - c.y * sn, c.x * sn + c.y * cs);
+            x[i0] = make_double2(a.x + w.x, a.y + w.y);
+            x[i1] = make_double2(a.x - w.x, a.y - w.y);
+        }
+        __syncthreads();
+    }
+    for (int j1 = threadIdx.x; j1 < GW_TM_N1; j1 += 256) {
+        double sn, cs;
+        sincospi(-2.0 * ((double)j1 * (double)k2) / (double)N, &sn, &cs);
+        const double2 v = x[j1];
+        G[(bl * N2 + k2) * GW_TM_N1 + j1] = make_double2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+    }
+}
+
+__global__ __launch_bounds__(256) void gw_time_marg_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                          const double2* __restrict__ G, const double* __restrict__ parts, const long b0,
+                                                          const int N2, double* __restrict__ out) {
+    const GwDev& P = *Pp;
+    const long b = b0 + blockIdx.x;
+    const double2* Gb = G + (long)blockIdx.x * N2 * GW_TM_N1;
+    const double hh = parts[3 * b + 2];
+    __shared__ double red[256];
+    __shared__ double xs[1024];               // x_j of the supported shifts, kept between the two passes (re-summed when there are more)
+    double mx = -dinf();
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0, m = -dinf();
+        for (long j = P.tm_lo + threadIdx.x; j < P.tm_hi; j += 256) {
+            const double lw = P.time_logw[j];
+            if (!(lw > -dinf())) continue;
+            const long slot = j - P.tm_lo;
+            double x;
+            if (pass == 0 || slot >= 1024) {
+                // F_j = 4/T sum_k2 G[k2][j1] exp(-2 pi i j2 k2 / N2)
+                const int j1 = (int)(j & (GW_TM_N1 - 1));
+                const long j2 = j >> 10;
+                double re = 0.0, im = 0.0;
+                for (int k2 = 0; k2 < N2; ++k2) {
+                    double sn, cs;
+                    sincospi(-2.0 * (double)((j2 * k2) % N2) / (double)N2, &sn, &cs);
+                    const double2 g = Gb[(long)k2 * GW_TM_N1 + j1];
+                    re += g.x * cs - g.y * sn;
+                    im += g.x * sn + g.y * cs;
+                }
+                re *= P.four_over_T; im *= P.four_over_T;
+                x = (P.phase_marg ? gw::ln_bessel_i0(sqrt(re * re + im * im)) : re) - hh / 2.0 + lw;
+                if (pass == 0 && slot < 1024) xs[slot] = x;
+            } else {
+                x = xs[slot];
+            }
+            if (pass == 0) m = x > m ? x : m; else acc += exp(x - mx);
+        }
+        red[threadIdx.x] = pass == 0 ? m : acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] = pass == 0 ? (red[threadIdx.x] > red[threadIdx.x + st] ? red[threadIdx.x] : red[threadIdx.x + st])
+                                                                   : red[threadIdx.x] + red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (pass == 0) mx = red[0];
+        else if (threadIdx.x == 0) {
+            const double r = mx + log(red[0]);
+            out[b] = (src[b].valid != 0.0 && isfinite(r)) ? r : NMMA_LOGL_FLOOR;
+        }
+        __syncthreads();
+    }
+}
+
+// =======================================================================================
 // sum over messengers + floor (MultiMessengerLikelihood.sub_log_likelihood, joint/joint_likelihood.py:62-67)
 // =======================================================================================
 struct LoglParts {
@@ -463,6 +594,10 @@ struct nmma_gw_handle {
     bool prof_on = false;
     std::vector<hipEvent_t> ev;
     int prof_max = 0;
+    // time marginalisation: the per-bin integrand of tm_batch rows and its first FFT stage; <d|h>, <h|h> per row
+    int64_t tm_batch = 0, tm_parts_cap = 0;
+    double2* tm_buf = nullptr;      // [2][tm_batch][n_freq - 1]: integrand | first FFT stage
+    double* tm_parts = nullptr;
 };
 
 extern "C" {
@@ -513,6 +648,8 @@ void nmma_gw_destroy(nmma_gw_handle* h) {
     for (void* p : h->owned) (void)hipFree(p);
     if (h->src) (void)hipFree(h->src);
     if (h->partial) (void)hipFree(h->partial);
+    if (h->tm_buf) (void)hipFree(h->tm_buf);
+    if (h->tm_parts) (void)hipFree(h->tm_parts);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -614,6 +751,18 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
         if (e == hipSuccess) { P.dist_grid = reinterpret_cast<const double*>(p); e = up(c->distance_log_weight, (size_t)c->n_distance * 8, &p); }
         if (e == hipSuccess) { P.dist_logw = reinterpret_cast<const double*>(p); P.n_dist = c->n_distance; }
     }
+    P.time_logw = nullptr; P.tm_lo = 0; P.tm_hi = 0;
+    if (e == hipSuccess && c->time_log_weight != nullptr) {      // time marginalisation
+        if (c->n_distance > 0) { nmma_gw_destroy(h); return fail("nmma_gw_create: time and distance marginalisation are not combined on the device path"); }
+        const int64_t N = NF - 1;
+        if (N % GW_TM_N1 != 0) { nmma_gw_destroy(h); return fail("nmma_gw_create: time marginalisation needs n_freq - 1 to be a multiple of 1024"); }
+        int64_t lo = N, hi = 0;
+        for (int64_t j = 0; j < N; ++j)
+            if (c->time_log_weight[j] > -HUGE_VAL) { lo = std::min(lo, j); hi = std::max(hi, j + 1); }
+        if (hi <= lo) { nmma_gw_destroy(h); return fail("nmma_gw_create: the time prior has no support inside the data segment"); }
+        e = up(c->time_log_weight, (size_t)N * 8, &p);
+        if (e == hipSuccess) { P.time_logw = reinterpret_cast<const double*>(p); P.tm_lo = lo; P.tm_hi = hi; }
+    }
     if (e == hipSuccess) e = up(&P, sizeof(P), &p);
     if (e != hipSuccess) { nmma_gw_destroy(h); return fail(std::string("nmma_gw_create: ") + hipGetErrorString(e)); }
     h->dev_d = reinterpret_cast<GwDev*>(p);
@@ -671,8 +820,44 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
     }
 #undef GW_LAUNCH
     if (prof) GW_HIP(hipEventRecord(h->ev.back(), s));
-    hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode,
-                       P.n_chunks, out_dev);
+    const bool tm = P.time_logw != nullptr && mode == 0;
+    if (tm) {
+        // time marginalisation: <h|h> from the fused kernel (mode 1 of the finish step), then per chunk of rows the per-bin
+        // integrand, the first stage of its FFT over the coalescence-time shifts and the weighted log-sum over the prior's support
+        const int64_t N = P.n_freq - 1;
+        if (h->tm_parts_cap < B) {
+            GW_HIP(hipDeviceSynchronize());
+            if (h->tm_parts) (void)hipFree(h->tm_parts);
+            h->tm_parts = nullptr; h->tm_parts_cap = 0;
+            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_parts), (size_t)std::max<int64_t>(B, 256) * 3 * sizeof(double)));
+            h->tm_parts_cap = std::max<int64_t>(B, 256);
+        }
+        const int N2 = (int)(N / GW_TM_N1);
+        if (h->tm_buf == nullptr) {
+            const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)1 << 28) / (N * 16)));      // 2 x <= 256 MiB
+            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_buf), (size_t)2 * batch * N * sizeof(double2)));
+            h->tm_batch = batch;
+        }
+        double2* const integrand = h->tm_buf;
+        double2* const stage1 = h->tm_buf + h->tm_batch * N;
+        hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, 1,
+                           P.n_chunks, h->tm_parts);
+        for (int64_t b0 = 0; b0 < B; b0 += h->tm_batch) {
+            const int64_t nb = std::min<int64_t>(h->tm_batch, B - b0);
+            const dim3 g((unsigned)((N + 255) / 256), (unsigned)nb);
+            switch (P.n_ifo) {
+                case 1: hipLaunchKernelGGL(gw_integrand_kernel<1>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
+                case 2: hipLaunchKernelGGL(gw_integrand_kernel<2>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
+                case 3: hipLaunchKernelGGL(gw_integrand_kernel<3>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
+                default: hipLaunchKernelGGL(gw_integrand_kernel<4>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
+            }
+            hipLaunchKernelGGL(gw_tm_fft_kernel, dim3((unsigned)N2, (unsigned)nb), dim3(256), 0, s, integrand, (long)N, N2, stage1);
+            hipLaunchKernelGGL(gw_time_marg_kernel, dim3((unsigned)nb), dim3(256), 0, s, h->dev_d, h->src, stage1, h->tm_parts, (long)b0, N2, out_dev);
+        }
+    } else {
+        hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode,
+                           P.n_chunks, out_dev);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string(what) + " launch failed: " + hipGetErrorString(e));
     return 0;

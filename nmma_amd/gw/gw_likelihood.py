@@ -139,7 +139,7 @@ class GWEngine:
     ``chi_1`` / ``chi_2``; inclination: ``theta_jn`` or ``cos_theta_jn``.  No CPU fallback."""
 
     def __init__(self, interferometers, parameter_names, fixed=None, waveform_arguments=None, phase_marginalization=False,
-                 gmst_reference_time=None, device=0, distance_marginalization=None):
+                 gmst_reference_time=None, device=0, distance_marginalization=None, time_marginalization=None):
         import torch  # noqa: F401  (device buffers / stream)
         self._handle = None
         self._lib = L.load_library()
@@ -218,7 +218,18 @@ class GWEngine:
             cfg.n_distance = dgrid.size
             cfg.distance_grid, cfg.distance_log_weight = dgrid.ctypes.data_as(L._pd), dlogw.ctypes.data_as(L._pd)
             dist = (dgrid, dlogw)
-        keep = (data, psd, mask, tensor, vertex, dist)        # alive until create returns (the library copies)
+        tlw = None
+        if time_marginalization is not None:
+            # ln(prior(t_j) * delta_t) on the n_freq - 1 coalescence times of the segment -- see time_marginalization_weights
+            tlw = np.ascontiguousarray(time_marginalization, dtype=np.float64)
+            if tlw.shape != (n_freq - 1,):
+                raise L.NMMAHipError(f"time_marginalization needs ln(prior x step) on the {n_freq - 1} time shifts of the segment")
+            if "geocent_time" in names:
+                raise L.NMMAHipError("geocent_time is marginalised: it must not be a sampled column")
+            if distance_marginalization is not None:
+                raise L.NMMAHipError("time and distance marginalisation are not combined on the device path")
+            cfg.time_log_weight = tlw.ctypes.data_as(L._pd)
+        keep = (data, psd, mask, tensor, vertex, dist, tlw)        # alive until create returns (the library copies)
         h = C.c_void_p()
         L.check(self._lib.nmma_gw_create(C.byref(cfg), C.byref(h)), "nmma_gw_create")
         del keep
@@ -226,6 +237,7 @@ class GWEngine:
         self.n_bins = int(self._lib.nmma_gw_n_bins(h))
         self.phase_marginalization = bool(phase_marginalization)
         self.distance_marginalization = distance_marginalization is not None
+        self.time_marginalization = time_marginalization is not None
         self._noise = float(self._lib.nmma_gw_noise_log_likelihood(h))
 
     # ---- lifetime
@@ -326,6 +338,19 @@ def distance_marginalization_grid(prior, n=10000):
     return grid, logw, ref
 
 
+def time_marginalization_weights(prior, start_time, duration, n_freq):
+    """What bilby's ``_setup_time_marginalization`` tabulates from the ``geocent_time`` prior (bilby/gw/likelihood/base.py): the
+    coalescence times the FFT of the integrand resolves, ``delta_tc = duration / (n_freq - 1)`` (= 2 / sampling_frequency) apart,
+    and ``prior.prob`` on them times the step, as ln(prob x step).  Index j is the shift j * delta_tc of a waveform evaluated
+    with ``geocent_time = start_time`` (bilby's delta-function replacement of the time prior)."""
+    n = int(n_freq) - 1
+    delta = float(duration) / n
+    times = float(start_time) + delta * np.arange(n)
+    prob = np.asarray(prior.prob(times), dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        return np.log(prob * delta)
+
+
 class GravitationalWaveTransient:
     """What ``GravitationalWaveTransientLikelihood.sub_model`` exposes of ``bilby.gw.likelihood.GravitationalWaveTransient``:
     the objects it was built from, the marginalisation flags, ``noise_log_likelihood`` and the evaluation -- per sample
@@ -333,11 +358,20 @@ class GravitationalWaveTransient:
     lazily per process and dropped on pickling, like the EM likelihood's."""
 
     def __init__(self, interferometers, waveform_generator, priors=None, phase_marginalization=False, device=0,
-                 distance_marginalization=False):
+                 distance_marginalization=False, time_marginalization=False):
         self.interferometers, self.waveform_generator, self.priors = list(interferometers), waveform_generator, priors
-        self.phase_marginalization, self.time_marginalization = bool(phase_marginalization), False
+        self.phase_marginalization, self.time_marginalization = bool(phase_marginalization), bool(time_marginalization)
         self.distance_marginalization = bool(distance_marginalization)
-        self._distance = None
+        self._distance, self._time_logw = None, None
+        if self.time_marginalization:
+            if self.distance_marginalization:
+                raise L.NMMAHipError("time and distance marginalisation are not combined on the device path")
+            try:
+                ifo = self.interferometers[0]
+                self._time_logw = time_marginalization_weights(priors["geocent_time"], ifo.strain_data.start_time,
+                                                               ifo.strain_data.duration, len(ifo.frequency_array))
+            except (KeyError, TypeError, AttributeError) as exc:
+                raise L.NMMAHipError("time marginalisation needs priors['geocent_time'] with prob()") from exc
         if self.distance_marginalization:
             try:
                 prior = priors["luminosity_distance"]
@@ -364,6 +398,8 @@ class GravitationalWaveTransient:
             fixed["phase"] = 0.0        # bilby: the phase prior becomes a delta function at 0
         if self.distance_marginalization:
             fixed["luminosity_distance"] = self._distance[2]      # bilby: ... and the distance prior one at the reference distance
+        if self.time_marginalization:
+            fixed["geocent_time"] = float(self.interferometers[0].strain_data.start_time)     # bilby: ... the time prior one at the segment start
         return fixed
 
     def engine(self, names):
@@ -372,15 +408,28 @@ class GravitationalWaveTransient:
             raise L.NMMAHipError("phase is marginalised: it must not be a sampled column")
         if self.distance_marginalization and "luminosity_distance" in names:
             raise L.NMMAHipError("luminosity_distance is marginalised: it must not be a sampled column")
+        if self.time_marginalization and "geocent_time" in names:
+            raise L.NMMAHipError("geocent_time is marginalised: it must not be a sampled column")
         if self._engine is None or self._names != names:
             if self._engine is not None:
                 self._engine.close()
             self._engine = GWEngine(self.interferometers, names, fixed=self.fixed_parameters(names),
                                     waveform_arguments=self.waveform_generator.waveform_arguments,
                                     phase_marginalization=self.phase_marginalization, device=self.device,
-                                    distance_marginalization=self._distance[:2] if self.distance_marginalization else None)
+                                    distance_marginalization=self._distance[:2] if self.distance_marginalization else None,
+                                    time_marginalization=self._time_logw,
+                                    gmst_reference_time=self._gmst_reference_time())
             self._names = names
         return self._engine
+
+    def _gmst_reference_time(self):
+        """Where the sidereal time is linearised: with the time marginalised the waveform sits at the segment start while the signal
+        sits in the support of the time prior -- take the prior's centre (the antenna pattern is evaluated at the row's geocent_time,
+        as in bilby, so this only keeps the linearisation error of the rotation negligible)."""
+        if not self.time_marginalization:
+            return None
+        ifo = self.interferometers[0]
+        return float(ifo.strain_data.start_time)
 
     def noise_log_likelihood(self):
         return self._noise
@@ -408,9 +457,11 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
     moved to the GPU for a whole batch (``log_likelihood_batch``).
 
     Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` and
-    ``distance_marginalization`` on or off (the distance sum evaluated per row instead of bilby's lookup table), sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
+    ``distance_marginalization`` on or off (the distance sum evaluated per row instead of bilby's lookup table) or
+    ``time_marginalization`` (FFT of the per-bin integrand over the coalescence-time shifts, ``jitter_time=False``), sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
     Refused at construction (never approximated): the ROQ / relative-binning / multibanded likelihood classes (they need
-    bilby's basis files and fiducial waveforms), time marginalisation (:174-178), other reference frames."""
+    bilby's basis files and fiducial waveforms), time marginalisation with ``jitter_time`` or together with distance
+    marginalisation, other reference frames."""
 
     def __init__(self, priors, interferometers, waveform_generator, gw_likelihood_type="GravitationalWaveTransient",
                  time_marginalization=False, distance_marginalization=False, phase_marginalization=False,
@@ -424,15 +475,16 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
             raise ValueError("Unknown GW Likelihood class {}")                            # :205 (sic)
         if gw_likelihood_type != "GravitationalWaveTransient":
             raise L.NMMAHipError(f"{gw_likelihood_type} is not built on the device path (it needs bilby's basis / fiducial data)")
-        if time_marginalization:
-            raise L.NMMAHipError("time marginalisation is not built on the device path")
+        if time_marginalization and jitter_time:
+            raise L.NMMAHipError("time marginalisation on the device path takes jitter_time=False (no per-call random time offset)")
         if distance_marginalization and distance_marginalization_lookup_table is not None:
             pass        # (bilby caches its (d_inner_h, h_inner_h) table there; the device evaluates the sum per row and needs none)
         if reference_frame != "sky" or time_reference not in ("geocent", "geocenter"):
             raise L.NMMAHipError("only reference_frame='sky' and time_reference='geocenter' are built on the device path")
         sub_model = GravitationalWaveTransient(interferometers, waveform_generator, priors=priors,
                                                phase_marginalization=phase_marginalization, device=device,
-                                               distance_marginalization=distance_marginalization)
+                                               distance_marginalization=distance_marginalization,
+                                               time_marginalization=time_marginalization)
         super().__init__(sub_model, priors)
         from ..core import conversion
         name = getattr(waveform_generator.frequency_domain_source_model, "__name__", "")

@@ -591,18 +591,34 @@ def ln_i0(x):
 
 
 def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalization=False, tidal=True, f_max_waveform=np.inf,
-                         distance_marginalization=None):
+                         distance_marginalization=None, time_marginalization=None):
     """``ifos``: list of dicts with name, frequency_array, data, psd, mask, start_time, duration.
     ``distance_marginalization`` = (grid, ln(prior x step)): bilby's distance-marginalised likelihood
     (bilby/gw/likelihood/base.py: ``distance_marginalized_likelihood`` with the sum of ``_create_lookup_table`` evaluated
     directly instead of tabulated over (d_inner_h, h_inner_h) and interpolated)."""
     d_inner_h, opt = 0.0 + 0.0j, 0.0
+    tc_array = 0.0
     for ifo in ifos:
         m = ifo["mask"]
         fa = ifo["frequency_array"]
         h = detector_strain(params, ifo["name"], fa, ifo["start_time"], f_ref, f_min_waveform, f_max_waveform, tidal)
+        if time_marginalization is not None:
+            # bilby calculate_snrs: d_inner_h_array = 4 / duration * fft(signal[0:-1] * conj(data)[0:-1] / psd[0:-1]); the data are
+            # zero outside the detector's band (frequency_domain_strain * frequency_mask)
+            prod = np.where(m, h * np.conj(ifo["data"]) / ifo["psd"], 0.0)[:-1]
+            tc_array = tc_array + 4.0 / ifo["duration"] * np.fft.fft(prod)
         d_inner_h += 4.0 / ifo["duration"] * np.sum(np.conj(ifo["data"][m]) * h[m] / ifo["psd"][m])
         opt += (4.0 / ifo["duration"] * np.sum(np.conj(h[m]) * h[m] / ifo["psd"][m])).real
+    if time_marginalization is not None:
+        # bilby time_marginalized_likelihood: logsumexp(log_l_tc_array, b=time_prior_array), params["geocent_time"] = start_time
+        from scipy.special import logsumexp
+        logw = np.asarray(time_marginalization, dtype=np.float64)
+        keep = np.isfinite(logw)
+        if phase_marginalization:
+            x = np.array([ln_i0(abs(v)) for v in tc_array[keep]]) - opt / 2.0
+        else:
+            x = tc_array[keep].real - opt / 2.0
+        return float(logsumexp(x + logw[keep]))
     if distance_marginalization is not None:
         from scipy.special import logsumexp
         grid, logw = (np.asarray(a, dtype=np.float64) for a in distance_marginalization)

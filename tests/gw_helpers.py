@@ -29,7 +29,8 @@ def make_case(seed=11, duration=4.0, sampling_frequency=2048.0, ifo_names=("H1",
                 f_min=minimum_frequency, tidal=tidal, start_time=start, duration=duration, frequency_array=freq)
 
 
-def oracle_loglike_ratio(case, names, theta, fixed=None, phase_marginalization=False, distance_marginalization=None):
+def oracle_loglike_ratio(case, names, theta, fixed=None, phase_marginalization=False, distance_marginalization=None,
+                         time_marginalization=None):
     from oracle import gw_waveform_oracle as gwo
     out = np.empty(len(theta))
     for i, row in enumerate(theta):
@@ -40,5 +41,6 @@ def oracle_loglike_ratio(case, names, theta, fixed=None, phase_marginalization=F
             p["phase"] = 0.0
         out[i] = gwo.log_likelihood_ratio(p, case["oracle_ifos"], case["f_ref"], case["f_min"],
                                           phase_marginalization=phase_marginalization, tidal=case["tidal"],
-                                          distance_marginalization=distance_marginalization)
+                                          distance_marginalization=distance_marginalization,
+                                          time_marginalization=time_marginalization)
     return out

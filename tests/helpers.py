@@ -26,6 +26,17 @@ class SimplePrior:
             self.peak = peak
 
 
+class UniformPrior(SimplePrior):
+    """bilby.core.prior.Uniform(minimum, maximum): ``prob`` as bilby defines it."""
+
+    def prob(self, val):
+        val = np.asarray(val, dtype=np.float64)
+        return np.where((val >= self.minimum) & (val <= self.maximum), 1.0 / (self.maximum - self.minimum), 0.0)
+
+    def rescale(self, val):
+        return self.minimum + val * (self.maximum - self.minimum)
+
+
 class PowerLawPrior(SimplePrior):
     """bilby.core.prior.PowerLaw(alpha, minimum, maximum): p(x) ~ x^alpha (alpha = 2: uniform in volume, bilby's usual
     luminosity-distance prior) -- ``prob`` and ``rescale`` as bilby defines them (bilby/core/prior/analytical.py)."""

@@ -63,13 +63,13 @@ def test_projected_strain_matches_oracle(approximant, torch_cuda):
 
 
 @pytest.mark.parametrize("variant", ["bns", "phase_marginalised", "distance_marginalised", "distance_phase_marginalised",
-                                     "component_masses_cos", "two_ifos", "one_ifo_bbh"])
+                                     "time_marginalised", "time_phase_marginalised", "component_masses_cos", "two_ifos", "one_ifo_bbh"])
 def test_loglike_ratio_matches_oracle(variant, torch_cuda):
     from nmma_amd.gw import GWEngine
-    from nmma_amd.gw.gw_likelihood import distance_marginalization_grid
-    from tests.helpers import PowerLawPrior
-    kw, names, fixed, pm, dm = {}, list(syn.GW_NAMES), {}, False, None
-    if variant in ("phase_marginalised", "distance_phase_marginalised"):
+    from nmma_amd.gw.gw_likelihood import distance_marginalization_grid, time_marginalization_weights
+    from tests.helpers import PowerLawPrior, UniformPrior
+    kw, names, fixed, pm, dm, tm = {}, list(syn.GW_NAMES), {}, False, None, None
+    if variant in ("phase_marginalised", "distance_phase_marginalised", "time_phase_marginalised"):
         names.remove("phase")
         pm = True
     if variant in ("distance_marginalised", "distance_phase_marginalised"):
@@ -86,6 +86,12 @@ def test_loglike_ratio_matches_oracle(variant, torch_cuda):
         names = ["mass_1", "mass_2", "chi_1", "chi_2", "luminosity_distance", "theta_jn", "phase", "ra", "dec", "psi", "geocent_time"]
     case = make_case(**kw)
     centre = dict(case["injection"])
+    if variant in ("time_marginalised", "time_phase_marginalised"):
+        # a uniform prior of +-0.1 s around the trigger; the waveform is evaluated with geocent_time = segment start, as bilby does
+        t0 = case["injection"]["geocent_time"]
+        tm = time_marginalization_weights(UniformPrior(t0 - 0.1, t0 + 0.1), case["start_time"], case["duration"], len(case["frequency_array"]))
+        names.remove("geocent_time")
+        fixed = dict(geocent_time=case["start_time"])
     if variant == "component_masses_cos":
         from oracle import gw_waveform_oracle as gwo
         m1, m2 = gwo.component_masses(centre["chirp_mass"], centre["mass_ratio"])
@@ -96,9 +102,9 @@ def test_loglike_ratio_matches_oracle(variant, torch_cuda):
     names, theta = syn.draw_gw_theta(21, 40, centre=centre, names=names, width=0.5 if variant != "one_ifo_bbh" else 0.2)
     theta[0] = [centre[n] for n in names]                       # the injection itself: the likelihood peak
     eng = GWEngine(case["ifos"], names, fixed=fixed, waveform_arguments=case["waveform_arguments"], phase_marginalization=pm,
-                   distance_marginalization=dm)
+                   distance_marginalization=dm, time_marginalization=tm)
     got = eng.loglike_ratio(theta).cpu().numpy()
-    want = oracle_loglike_ratio(case, names, theta, fixed, phase_marginalization=pm, distance_marginalization=dm)
+    want = oracle_loglike_ratio(case, names, theta, fixed, phase_marginalization=pm, distance_marginalization=dm, time_marginalization=tm)
     err = _rel(got, want)
     print(f"{variant}: logL ratio in [{want.min():.2f}, {want.max():.2f}], max rel err {err.max():.3e}")
     assert np.all(np.isfinite(want)) and want.max() > 10.0      # the data do hold a signal
@@ -167,7 +173,7 @@ def test_unsupported_configurations_are_refused(torch_cuda):
         GWEngine(case["ifos"], ["chirp_mass"], waveform_arguments=case["waveform_arguments"])
     wg = WaveformGenerator(case["duration"], 2048.0, waveform_arguments=case["waveform_arguments"])
     priors = {n: None for n in syn.GW_NAMES}
-    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True),      # (no distance prior to marginalise over)
+    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True),      # (jitter_time defaults to True; no distance prior)
                dict(gw_likelihood_type="ROQGravitationalWaveTransient"), dict(reference_frame="H1L1")):
         with pytest.raises(L.NMMAHipError):
             GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, **kw)
@@ -205,6 +211,36 @@ def test_reference_constructor_with_distance_and_phase_marginalisation(torch_cud
     assert abs(one - got[0]) <= 1e-9 * abs(got[0])
     with pytest.raises(L.NMMAHipError):
         gw.log_likelihood_batch(torch.as_tensor(np.c_[theta, np.full(len(theta), 40.0)], device="cuda:0"), names + ["luminosity_distance"])
+
+
+def test_reference_constructor_with_time_marginalisation(torch_cuda):
+    """``GravitationalWaveTransientLikelihood(..., time_marginalization=True, jitter_time=False)`` on a longer segment (16 384 time
+    shifts: a 1024 x 16 decomposition of the transform, whose second stage is evaluated only on the 400 shifts the prior supports)
+    against the oracle's numpy FFT; ``jitter_time`` (bilby's per-call random offset) is refused."""
+    torch = torch_cuda
+    from nmma_amd import _lib as L
+    from nmma_amd.gw import GravitationalWaveTransientLikelihood, WaveformGenerator
+    from nmma_amd.gw.gw_likelihood import time_marginalization_weights
+    from tests.helpers import SimplePrior, UniformPrior
+    case = make_case(duration=8.0, sampling_frequency=4096.0, ifo_names=("H1", "L1"))
+    names = [n for n in syn.GW_NAMES if n not in ("phase", "geocent_time")]
+    t0 = case["injection"]["geocent_time"]
+    priors = {n: SimplePrior(0.0, 1.0) for n in names}
+    priors["geocent_time"] = UniformPrior(t0 - 0.05, t0 + 0.05)
+    priors["phase"] = SimplePrior(0.0, 2 * np.pi)
+    wg = WaveformGenerator(case["duration"], 4096.0, waveform_arguments=case["waveform_arguments"])
+    with pytest.raises(L.NMMAHipError):
+        GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, time_marginalization=True)          # jitter_time defaults to True
+    gw = GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, time_marginalization=True, phase_marginalization=True,
+                                              jitter_time=False)
+    _, theta = syn.draw_gw_theta(43, 6, centre=case["injection"], names=names)
+    got = gw.log_likelihood_batch(torch.as_tensor(theta, device="cuda:0"), names).cpu().numpy()
+    logw = time_marginalization_weights(priors["geocent_time"], case["start_time"], case["duration"], len(case["frequency_array"]))
+    assert logw.shape == (16384,) and np.isfinite(logw).sum() in (204, 205, 206)
+    want = oracle_loglike_ratio(case, names, theta, dict(geocent_time=case["start_time"]), phase_marginalization=True,
+                                time_marginalization=logw) + gw.noise_log_likelihood()
+    assert _rel(got, want).max() <= GW_RTOL
+    assert want.max() - gw.noise_log_likelihood() > 10.0        # the prior window does hold the signal
 
 
 def test_reference_shaped_likelihood_and_joint_sum(torch_cuda):

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--fs", type=float, default=4096.0)
     ap.add_argument("--ifos", default="H1,L1,V1")
     ap.add_argument("--pm", action="store_true", help="phase marginalisation")
+    ap.add_argument("--dm", action="store_true", help="distance marginalisation (bilby's 10^4-node grid, prior uniform in volume)")
+    ap.add_argument("--tm", action="store_true", help="time marginalisation (uniform prior of +-0.1 s around the trigger)")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     import torch
@@ -33,9 +35,23 @@ def main():
     from nmma_amd.gw import GWEngine
     names_ifo = tuple(a.ifos.split(","))
     ifos, wa, inj = syn.make_gw_interferometers(7, a.duration, a.fs, names_ifo)
-    names = [n for n in syn.GW_NAMES if not (a.pm and n == "phase")]
+    names = [n for n in syn.GW_NAMES if not (a.pm and n == "phase") and not (a.dm and n == "luminosity_distance")
+             and not (a.tm and n == "geocent_time")]
     _, theta = syn.draw_gw_theta(3, a.batch, centre=inj, names=names, width=0.3)
-    eng = GWEngine(ifos, names, waveform_arguments=wa, phase_marginalization=a.pm)
+    kw, fixed = {}, {}
+    if a.dm:
+        import numpy as np
+        grid = np.linspace(10.0, 250.0, 10000)
+        kw["distance_marginalization"] = (grid, np.log(3 * grid ** 2 / (250.0 ** 3 - 10.0 ** 3) * (grid[1] - grid[0])))
+        fixed["luminosity_distance"] = 100.0
+    if a.tm:
+        import numpy as np
+        n = len(ifos[0].frequency_array) - 1
+        t = ifos[0].strain_data.start_time + a.duration / n * np.arange(n)
+        with np.errstate(divide="ignore"):
+            kw["time_marginalization"] = np.log(np.where(abs(t - inj["geocent_time"]) <= 0.1, 1.0 / 0.2, 0.0) * a.duration / n)
+        fixed["geocent_time"] = float(ifos[0].strain_data.start_time)
+    eng = GWEngine(ifos, names, fixed=fixed, waveform_arguments=wa, phase_marginalization=a.pm, **kw)
     th = torch.as_tensor(theta, device="cuda:0")
     out = eng.loglike_ratio(th)
     torch.cuda.synchronize()
@@ -50,6 +66,7 @@ def main():
     flops = FLOPS_PER_BIN_SAMPLE[len(names_ifo)] * eng.n_bins * a.batch
     o = out.cpu().numpy()
     print(json.dumps(dict(batch=a.batch, n_ifo=len(names_ifo), n_bins=eng.n_bins, phase_marginalization=a.pm,
+                          distance_marginalization=a.dm, time_marginalization=a.tm,
                           kernel_ms=ms, call_ms=wall * 1e3, evals_per_s=a.batch / wall,
                           bin_samples_per_s=eng.n_bins * a.batch / (ms * 1e-3),
                           roofline=dict(bound="fp64 vector FMA", achieved=flops / (ms * 1e-3) / 1e12, peak=PEAK_F64_TFLOPS, unit="TFLOP/s",
