@@ -293,7 +293,8 @@ typedef struct nmma_gw_config {
      * t_j = start_time + j * duration / (n_freq - 1), x_j = Re F_j - <h|h>/2 (ln I0(|F_j|) - <h|h>/2 with phase marginalisation),
      * F = 4/T * FFT_k( sum_ifo conj(d_k) h_k / S_k ), k = 0 .. n_freq - 2 (bilby/gw/likelihood/base.py: calculate_snrs,
      * time_marginalized_likelihood), with the row's geocent_time fixed at start_time as bilby does, and
-     * time_log_weight[j] = ln(prior(t_j) * delta_t) (-inf outside the prior's support).  Not combined with distance marginalisation. */
+     * time_log_weight[j] = ln(prior(t_j) * delta_t) (-inf outside the prior's support).  With n_distance > 0 as well, x_j is the
+     * distance-marginalised value at F_j (bilby's order: the distance sum inside the time sum). */
     const double* time_log_weight;      /* [n_freq - 1] or NULL */
 } nmma_gw_config;
 

@@ -345,6 +345,24 @@ __global__ __launch_bounds__(GWL_THREADS, GWL_MIN_WAVES) void gw_logl_kernel(con
 }
 
 // mode 0: log-likelihood ratio (floor for invalid / non-finite); mode 1: the three inner products parts[b][3]
+// Distance marginalisation: log sum_j w_j exp(x(d_j)), x(d) = dh (ds / d) - hh (ds / d)^2 / 2 with dh = Re<d|h> (ln I0(dh ds / d) - ...
+// with dh = |<d|h>| when the phase is marginalised too), <d|h> and <h|h> given at the distance ds the row was evaluated at
+// (bilby/gw/likelihood/base.py: distance_marginalized_likelihood + _create_lookup_table, evaluated instead of tabulated).
+__device__ inline double gw_distance_marginalised(const GwDev& P, const double dh, const double hh, const double ds) {
+    // (one pass with a running maximum: the sum is rescaled whenever a larger term appears -- every node costs one exp either way,
+    //  and ln I0 is evaluated once per node instead of twice)
+    double mx = -dinf(), acc = 0.0;
+    for (int j = 0; j < P.n_dist; ++j) {
+        const double lw = P.dist_logw[j];
+        if (!(lw > -dinf())) continue;
+        const double sc = ds / P.dist_grid[j];
+        const double x = (P.phase_marg ? gw::ln_bessel_i0(dh * sc) : dh * sc) - hh * sc * sc / 2.0 + lw;
+        if (x > mx) { acc = acc * exp(mx - x) + 1.0; mx = x; }
+        else acc += exp(x - mx);
+    }
+    return mx + log(acc);
+}
+
 __global__ __launch_bounds__(256) void gw_finish_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
                                                         const double* __restrict__ partial, const long B, const int mode,
                                                         const int n_chunks, double* __restrict__ out) {
@@ -367,22 +385,7 @@ __global__ __launch_bounds__(256) void gw_finish_kernel(const GwDev* __restrict_
     }
     double r;
     if (P.n_dist > 0) {
-        // distance marginalisation: log sum_j w_j exp(x(d_j)); <d|h> ~ 1/d and <h|h> ~ 1/d^2 rescaled from the row's own distance
-        // (bilby/gw/likelihood/base.py: distance_marginalized_likelihood + _create_lookup_table, evaluated here instead of tabulated)
-        const double dh = P.phase_marg ? sqrt(re * re + im * im) : re;
-        const double ds = src[b].distance;
-        double mx = -dinf();
-        for (int pass = 0; pass < 2; ++pass) {
-            double acc = 0.0;
-            for (int j = 0; j < P.n_dist; ++j) {
-                const double lw = P.dist_logw[j];
-                if (!(lw > -dinf())) continue;
-                const double sc = ds / P.dist_grid[j];
-                const double x = (P.phase_marg ? gw::ln_bessel_i0(dh * sc) : dh * sc) - hh * sc * sc / 2.0 + lw;
-                if (pass == 0) mx = x > mx ? x : mx; else acc += exp(x - mx);
-            }
-            if (pass == 1) r = mx + log(acc);
-        }
+        r = gw_distance_marginalised(P, P.phase_marg ? sqrt(re * re + im * im) : re, hh, src[b].distance);
     } else if (P.phase_marg) r = gw::ln_bessel_i0(sqrt(re * re + im * im)) - hh / 2.0;      // bilby: ln_i0(abs(d_inner_h)) - optimal_snr_squared / 2
     else r = re - hh / 2.0;
     out[b] = (valid && isfinite(r)) ? r : NMMA_LOGL_FLOOR;                            // core/base.py:82, :181
@@ -427,7 +430,8 @@ __global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict_
 // Time marginalisation (bilby/gw/likelihood/base.py: calculate_snrs + time_marginalized_likelihood)
 // gw_integrand_kernel: I[b][k] = sum_ifo conj(d_k) h_k / S_k for k = 0 .. n_freq - 2 (zero outside the evaluated band), the
 //   array whose forward FFT is <d|h> as a function of the coalescence-time shift j * duration / (n_freq - 1);
-// gw_time_marg_kernel: log sum_j w_j exp(x_j) over the support of the time prior, one workgroup per sample.
+// gw_tm_fft_kernel / gw_tm_shift_kernel: its FFT, pruned to the shifts the time prior supports; gw_tm_term_kernel: the terms of the
+//   time sum, one thread per (row, shift); gw_tm_logsum_kernel: log sum_j w_j exp(x_j), one workgroup per row.
 // =======================================================================================
 template <int NIFO>
 __global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src, const long b0,
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restri
 
 // First stage of the N = GW_TM_N1 x N2 decomposition (k = N2 k1 + k2, j = j1 + GW_TM_N1 j2): one workgroup per (k2, row) gathers
 // the row's integrand at k = N2 k1 + k2, does the GW_TM_N1-point FFT over k1 in LDS (radix 2, decimation in time), applies the twiddle
-// exp(-2 pi i j1 k2 / N) and stores G[row][k2][j1].  The second stage is pruned: gw_time_marg_kernel sums over k2 only for the shifts
+// exp(-2 pi i j1 k2 / N) and stores G[row][k2][j1].  The second stage is pruned: gw_tm_shift_kernel sums over k2 only for the shifts
 // j the time prior supports (a few hundred of the 2.6e5 of config 5).
 constexpr int GW_TM_N1 = 1024;
 __global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restrict__ I, const long N, const int N2, double2* __restrict__ G) {
@@ -499,42 +503,66 @@ __global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void gw_time_marg_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
-                                                          const double2* __restrict__ G, const double* __restrict__ parts, const long b0,
-                                                          const int N2, double* __restrict__ out) {
+// Second, pruned stage: F_j = 4/T sum_k2 G[k2][j1] exp(-2 pi i j2 k2 / N2) for the shifts j the time prior supports only,
+// stored per row as (re, im) in slot j - tm_lo.
+__global__ __launch_bounds__(256) void gw_tm_shift_kernel(const GwDev* __restrict__ Pp, const double2* __restrict__ G, const long b0, const int N2,
+                                                         double2* __restrict__ Fs) {
     const GwDev& P = *Pp;
-    const long b = b0 + blockIdx.x;
+    const long n_sup = P.tm_hi - P.tm_lo;
     const double2* Gb = G + (long)blockIdx.x * N2 * GW_TM_N1;
-    const double hh = parts[3 * b + 2];
+    for (long slot = threadIdx.x; slot < n_sup; slot += 256) {
+        const long j = P.tm_lo + slot;
+        const int j1 = (int)(j & (GW_TM_N1 - 1));
+        const long j2 = j >> 10;
+        double re = 0.0, im = 0.0;
+        for (int k2 = 0; k2 < N2; ++k2) {
+            double sn, cs;
+            sincospi(-2.0 * (double)((j2 * k2) % N2) / (double)N2, &sn, &cs);
+            const double2 g = Gb[(long)k2 * GW_TM_N1 + j1];
+            re += g.x * cs - g.y * sn;
+            im += g.x * sn + g.y * cs;
+        }
+        Fs[(b0 + blockIdx.x) * n_sup + slot] = make_double2(re * P.four_over_T, im * P.four_over_T);
+    }
+}
+
+// x[b][slot] = the (distance-marginalised) log-likelihood ratio at shift slot + ln w_slot: one thread per (row, shift) -- with the
+// distance marginalised too this is the expensive step (10^4 distance nodes per pair), spread over the whole batch at once.
+__global__ __launch_bounds__(256) void gw_tm_term_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                        const double2* __restrict__ Fs, const double* __restrict__ parts, const long B,
+                                                        double* __restrict__ x) {
+    const GwDev& P = *Pp;
+    const long n_sup = P.tm_hi - P.tm_lo;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n_sup) return;
+    const long b = idx / n_sup, slot = idx - b * n_sup;
+    const double lw = P.time_logw[P.tm_lo + slot];
+    double v = -dinf();
+    if (lw > -dinf()) {
+        const double2 f = Fs[idx];
+        const double hh = parts[3 * b + 2];
+        const double dh = P.phase_marg ? sqrt(f.x * f.x + f.y * f.y) : f.x;
+        if (P.n_dist > 0) v = gw_distance_marginalised(P, dh, hh, src[b].distance) + lw;
+        else v = (P.phase_marg ? gw::ln_bessel_i0(dh) : dh) - hh / 2.0 + lw;
+    }
+    x[idx] = v;
+}
+
+// log sum over the shifts, one workgroup per row
+__global__ __launch_bounds__(256) void gw_tm_logsum_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src,
+                                                          const double* __restrict__ x, double* __restrict__ out) {
+    const GwDev& P = *Pp;
+    const long n_sup = P.tm_hi - P.tm_lo;
+    const long b = blockIdx.x;
+    const double* xb = x + b * n_sup;
     __shared__ double red[256];
-    __shared__ double xs[1024];               // x_j of the supported shifts, kept between the two passes (re-summed when there are more)
     double mx = -dinf();
     for (int pass = 0; pass < 2; ++pass) {
         double acc = 0.0, m = -dinf();
-        for (long j = P.tm_lo + threadIdx.x; j < P.tm_hi; j += 256) {
-            const double lw = P.time_logw[j];
-            if (!(lw > -dinf())) continue;
-            const long slot = j - P.tm_lo;
-            double x;
-            if (pass == 0 || slot >= 1024) {
-                // F_j = 4/T sum_k2 G[k2][j1] exp(-2 pi i j2 k2 / N2)
-                const int j1 = (int)(j & (GW_TM_N1 - 1));
-                const long j2 = j >> 10;
-                double re = 0.0, im = 0.0;
-                for (int k2 = 0; k2 < N2; ++k2) {
-                    double sn, cs;
-                    sincospi(-2.0 * (double)((j2 * k2) % N2) / (double)N2, &sn, &cs);
-                    const double2 g = Gb[(long)k2 * GW_TM_N1 + j1];
-                    re += g.x * cs - g.y * sn;
-                    im += g.x * sn + g.y * cs;
-                }
-                re *= P.four_over_T; im *= P.four_over_T;
-                x = (P.phase_marg ? gw::ln_bessel_i0(sqrt(re * re + im * im)) : re) - hh / 2.0 + lw;
-                if (pass == 0 && slot < 1024) xs[slot] = x;
-            } else {
-                x = xs[slot];
-            }
-            if (pass == 0) m = x > m ? x : m; else acc += exp(x - mx);
+        for (long slot = threadIdx.x; slot < n_sup; slot += 256) {
+            const double v = xb[slot];
+            if (!(v > -dinf())) continue;
+            if (pass == 0) m = v > m ? v : m; else acc += exp(v - mx);
         }
         red[threadIdx.x] = pass == 0 ? m : acc;
         __syncthreads();
@@ -598,6 +626,8 @@ struct nmma_gw_handle {
     int64_t tm_batch = 0, tm_parts_cap = 0;
     double2* tm_buf = nullptr;      // [2][tm_batch][n_freq - 1]: integrand | first FFT stage
     double* tm_parts = nullptr;
+    double2* tm_F = nullptr;        // [rows][shifts in the prior's support] <d|h>(t_j)
+    double* tm_x = nullptr;         // [rows][shifts] terms of the time sum
 };
 
 extern "C" {
@@ -650,6 +680,8 @@ void nmma_gw_destroy(nmma_gw_handle* h) {
     if (h->partial) (void)hipFree(h->partial);
     if (h->tm_buf) (void)hipFree(h->tm_buf);
     if (h->tm_parts) (void)hipFree(h->tm_parts);
+    if (h->tm_F) (void)hipFree(h->tm_F);
+    if (h->tm_x) (void)hipFree(h->tm_x);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -753,7 +785,6 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
     }
     P.time_logw = nullptr; P.tm_lo = 0; P.tm_hi = 0;
     if (e == hipSuccess && c->time_log_weight != nullptr) {      // time marginalisation
-        if (c->n_distance > 0) { nmma_gw_destroy(h); return fail("nmma_gw_create: time and distance marginalisation are not combined on the device path"); }
         const int64_t N = NF - 1;
         if (N % GW_TM_N1 != 0) { nmma_gw_destroy(h); return fail("nmma_gw_create: time marginalisation needs n_freq - 1 to be a multiple of 1024"); }
         int64_t lo = N, hi = 0;
@@ -828,9 +859,14 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
         if (h->tm_parts_cap < B) {
             GW_HIP(hipDeviceSynchronize());
             if (h->tm_parts) (void)hipFree(h->tm_parts);
-            h->tm_parts = nullptr; h->tm_parts_cap = 0;
-            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_parts), (size_t)std::max<int64_t>(B, 256) * 3 * sizeof(double)));
-            h->tm_parts_cap = std::max<int64_t>(B, 256);
+            if (h->tm_F) (void)hipFree(h->tm_F);
+            if (h->tm_x) (void)hipFree(h->tm_x);
+            h->tm_parts = nullptr; h->tm_F = nullptr; h->tm_x = nullptr; h->tm_parts_cap = 0;
+            const int64_t cap = std::max<int64_t>(B, 256), n_sup = P.tm_hi - P.tm_lo;
+            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_parts), (size_t)cap * 3 * sizeof(double)));
+            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_F), (size_t)cap * n_sup * sizeof(double2)));
+            GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_x), (size_t)cap * n_sup * sizeof(double)));
+            h->tm_parts_cap = cap;
         }
         const int N2 = (int)(N / GW_TM_N1);
         if (h->tm_buf == nullptr) {
@@ -852,8 +888,12 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
                 default: hipLaunchKernelGGL(gw_integrand_kernel<4>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
             }
             hipLaunchKernelGGL(gw_tm_fft_kernel, dim3((unsigned)N2, (unsigned)nb), dim3(256), 0, s, integrand, (long)N, N2, stage1);
-            hipLaunchKernelGGL(gw_time_marg_kernel, dim3((unsigned)nb), dim3(256), 0, s, h->dev_d, h->src, stage1, h->tm_parts, (long)b0, N2, out_dev);
+            hipLaunchKernelGGL(gw_tm_shift_kernel, dim3((unsigned)nb), dim3(256), 0, s, h->dev_d, stage1, (long)b0, N2, h->tm_F);
         }
+        const int64_t pairs = B * (P.tm_hi - P.tm_lo);
+        hipLaunchKernelGGL(gw_tm_term_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->tm_F, h->tm_parts, (long)B,
+                           h->tm_x);
+        hipLaunchKernelGGL(gw_tm_logsum_kernel, dim3((unsigned)B), dim3(256), 0, s, h->dev_d, h->src, h->tm_x, out_dev);
     } else {
         hipLaunchKernelGGL(gw_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, h->dev_d, h->src, h->partial, (long)B, mode,
                            P.n_chunks, out_dev);

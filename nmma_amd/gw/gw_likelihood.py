@@ -226,8 +226,6 @@ class GWEngine:
                 raise L.NMMAHipError(f"time_marginalization needs ln(prior x step) on the {n_freq - 1} time shifts of the segment")
             if "geocent_time" in names:
                 raise L.NMMAHipError("geocent_time is marginalised: it must not be a sampled column")
-            if distance_marginalization is not None:
-                raise L.NMMAHipError("time and distance marginalisation are not combined on the device path")
             cfg.time_log_weight = tlw.ctypes.data_as(L._pd)
         keep = (data, psd, mask, tensor, vertex, dist, tlw)        # alive until create returns (the library copies)
         h = C.c_void_p()
@@ -364,8 +362,6 @@ class GravitationalWaveTransient:
         self.distance_marginalization = bool(distance_marginalization)
         self._distance, self._time_logw = None, None
         if self.time_marginalization:
-            if self.distance_marginalization:
-                raise L.NMMAHipError("time and distance marginalisation are not combined on the device path")
             try:
                 ifo = self.interferometers[0]
                 self._time_logw = time_marginalization_weights(priors["geocent_time"], ifo.strain_data.start_time,
@@ -458,10 +454,10 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
 
     Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` and
     ``distance_marginalization`` on or off (the distance sum evaluated per row instead of bilby's lookup table) or
-    ``time_marginalization`` (FFT of the per-bin integrand over the coalescence-time shifts, ``jitter_time=False``), sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
+    ``time_marginalization`` (FFT of the per-bin integrand over the coalescence-time shifts, ``jitter_time=False``), in any
+    combination, sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
     Refused at construction (never approximated): the ROQ / relative-binning / multibanded likelihood classes (they need
-    bilby's basis files and fiducial waveforms), time marginalisation with ``jitter_time`` or together with distance
-    marginalisation, other reference frames."""
+    bilby's basis files and fiducial waveforms), time marginalisation with ``jitter_time``, other reference frames."""
 
     def __init__(self, priors, interferometers, waveform_generator, gw_likelihood_type="GravitationalWaveTransient",
                  time_marginalization=False, distance_marginalization=False, phase_marginalization=False,

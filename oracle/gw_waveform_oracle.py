@@ -614,7 +614,21 @@ def log_likelihood_ratio(params, ifos, f_ref, f_min_waveform, phase_marginalizat
         from scipy.special import logsumexp
         logw = np.asarray(time_marginalization, dtype=np.float64)
         keep = np.isfinite(logw)
-        if phase_marginalization:
+        if distance_marginalization is not None:
+            # bilby: log_l_tc_array = distance_marginalized_likelihood(d_inner_h_tc_array, h_inner_h) -- the distance sum per time shift
+            grid, dlogw = (np.asarray(a, dtype=np.float64) for a in distance_marginalization)
+            dkeep = np.isfinite(dlogw)
+            scale = float(params["luminosity_distance"]) / grid[dkeep]
+            x = np.empty(int(keep.sum()))
+            for n, v in enumerate(tc_array[keep]):
+                if phase_marginalization:
+                    from scipy.special import ive
+                    arg = abs(v) * scale
+                    xd = np.log(ive(0, arg)) + arg - opt * scale ** 2 / 2.0
+                else:
+                    xd = v.real * scale - opt * scale ** 2 / 2.0
+                x[n] = logsumexp(xd + dlogw[dkeep])
+        elif phase_marginalization:
             x = np.array([ln_i0(abs(v)) for v in tc_array[keep]]) - opt / 2.0
         else:
             x = tc_array[keep].real - opt / 2.0

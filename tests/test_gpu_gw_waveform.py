@@ -63,16 +63,17 @@ def test_projected_strain_matches_oracle(approximant, torch_cuda):
 
 
 @pytest.mark.parametrize("variant", ["bns", "phase_marginalised", "distance_marginalised", "distance_phase_marginalised",
-                                     "time_marginalised", "time_phase_marginalised", "component_masses_cos", "two_ifos", "one_ifo_bbh"])
+                                     "time_marginalised", "time_phase_marginalised", "time_distance_phase_marginalised",
+                                     "component_masses_cos", "two_ifos", "one_ifo_bbh"])
 def test_loglike_ratio_matches_oracle(variant, torch_cuda):
     from nmma_amd.gw import GWEngine
     from nmma_amd.gw.gw_likelihood import distance_marginalization_grid, time_marginalization_weights
     from tests.helpers import PowerLawPrior, UniformPrior
     kw, names, fixed, pm, dm, tm = {}, list(syn.GW_NAMES), {}, False, None, None
-    if variant in ("phase_marginalised", "distance_phase_marginalised", "time_phase_marginalised"):
+    if variant in ("phase_marginalised", "distance_phase_marginalised", "time_phase_marginalised", "time_distance_phase_marginalised"):
         names.remove("phase")
         pm = True
-    if variant in ("distance_marginalised", "distance_phase_marginalised"):
+    if variant in ("distance_marginalised", "distance_phase_marginalised", "time_distance_phase_marginalised"):
         # bilby's usual prior, uniform in volume; the waveform is evaluated at bilby's reference distance prior.rescale(0.5)
         grid, logw, ref = distance_marginalization_grid(PowerLawPrior(2.0, 10.0, 250.0), n=2000)
         names.remove("luminosity_distance")
@@ -86,12 +87,12 @@ def test_loglike_ratio_matches_oracle(variant, torch_cuda):
         names = ["mass_1", "mass_2", "chi_1", "chi_2", "luminosity_distance", "theta_jn", "phase", "ra", "dec", "psi", "geocent_time"]
     case = make_case(**kw)
     centre = dict(case["injection"])
-    if variant in ("time_marginalised", "time_phase_marginalised"):
+    if variant in ("time_marginalised", "time_phase_marginalised", "time_distance_phase_marginalised"):
         # a uniform prior of +-0.1 s around the trigger; the waveform is evaluated with geocent_time = segment start, as bilby does
         t0 = case["injection"]["geocent_time"]
         tm = time_marginalization_weights(UniformPrior(t0 - 0.1, t0 + 0.1), case["start_time"], case["duration"], len(case["frequency_array"]))
         names.remove("geocent_time")
-        fixed = dict(geocent_time=case["start_time"])
+        fixed = dict(fixed, geocent_time=case["start_time"])
     if variant == "component_masses_cos":
         from oracle import gw_waveform_oracle as gwo
         m1, m2 = gwo.component_masses(centre["chirp_mass"], centre["mass_ratio"])
