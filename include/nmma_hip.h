@@ -296,6 +296,12 @@ typedef struct nmma_gw_config {
      * time_log_weight[j] = ln(prior(t_j) * delta_t) (-inf outside the prior's support).  With n_distance > 0 as well, x_j is the
      * distance-marginalised value at F_j (bilby's order: the distance sum inside the time sum). */
     const double* time_log_weight;      /* [n_freq - 1] or NULL */
+    /* bilby's jitter_time: a sampled offset time_jitter in [-delta_t/2, delta_t/2] is added to the waveform's geocent_time and to
+     * the times the prior is evaluated at.  On the device the weight of shift j becomes that of the nearest node with a finite
+     * weight if time_prior_minimum <= t_j + jitter <= time_prior_maximum and zero otherwise (exact for a uniform time prior).
+     * col < 0 and value 0: no jitter. */
+    nmma_slot time_jitter;
+    double time_prior_minimum, time_prior_maximum;
 } nmma_gw_config;
 
 typedef struct nmma_gw_handle nmma_gw_handle;

@@ -96,6 +96,7 @@ class GwConfig(C.Structure):
         ("geocent_time", Slot),
         ("n_distance", C.c_int32), ("pad_distance", C.c_int32), ("distance_grid", _pd), ("distance_log_weight", _pd),
         ("time_log_weight", _pd),
+        ("time_jitter", Slot), ("time_prior_minimum", C.c_double), ("time_prior_maximum", C.c_double),
     ]
 
 

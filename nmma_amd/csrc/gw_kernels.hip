@@ -135,7 +135,10 @@ struct GwDev {
     const double* dist_grid;       // [n_dist] Mpc
     const double* dist_logw;       // [n_dist] ln(prior(d_j) delta_d)
     const double* time_logw;       // time marginalisation: [n_freq - 1] ln(prior(t_j) delta_t), or null
-    int64_t tm_lo, tm_hi;          // first / one past the last time index with a finite weight
+    int64_t tm_lo, tm_hi;          // first / one past the last time index that can carry weight (one node of slack with jitter)
+    int32_t tm_jitter, pad_tm;     // bilby's jitter_time: per-row weights from the prior's bounds
+    double tm_min, tm_max, tm_dt;  // time prior bounds [GPS s], spacing of the shifts
+    nmma_slot time_jitter;
     int64_t n_bins;                // bins k0 .. k0 + n_bins - 1 of the frequency array
     int64_t k0, n_freq;
     int32_t n_chunks, n_dim;       // chunks of GWL_CHUNK bins
@@ -169,10 +172,12 @@ __global__ __launch_bounds__(64) void gw_source_kernel(const GwDev* __restrict__
     q.theta_jn = apply_slot(P.theta_jn, row); q.phase = apply_slot(P.phase, row);
     q.ra = apply_slot(P.ra, row); q.dec = apply_slot(P.dec, row); q.psi = apply_slot(P.psi, row);
     q.geocent_time = apply_slot(P.geocent_time, row);
+    if (P.tm_jitter) q.geocent_time += apply_slot(P.time_jitter, row);       // bilby: parameters['geocent_time'] += parameters['time_jitter']
     gw::GwSource S;
     for (int i = 0; i < gw::kMaxIfo; ++i) { S.k_re[i] = 0.0; S.k_im[i] = 0.0; S.k_sq[i] = 0.0; S.dt[i] = 0.0; S.rs_re[i] = 1.0; S.rs_im[i] = 0.0; }
     gw::setup_source(q, P.f_ref, P.tidal != 0, S);
     S.distance = q.luminosity_distance;
+    S.jitter = P.tm_jitter ? apply_slot(P.time_jitter, row) : 0.0;
     if (S.valid != 0.0)
         for (int i = 0; i < P.n_ifo; ++i) gw::project_source(q, P.det[i], i, P.start_time, P.gmst_ref_time, P.gmst_ref, P.gmst_rate, stride_hz, S);
     src[b] = S;
@@ -536,7 +541,19 @@ __global__ __launch_bounds__(256) void gw_tm_term_kernel(const GwDev* __restrict
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n_sup) return;
     const long b = idx / n_sup, slot = idx - b * n_sup;
-    const double lw = P.time_logw[P.tm_lo + slot];
+    double lw = P.time_logw[P.tm_lo + slot];
+    if (P.tm_jitter) {
+        // bilby: time_prior_array = prior.prob(times + time_jitter) * delta_tc -- the node's own weight, or its neighbour's where the
+        // shifted time enters the prior's support, and nothing where it leaves it
+        const long j = P.tm_lo + slot;
+        const double t = P.start_time + (double)j * P.tm_dt + src[b].jitter;
+        if (!(lw > -dinf())) {
+            const long N = P.n_freq - 1;
+            const double ln = j > 0 ? P.time_logw[j - 1] : -dinf(), lp = j + 1 < N ? P.time_logw[j + 1] : -dinf();
+            lw = ln > -dinf() ? ln : lp;
+        }
+        if (!(t >= P.tm_min && t <= P.tm_max)) lw = -dinf();
+    }
     double v = -dinf();
     if (lw > -dinf()) {
         const double2 f = Fs[idx];
@@ -783,7 +800,8 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
         if (e == hipSuccess) { P.dist_grid = reinterpret_cast<const double*>(p); e = up(c->distance_log_weight, (size_t)c->n_distance * 8, &p); }
         if (e == hipSuccess) { P.dist_logw = reinterpret_cast<const double*>(p); P.n_dist = c->n_distance; }
     }
-    P.time_logw = nullptr; P.tm_lo = 0; P.tm_hi = 0;
+    P.time_logw = nullptr; P.tm_lo = 0; P.tm_hi = 0; P.tm_jitter = 0; P.tm_min = 0.0; P.tm_max = 0.0; P.tm_dt = 0.0;
+    P.time_jitter.col = -1; P.time_jitter.op = 0; P.time_jitter.value = 0.0;
     if (e == hipSuccess && c->time_log_weight != nullptr) {      // time marginalisation
         const int64_t N = NF - 1;
         if (N % GW_TM_N1 != 0) { nmma_gw_destroy(h); return fail("nmma_gw_create: time marginalisation needs n_freq - 1 to be a multiple of 1024"); }
@@ -791,6 +809,13 @@ int32_t nmma_gw_create(const nmma_gw_config* c, nmma_gw_handle** out) {
         for (int64_t j = 0; j < N; ++j)
             if (c->time_log_weight[j] > -HUGE_VAL) { lo = std::min(lo, j); hi = std::max(hi, j + 1); }
         if (hi <= lo) { nmma_gw_destroy(h); return fail("nmma_gw_create: the time prior has no support inside the data segment"); }
+        P.tm_jitter = (c->time_jitter.col >= 0 || c->time_jitter.value != 0.0) ? 1 : 0;
+        P.time_jitter = c->time_jitter;
+        P.tm_min = c->time_prior_minimum; P.tm_max = c->time_prior_maximum; P.tm_dt = c->duration / (double)N;
+        if (P.tm_jitter) {
+            if (c->time_jitter.col >= c->n_dim || !(P.tm_max > P.tm_min)) { nmma_gw_destroy(h); return fail("nmma_gw_create: bad time_jitter slot or time prior bounds"); }
+            lo = std::max<int64_t>(0, lo - 1); hi = std::min<int64_t>(N, hi + 1);
+        }
         e = up(c->time_log_weight, (size_t)N * 8, &p);
         if (e == hipSuccess) { P.time_logw = reinterpret_cast<const double*>(p); P.tm_lo = lo; P.tm_hi = hi; }
     }

@@ -158,6 +158,7 @@ struct GwParams {
 struct GwSource {
     double valid;                 // 0: a non-finite or unphysical input -> the sample gets the floor
     double distance;              // Mpc: the luminosity distance the amplitude was scaled with (distance marginalisation rescales from it)
+    double jitter;                // s: bilby's time_jitter of the row (time marginalisation with jitter_time), else 0
     // ---- amplitude: A(f) = amp_scale * f^(-7/6) * (bracket(f) + tidal bracket) * taper
     double amp_scale;
     double fa1, fa3;              // Hz: inspiral | intermediate | merger-ringdown boundaries of the amplitude

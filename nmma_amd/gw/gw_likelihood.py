@@ -139,7 +139,8 @@ class GWEngine:
     ``chi_1`` / ``chi_2``; inclination: ``theta_jn`` or ``cos_theta_jn``.  No CPU fallback."""
 
     def __init__(self, interferometers, parameter_names, fixed=None, waveform_arguments=None, phase_marginalization=False,
-                 gmst_reference_time=None, device=0, distance_marginalization=None, time_marginalization=None):
+                 gmst_reference_time=None, device=0, distance_marginalization=None, time_marginalization=None,
+                 time_jitter_bounds=None):
         import torch  # noqa: F401  (device buffers / stream)
         self._handle = None
         self._lib = L.load_library()
@@ -227,6 +228,13 @@ class GWEngine:
             if "geocent_time" in names:
                 raise L.NMMAHipError("geocent_time is marginalised: it must not be a sampled column")
             cfg.time_log_weight = tlw.ctypes.data_as(L._pd)
+            cfg.time_jitter = L.Slot.constant(0.0)
+            if time_jitter_bounds is not None:
+                # bilby's jitter_time: the sampled time_jitter moves the waveform and the times the prior is evaluated at
+                if "time_jitter" not in names:
+                    raise L.NMMAHipError("jitter_time needs the sampled column 'time_jitter' (bilby adds its Uniform(-dt/2, dt/2) prior)")
+                cfg.time_jitter = L.Slot.column(names.index("time_jitter"))
+                cfg.time_prior_minimum, cfg.time_prior_maximum = float(time_jitter_bounds[0]), float(time_jitter_bounds[1])
         keep = (data, psd, mask, tensor, vertex, dist, tlw)        # alive until create returns (the library copies)
         h = C.c_void_p()
         L.check(self._lib.nmma_gw_create(C.byref(cfg), C.byref(h)), "nmma_gw_create")
@@ -336,6 +344,21 @@ def distance_marginalization_grid(prior, n=10000):
     return grid, logw, ref
 
 
+class _UniformLike:
+    """The prior bilby adds for ``time_jitter`` when no bilby is around to supply ``bilby.core.prior.Uniform``: minimum, maximum,
+    ``prob`` and ``rescale`` with bilby's meaning (enough for the batched prior transform and the samplers' bookkeeping)."""
+
+    def __init__(self, minimum, maximum, name="time_jitter"):
+        self.minimum, self.maximum, self.name, self.latex_label = float(minimum), float(maximum), name, name
+
+    def prob(self, val):
+        val = np.asarray(val, dtype=np.float64)
+        return np.where((val >= self.minimum) & (val <= self.maximum), 1.0 / (self.maximum - self.minimum), 0.0)
+
+    def rescale(self, val):
+        return self.minimum + np.asarray(val) * (self.maximum - self.minimum)
+
+
 def time_marginalization_weights(prior, start_time, duration, n_freq):
     """What bilby's ``_setup_time_marginalization`` tabulates from the ``geocent_time`` prior (bilby/gw/likelihood/base.py): the
     coalescence times the FFT of the integrand resolves, ``delta_tc = duration / (n_freq - 1)`` (= 2 / sampling_frequency) apart,
@@ -356,16 +379,23 @@ class GravitationalWaveTransient:
     lazily per process and dropped on pickling, like the EM likelihood's."""
 
     def __init__(self, interferometers, waveform_generator, priors=None, phase_marginalization=False, device=0,
-                 distance_marginalization=False, time_marginalization=False):
+                 distance_marginalization=False, time_marginalization=False, jitter_time=False):
         self.interferometers, self.waveform_generator, self.priors = list(interferometers), waveform_generator, priors
+        self.jitter_time = bool(jitter_time) and bool(time_marginalization)
         self.phase_marginalization, self.time_marginalization = bool(phase_marginalization), bool(time_marginalization)
         self.distance_marginalization = bool(distance_marginalization)
-        self._distance, self._time_logw = None, None
+        self._distance, self._time_logw, self._time_bounds = None, None, None
         if self.time_marginalization:
             try:
                 ifo = self.interferometers[0]
-                self._time_logw = time_marginalization_weights(priors["geocent_time"], ifo.strain_data.start_time,
+                prior = priors["geocent_time"]
+                self._time_logw = time_marginalization_weights(prior, ifo.strain_data.start_time,
                                                                ifo.strain_data.duration, len(ifo.frequency_array))
+                self._time_bounds = (float(prior.minimum), float(prior.maximum)) if self.jitter_time else None
+                if self.jitter_time and "time_jitter" not in priors:
+                    # bilby/gw/likelihood/base.py: priors['time_jitter'] = Uniform(-delta_tc / 2, delta_tc / 2)
+                    half = 0.5 * float(ifo.strain_data.duration) / (len(ifo.frequency_array) - 1)
+                    priors["time_jitter"] = _UniformLike(-half, half)
             except (KeyError, TypeError, AttributeError) as exc:
                 raise L.NMMAHipError("time marginalisation needs priors['geocent_time'] with prob()") from exc
         if self.distance_marginalization:
@@ -414,6 +444,7 @@ class GravitationalWaveTransient:
                                     phase_marginalization=self.phase_marginalization, device=self.device,
                                     distance_marginalization=self._distance[:2] if self.distance_marginalization else None,
                                     time_marginalization=self._time_logw,
+                                    time_jitter_bounds=self._time_bounds if self.time_marginalization else None,
                                     gmst_reference_time=self._gmst_reference_time())
             self._names = names
         return self._engine
@@ -443,7 +474,7 @@ class GravitationalWaveTransient:
         return self.log_likelihood_ratio(parameters) + self._noise
 
 
-_GW_KEYS = set(GW_PARAMETERS) | {"chirp_mass", "mass_ratio", "mass_1", "mass_2", "cos_theta_jn"}
+_GW_KEYS = set(GW_PARAMETERS) | {"chirp_mass", "mass_ratio", "mass_1", "mass_2", "cos_theta_jn", "time_jitter"}
 
 
 class GravitationalWaveTransientLikelihood(NMMALikelihood):
@@ -454,10 +485,10 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
 
     Built on the device path: ``gw_likelihood_type='GravitationalWaveTransient'`` with ``phase_marginalization`` and
     ``distance_marginalization`` on or off (the distance sum evaluated per row instead of bilby's lookup table) or
-    ``time_marginalization`` (FFT of the per-bin integrand over the coalescence-time shifts, ``jitter_time=False``), in any
-    combination, sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
+    ``time_marginalization`` (FFT of the per-bin integrand over the coalescence-time shifts; with ``jitter_time`` the sampled
+    ``time_jitter`` column, whose prior is added as bilby does), in any combination, sky reference frame, geocentre time reference, approximants ``IMRPhenomD_NRTidalv2`` / ``IMRPhenomD`` with aligned spins.
     Refused at construction (never approximated): the ROQ / relative-binning / multibanded likelihood classes (they need
-    bilby's basis files and fiducial waveforms), time marginalisation with ``jitter_time``, other reference frames."""
+    bilby's basis files and fiducial waveforms), other reference frames."""
 
     def __init__(self, priors, interferometers, waveform_generator, gw_likelihood_type="GravitationalWaveTransient",
                  time_marginalization=False, distance_marginalization=False, phase_marginalization=False,
@@ -471,8 +502,6 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
             raise ValueError("Unknown GW Likelihood class {}")                            # :205 (sic)
         if gw_likelihood_type != "GravitationalWaveTransient":
             raise L.NMMAHipError(f"{gw_likelihood_type} is not built on the device path (it needs bilby's basis / fiducial data)")
-        if time_marginalization and jitter_time:
-            raise L.NMMAHipError("time marginalisation on the device path takes jitter_time=False (no per-call random time offset)")
         if distance_marginalization and distance_marginalization_lookup_table is not None:
             pass        # (bilby caches its (d_inner_h, h_inner_h) table there; the device evaluates the sum per row and needs none)
         if reference_frame != "sky" or time_reference not in ("geocent", "geocenter"):
@@ -480,7 +509,7 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
         sub_model = GravitationalWaveTransient(interferometers, waveform_generator, priors=priors,
                                                phase_marginalization=phase_marginalization, device=device,
                                                distance_marginalization=distance_marginalization,
-                                               time_marginalization=time_marginalization)
+                                               time_marginalization=time_marginalization, jitter_time=jitter_time)
         super().__init__(sub_model, priors)
         from ..core import conversion
         name = getattr(waveform_generator.frequency_domain_source_model, "__name__", "")

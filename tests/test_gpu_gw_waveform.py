@@ -174,7 +174,7 @@ def test_unsupported_configurations_are_refused(torch_cuda):
         GWEngine(case["ifos"], ["chirp_mass"], waveform_arguments=case["waveform_arguments"])
     wg = WaveformGenerator(case["duration"], 2048.0, waveform_arguments=case["waveform_arguments"])
     priors = {n: None for n in syn.GW_NAMES}
-    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True),      # (jitter_time defaults to True; no distance prior)
+    for kw in (dict(time_marginalization=True), dict(distance_marginalization=True),      # (no time / distance prior to marginalise over)
                dict(gw_likelihood_type="ROQGravitationalWaveTransient"), dict(reference_frame="H1L1")):
         with pytest.raises(L.NMMAHipError):
             GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, **kw)
@@ -217,7 +217,7 @@ def test_reference_constructor_with_distance_and_phase_marginalisation(torch_cud
 def test_reference_constructor_with_time_marginalisation(torch_cuda):
     """``GravitationalWaveTransientLikelihood(..., time_marginalization=True, jitter_time=False)`` on a longer segment (16 384 time
     shifts: a 1024 x 16 decomposition of the transform, whose second stage is evaluated only on the 400 shifts the prior supports)
-    against the oracle's numpy FFT; ``jitter_time`` (bilby's per-call random offset) is refused."""
+    against the oracle's numpy FFT, without and with bilby's ``jitter_time``."""
     torch = torch_cuda
     from nmma_amd import _lib as L
     from nmma_amd.gw import GravitationalWaveTransientLikelihood, WaveformGenerator
@@ -230,8 +230,6 @@ def test_reference_constructor_with_time_marginalisation(torch_cuda):
     priors["geocent_time"] = UniformPrior(t0 - 0.05, t0 + 0.05)
     priors["phase"] = SimplePrior(0.0, 2 * np.pi)
     wg = WaveformGenerator(case["duration"], 4096.0, waveform_arguments=case["waveform_arguments"])
-    with pytest.raises(L.NMMAHipError):
-        GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, time_marginalization=True)          # jitter_time defaults to True
     gw = GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, time_marginalization=True, phase_marginalization=True,
                                               jitter_time=False)
     _, theta = syn.draw_gw_theta(43, 6, centre=case["injection"], names=names)
@@ -242,6 +240,26 @@ def test_reference_constructor_with_time_marginalisation(torch_cuda):
                                 time_marginalization=logw) + gw.noise_log_likelihood()
     assert _rel(got, want).max() <= GW_RTOL
     assert want.max() - gw.noise_log_likelihood() > 10.0        # the prior window does hold the signal
+    # jitter_time (the reference constructor's default): bilby adds a Uniform(-dt/2, dt/2) prior for time_jitter, shifts the waveform's
+    # geocent_time by the sampled value and evaluates the time prior on the shifted times
+    gwj = GravitationalWaveTransientLikelihood(priors, case["ifos"], wg, time_marginalization=True, phase_marginalization=True)
+    dt = case["duration"] / 16384
+    assert abs(priors["time_jitter"].minimum + dt / 2) < 1e-15 and abs(priors["time_jitter"].maximum - dt / 2) < 1e-15
+    with pytest.raises(L.NMMAHipError):
+        gwj.log_likelihood_batch(torch.as_tensor(theta, device="cuda:0"), names)                      # no time_jitter column
+    jit = np.random.default_rng(3).uniform(-dt / 2, dt / 2, len(theta))
+    jit[0], jit[1] = -dt / 2 * 0.999, dt / 2 * 0.999
+    thj = np.c_[theta, jit]
+    gotj = gwj.log_likelihood_batch(torch.as_tensor(thj, device="cuda:0"), names + ["time_jitter"]).cpu().numpy()
+    times = case["start_time"] + dt * np.arange(16384)
+    wantj = np.empty(len(theta))
+    for i in range(len(theta)):
+        with np.errstate(divide="ignore"):
+            lw = np.log(priors["geocent_time"].prob(times + jit[i]) * dt)
+        wantj[i] = oracle_loglike_ratio(case, names, theta[i:i + 1], dict(geocent_time=case["start_time"] + jit[i]),
+                                        phase_marginalization=True, time_marginalization=lw)[0] + gw.noise_log_likelihood()
+    assert _rel(gotj, wantj).max() <= GW_RTOL
+    assert np.abs(gotj - got).max() > 1e-6 * np.abs(got).max() * 1e-3        # the jitter does move the value
 
 
 def test_reference_shaped_likelihood_and_joint_sum(torch_cuda):
