@@ -24,6 +24,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 t
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw_fused -- python3 tools/perf_gw_fused.py --batch 16384 --reps 5 > $o/stats_gw_fused.log 2>&1
 python3 tools/perf_gw_fused.py --batch 16384 --reps 5 --pm > $o/gw_fused_pm.log 2>&1
 python3 tools/perf_gw_fused.py --batch 2048 --reps 5 > $o/gw_fused_2048.log 2>&1
+# the marginalised forms of the GW likelihood at config 5's shape: distance + phase, time, all three
+python3 tools/perf_gw_fused.py --batch 16384 --reps 3 --dm --pm > $o/gw_fused_dm_pm.log 2>&1
+python3 tools/perf_gw_fused.py --batch 16384 --reps 3 --tm > $o/gw_fused_tm.log 2>&1
+python3 tools/perf_gw_fused.py --batch 16384 --reps 1 --tm --dm --pm > $o/gw_fused_tm_dm_pm.log 2>&1
 bash tools/pmc_gw.sh $tag > $o/pmc_gw.log 2>&1
 bash tools/pmc_c4.sh $tag > $o/pmc_c4.log 2>&1
 # the real AT2017gfo photometry (9 filters, CLI grid, sampled em_syserr)
