@@ -636,3 +636,42 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, grid, torch_cuda, mon
     for n in (1, 33, 700, 4096):
         assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), got[:n]), n
     eng.close()
+
+
+@pytest.mark.parametrize("ext", ["linear", "p92"])
+@pytest.mark.parametrize("grid", ["svd", "cli", "log"])
+def test_dense_lean_task_with_extinction_and_sampled_systematic(grid, ext, torch_cuda, monkeypatch):
+    """The dense task with everything it can carry at once -- a sampled E(B-V) under either extinction law, a sampled em_syserr,
+    an upper limit, 60 or 130 points per band -- on all three kinds of sample grid, against the oracle and against the row form."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind", "Ebv", "em_syserr"]
+    # (the dense task is taken once a sample reconstructs more rows than the sample grid has nodes: 211 on the SVD grid)
+    case = cases._base(seed=9100, filters=["g", "r", "i", "z", "y"], counts=130 if grid == "svd" else 60, batch=48, names=names,
+                       upper_limit_filter="i")
+    case["systematics"] = dict(mode="param", name="em_syserr")
+    if ext == "linear":
+        case["ebv_coeff"] = {f: c for f, c in zip(case["model_filters"], (3.3, 2.3, 1.7, 1.3, 1.1))}
+    else:
+        case["filter_nu0"] = dict(zip(case["model_filters"], [2.99792458e14 / x for x in (0.48, 0.62, 0.75, 0.87, 0.96)]))
+    case["theta"][:2, names.index("Ebv")] = 0.0
+    if grid == "cli":
+        case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    elif grid == "log":
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    lds_dense = eng.last_launch_geometry()["lds_bytes"]
+    eng.close()
+    monkeypatch.setenv("NMMA_EM_NO_DENSE", "1")
+    eng = engine_from_case(case)
+    rows = eng.loglike(th).cpu().numpy()
+    assert eng.last_launch_geometry()["lds_bytes"] != lds_dense, "dense task not engaged"
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor) and np.array_equal(rows == FLOOR, floor) and (~floor).sum() > 30
+    assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    assert rel_err(got[~floor], rows[~floor]).max() <= 1e-9
