@@ -112,6 +112,7 @@ struct EmDev {
     const int32_t* sys_nidx;  // [N]  node bracket per datum (-1: left of first, K-1: at/after last)
     const double* sys_ndx;    // [N]  node spacing
     const double* sys_noff;   // [N]  t - node time
+    const double* sys_node_t; // [n_sys_slots] node times (NMMA_SYS_NODES groups; the finite mask on sampled node values)
     const int32_t* d_item;    // [N] first work item of each datum's observed filter (em_lc_loglike's flat pass over the photometry)
     // Item-staged photometry (lean task with so much photometry that staging ALL of it leaves room for one ring slot only,
     // BASELINE config 4): LDS then holds the epochs of all points (stage P) and each ring slot the {t, m, 1/sigma, ln sigma}

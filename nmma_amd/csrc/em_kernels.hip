@@ -763,10 +763,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 } else if (vwave == 2) {
                     for (int p = 0; p < P.NP; ++p) chk += apply_slot(P.model_param[p], row);
                 } else {
-                    for (int q = 0; q < P.n_sys_slots; ++q) {
-                        const double v = apply_slot(P.sys_slots[q], row);
-                        chk += v;
-                        if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + lane] = v;   // sysv[slot][sample]
+                    // (sampled time nodes are not "inputs that must be finite": autocomplete_data masks them, em/utils.py:634-645)
+                    for (int o = 0; o < P.O; ++o) {
+                        const int q0 = P.sys_off[o], q1 = P.sys_off[o + 1];
+                        const bool nodes = P.sys_kind[o] == NMMA_SYS_NODES;
+                        bool odd = false;
+                        for (int q = q0; q < q1; ++q) {
+                            const double v = apply_slot(P.sys_slots[q], row);
+                            if (nodes) odd = odd || !(v - v == 0.0); else chk += v;
+                            if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + lane] = v;   // sysv[slot][sample]
+                        }
+                        if constexpr (FAST)
+                            if (nodes && odd) repair_nodes(reinterpret_cast<double*>(smem + L.epar) + q0 * TS + lane, TS, P.sys_node_t + q0, q1 - q0);
                     }
                     bad[lane] = 0;
 
@@ -779,10 +787,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             const double* row = theta + b * ld;
             double chk;
             sample_scalars(P, row, praw + vt * 8, scal + vt * 8, chk);
-            for (int q = 0; q < P.n_sys_slots; ++q) {
-                const double v = apply_slot(P.sys_slots[q], row);
-                chk += v;
-                if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
+            for (int o = 0; o < P.O; ++o) {
+                const int q0 = P.sys_off[o], q1 = P.sys_off[o + 1];
+                const bool nodes = P.sys_kind[o] == NMMA_SYS_NODES;
+                bool odd = false;
+                for (int q = q0; q < q1; ++q) {
+                    const double v = apply_slot(P.sys_slots[q], row);
+                    if (nodes) odd = odd || !(v - v == 0.0); else chk += v;
+                    if constexpr (FAST) reinterpret_cast<double*>(smem + L.epar)[q * TS + vt] = v;
+                }
+                if constexpr (FAST)
+                    if (nodes && odd) repair_nodes(reinterpret_cast<double*>(smem + L.epar) + q0 * TS + vt, TS, P.sys_node_t + q0, q1 - q0);
             }
             if constexpr (LEANX) fill_ext(vt, scal[vt * 8 + S_EBV]);
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
@@ -1035,6 +1050,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                                 const double sl2 = (v1 - v0) / P.sys_ndx[di];
                                 e = sl2 * P.sys_noff[di] + v0;
                             }
+                            // (a non-finite node value: autocomplete_data's finite mask, em/utils.py:634-645)
+                            if (!(e - e == 0.0)) e = masked_nodes_at(sv, P.sys_node_t + P.sys_off[o], K, P.dt[di], row);
                         }
                         sig = sqrt(sd * sd + e * e);
                         lsig = log(sig);
@@ -2460,7 +2477,9 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         double chk;
         if (cosmo_lds) sample_scalars(P, row, praw, scal, chk, dgl, zgl);
         else sample_scalars(P, row, praw, scal, chk);
-        for (int q = 0; q < P.n_sys_slots; ++q) chk += apply_slot(P.sys_slots[q], row);
+        for (int o = 0; o < P.O; ++o)         // (sampled time nodes may be non-finite: autocomplete_data masks them)
+            if (P.sys_kind[o] != NMMA_SYS_NODES)
+                for (int q = P.sys_off[o]; q < P.sys_off[o + 1]; ++q) chk += apply_slot(P.sys_slots[q], row);
         scal[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2536,6 +2555,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
                     const double v0 = apply_slot(sv[ni], row), v1 = apply_slot(sv[ni + 1], row);
                     e = ((v1 - v0) / P.sys_ndx[di]) * P.sys_noff[di] + v0;
                 }
+                if (!(e - e == 0.0)) e = masked_nodes_at(sv, P.sys_node_t + P.sys_off[o], K, P.dt[di], row);      // (finite mask on the nodes)
             }
             sig = sqrt(sd * sd + e * e);
             lsig = log(sig);

@@ -62,6 +62,59 @@ NM_HD double apply_slot(const nmma_slot& s, RowPtr row) {
 }
 
 // ---------------------------------------------------------------------------
+// autocomplete_data's finite mask on a filter group's SAMPLED node values (em/utils.py:634-645 via systematics.py:288-291,
+// extrapolate = "constant"): non-finite nodes are dropped, np.interp runs over the rest with constant ends, fewer than two finite
+// nodes give ref_value = +inf everywhere.
+//   repair_nodes: in place on v[0], v[stride], ... -- a dropped node takes the value the interpolant through its finite neighbours
+//     has at its time (the constant end value beyond the first / last finite node), which leaves that interpolant unchanged;
+//   masked_nodes_at: the interpolant's value at time t straight from the nodes (the paths that read theta per datum).
+// Both are cold: a bounded prior never produces the input.
+// ---------------------------------------------------------------------------
+NM_HD_COLD void repair_nodes(double* v, const long stride, const double* xn, const int n) {
+    int nfin = 0;
+    for (int j = 0; j < n; ++j) nfin += (v[j * stride] - v[j * stride] == 0.0) ? 1 : 0;
+    if (nfin == n) return;
+    // (fewer than two finite nodes: sigma_sys = +inf for every datum -- written as a huge finite value so that the consumers' node
+    //  arithmetic, (v1 - v0) / dx * off + v0, stays finite; sigma_tot^2 overflows to +inf either way: every datum an upper limit)
+    if (nfin < 2) { for (int j = 0; j < n; ++j) v[j * stride] = 1e300; return; }
+    // (two sweeps over the ORIGINAL finiteness: replaced values are marked by a NaN until the second sweep fills them)
+    for (int j = 0; j < n; ++j) if (!(v[j * stride] - v[j * stride] == 0.0)) v[j * stride] = dnan();
+    for (int j = 0; j < n; ++j) {
+        if (v[j * stride] == v[j * stride]) continue;
+        int a = j - 1, b = j + 1;
+        while (a >= 0 && !(v[a * stride] == v[a * stride])) --a;
+        while (b < n && !(v[b * stride] == v[b * stride])) ++b;
+        // (a replaced node to the left has been filled by this sweep already: it lies on the same interpolant)
+        double r;
+        if (a >= 0 && b < n) {
+            const double slope = (v[b * stride] - v[a * stride]) / (xn[b] - xn[a]);
+            r = slope * (xn[j] - xn[a]) + v[a * stride];
+        } else r = a >= 0 ? v[a * stride] : v[b * stride];
+        v[j * stride] = r;
+    }
+}
+
+template <class RowPtr>
+NM_HD double masked_nodes_at(const nmma_slot* sv, const double* xn, const int n, const double t, RowPtr row) {
+    int nfin = 0, first = -1, last = -1;
+    for (int j = 0; j < n; ++j) {
+        const double v = apply_slot(sv[j], row);
+        if (v - v == 0.0) { ++nfin; if (first < 0) first = j; last = j; }
+    }
+    if (nfin < 2) return dinf();
+    if (t <= xn[first]) return apply_slot(sv[first], row);
+    if (t >= xn[last]) return apply_slot(sv[last], row);
+    int a = first, b = last;
+    for (int j = first; j <= last; ++j) {
+        const double v = apply_slot(sv[j], row);
+        if (!(v - v == 0.0)) continue;
+        if (xn[j] <= t) a = j;
+        else { b = j; break; }
+    }
+    const double va = apply_slot(sv[a], row), vb = apply_slot(sv[b], row);
+    return ((vb - va) / (xn[b] - xn[a])) * (t - xn[a]) + va;
+}
+// ---------------------------------------------------------------------------
 // np.interp on explicit arrays (cosmology grid, systematics nodes)
 // ---------------------------------------------------------------------------
 // Piecewise-linear value between two nodes exactly as arr_interp evaluates it,

@@ -101,6 +101,25 @@ def case_syserr_time_nodes():
     return c
 
 
+def case_syserr_nodes_masked():
+    """Non-finite SAMPLED node values of the time-dependent systematics: ``autocomplete_data`` drops them (em/utils.py:634-645 via
+    systematics.py:288-291) -- a datum interpolates over the remaining nodes, the end values stay constant, and with fewer than
+    two finite nodes the group's sigma_sys is +inf: every one of its data becomes an upper limit (ln 1/2 each)."""
+    c = case_syserr_time_nodes()
+    names, th = c["names"], c["theta"]
+    a = [names.index(f"em_syserr_blue_{i}") for i in range(4)]
+    b = [names.index(f"em_syserr_2massj_{i}") for i in range(4)]
+    th[1, a[1]] = np.nan                       # a middle node
+    th[2, a[0]] = np.inf                       # the first node: constant from the second on
+    th[3, b[3]] = np.nan                       # the last node of the other group
+    th[4, a[1]] = th[4, a[2]] = np.nan         # two neighbouring middle nodes
+    th[5, a[0]] = th[5, a[1]] = th[5, a[2]] = np.nan       # one finite node left: sigma_sys = +inf for the blue bands
+    th[6, b[0]] = th[6, b[1]] = th[6, b[2]] = th[6, b[3]] = -np.inf      # none left
+    th[7, a[3]] = np.nan; th[7, b[0]] = np.nan
+    th[8, names.index("em_syserr_rest")] = np.nan          # a single sampled parameter is NOT masked: NaN sigma -> floor
+    return c
+
+
 def case_averaging(names=None, counts=12, n_new=9, tt=None):
     """Observed filters the model does not provide (``w``, ``o``, ``I``): arithmetic mean
     of mapped model bands (em_likelihood.py:326-333), plus renamed ``B -> g``.
@@ -333,6 +352,7 @@ CASES = {
     "limit_violated": case_limit_violated,
     "syserr_param": case_syserr_param,
     "syserr_time_nodes": case_syserr_time_nodes,
+    "syserr_nodes_masked": case_syserr_nodes_masked,
     "averaging": case_averaging,
     "averaging_nodes_grid": case_averaging_nodes_grid,
     "edges": case_edges,

@@ -675,3 +675,29 @@ def test_dense_lean_task_with_extinction_and_sampled_systematic(grid, ext, torch
     assert np.array_equal(got == FLOOR, floor) and np.array_equal(rows == FLOOR, floor) and (~floor).sum() > 30
     assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
     assert rel_err(got[~floor], rows[~floor]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("flavour", ["general_lean", "extended", "generic"])
+def test_non_finite_systematics_nodes_are_masked_like_the_reference(flavour, torch_cuda, monkeypatch):
+    """``autocomplete_data``'s finite mask on sampled node values (em/utils.py:634-645): the reference golden
+    ``syserr_nodes_masked`` (NaN / inf nodes in the middle, at the ends, all but one, all of them) through every task flavour
+    that reads node values -- the prologue repairs the tile's values for the lean and extended tasks, the generic item phase
+    re-interpolates per datum."""
+    torch = torch_cuda
+    if flavour == "extended":
+        monkeypatch.setenv("NMMA_EM_NO_LEAN_NODES", "1")
+    if flavour == "generic":
+        monkeypatch.setenv("NMMA_EM_NO_FAST", "1")
+    case = cases.case_syserr_nodes_masked()
+    gold = cases.load_golden("syserr_nodes_masked")
+    eng = engine_from_case(case)
+    got = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+    eng.check()
+    eng.close()
+    want = gold["logl"]
+    floor = want == FLOOR
+    assert floor.sum() == 1 and floor[8]                       # only the NaN single parameter floors its row
+    assert np.array_equal(got == FLOOR, floor)
+    assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    # the rows whose blue bands / 2massj band lost all but one node are upper limits only there: finite and far from the others
+    assert np.isfinite(want[5]) and np.isfinite(want[6])
