@@ -290,3 +290,71 @@ def bns_source_frame(params):
         s, dl = (d * lt - b * dlt) / det, (-c * lt + a * dlt) / det
         p["lambda_1"], p["lambda_2"] = 0.5 * (s + dl), 0.5 * (s - dl)
     return p
+
+
+class MultimessengerConversion:
+    """``nmma/core/conversion.py:768-824``: the ordered chain of parameter conversions a joint likelihood applies -- cosmology
+    (distance from redshift / Hubble constant), GW source frame, EOS, kilonova ejecta fits, EM, custom -- each a callable
+    ``parameters -> parameters``.  The container, its ordering and ``convert_to_multimessenger_parameters`` are the reference's;
+    the EOS converter and ``KilonovaEjectaFitting`` (NR fit formulae over EOS tables, SURVEY section 2: out of scope) are not
+    built here, so ``'ejecta'`` needs the callable itself (``{'ejecta': my_fit}``) instead of ``True``.  Works on scalars (one
+    sample) and on arrays (the batched constraint check of ``MultiMessengerLikelihood.log_likelihood_batch``)."""
+
+    def __init__(self, *conversions):
+        self._conversions = conversions
+
+    @classmethod
+    def from_args(cls, args):
+        raise NotImplementedError("from_args not yet implemented")          # (as in the reference, :773-776)
+
+    @classmethod
+    def from_dict(cls, instruction_dict):
+        conversions = []
+        # NOTE: Order matters!!!  (:780)
+        if "cosmo" in instruction_dict:
+            cosmo = native_cosmology(instruction_dict["cosmo"])
+            conversions.append(lambda p, _c=cosmo: cosmology_to_distance(p, cosmology=_c))
+        if "gw" in instruction_dict:
+            conversions.append(instruction_dict["gw"])
+        if "eos" in instruction_dict:
+            conversions.append(instruction_dict["eos"])
+        if "ejecta" in instruction_dict:
+            fit = instruction_dict["ejecta"]
+            if not callable(fit):
+                raise NotImplementedError("KilonovaEjectaFitting (NR ejecta fits over an EOS) is not part of this build: "
+                                          "pass the fitting callable itself under 'ejecta'")
+            conversions.append(fit)
+        if "em" in instruction_dict:
+            conversions.append(instruction_dict["em"])
+        if "custom" in instruction_dict:
+            conversions.append(instruction_dict["custom"])
+        return cls(*conversions)
+
+    @classmethod
+    def basic_cbc(cls, eos_conversion, em_conversion, ejecta_fit=None):
+        if ejecta_fit is None:
+            raise NotImplementedError("KilonovaEjectaFitting is not part of this build: pass ejecta_fit")
+        return cls(bbh_source_frame, eos_conversion, ejecta_fit, em_conversion)
+
+    @staticmethod
+    def _scalar(v):
+        a = np.asarray(v)
+        return a.item() if a.size == 1 and a.ndim <= 1 and not isinstance(v, (str, bytes)) and a.dtype != object else v
+
+    def convert_to_multimessenger_parameters(self, parameters, add_new_keys=False):
+        original_keys = list(parameters.keys())
+        converted = {k: self._scalar(v) for k, v in parameters.items()}
+        converted = self.core_conversion(converted)
+        converted = {k: self._scalar(v) for k, v in converted.items()}
+        if add_new_keys:
+            return converted, [k for k in converted if k not in original_keys]
+        return converted
+
+    def core_conversion(self, parameters):
+        for conv in self._conversions:
+            out = conv(parameters)
+            parameters = out[0] if isinstance(out, tuple) else out       # (bilby-style converters return (parameters, added_keys))
+        return parameters
+
+    def identity_conversion(self, parameters):
+        return parameters

@@ -60,6 +60,26 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
         self.priors = priors
         self.conversion_instructions = conversion_instructions
         self._noise_logl = float(sum(lh.noise_log_likelihood() for lh in self.likelihoods))
+        self.multi_conversion = None
+        self.setup_parameter_conversion()
+
+    def setup_parameter_conversion(self):
+        """joint_likelihood.py:42-58: without instructions every messenger's own conversion in turn; with a
+        ``conversion_instructions`` dict a ``MultimessengerConversion`` chain in the reference's order (cosmo, gw, eos, ejecta,
+        em, custom), the messengers' conversions filled in by their kind."""
+        if self.conversion_instructions is None:
+            return
+        from ..core.conversion import MultimessengerConversion
+        from ..em.em_likelihood import EMTransientLikelihood
+        instructions = dict(self.conversion_instructions)
+        for lh in self.likelihoods:
+            if isinstance(lh, EMTransientLikelihood):
+                instructions["em"] = lh.parameter_conversion
+            elif type(lh).__name__ == "GravitationalWaveTransientLikelihood":
+                instructions["gw"] = lh.parameter_conversion
+            elif type(lh).__name__ == "EquationofStateLikelihood":
+                instructions["eos"] = lh.parameter_conversion
+        self.multi_conversion = MultimessengerConversion.from_dict(instructions)
 
     def __repr__(self):
         reprs = [repr(lh) for lh in self.likelihoods]
@@ -75,8 +95,10 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
         return bool(np.prod([lh.sanity_checks() for lh in self.likelihoods]))
 
     def parameter_conversion(self, parameters):
-        """basic_parameter_conversion (joint_likelihood.py:75-78): every messenger's conversion in turn.
-        (The MultimessengerConversion object of :58 needs the EOS / GW converters, which are out of scope.)"""
+        """joint_likelihood.py:72-78: the ``MultimessengerConversion`` chain when ``conversion_instructions`` were given (:72-73),
+        else basic_parameter_conversion -- every messenger's conversion in turn."""
+        if self.multi_conversion is not None:
+            return self.multi_conversion.convert_to_multimessenger_parameters(parameters)
         for lh in self.likelihoods:
             parameters = lh.parameter_conversion(parameters)
         return parameters

@@ -416,6 +416,40 @@ def test_hubble_constant_conversion_and_device_refusal():
         mft.engine(["luminosity_distance", "Hubble_constant", "Omega_matter", "log10_mej"])
 
 
+def test_multimessenger_conversion_chain_and_joint_setup():
+    """``MultimessengerConversion`` (core/conversion.py:768-824): the reference's order (cosmo, gw, eos, ejecta, em, custom), scalar
+    unwrapping, ``add_new_keys``, tuple-returning converters, arrays for the batched path; ``MultiMessengerLikelihood`` switches to it
+    when ``conversion_instructions`` are given (joint_likelihood.py:42-58, :72-73); the ejecta fits themselves are not built."""
+    from nmma_amd.core.conversion import MultimessengerConversion
+    from nmma_amd.joint.joint_likelihood import ExternalLogLikelihood, MultiMessengerLikelihood
+    order = []
+
+    def step(tag, **add):
+        def f(p):
+            order.append(tag)
+            return dict(p, **{k: (v(p) if callable(v) else v) for k, v in add.items()})
+        return f
+
+    chain = MultimessengerConversion.from_dict({
+        "custom": step("custom", done=1), "em": lambda p: (step("em", KNtheta=lambda q: q["inc"] * 2)(p), ["KNtheta"]),
+        "ejecta": step("ejecta", log10_mej_dyn=-2.0), "eos": step("eos", lambda_1=400.0), "gw": step("gw", chi_eff=0.0)})
+    out, added = chain.convert_to_multimessenger_parameters({"inc": np.array([0.25])}, add_new_keys=True)
+    assert order == ["gw", "eos", "ejecta", "em", "custom"]
+    assert out["KNtheta"] == 0.5 and isinstance(out["inc"], float) and added == ["chi_eff", "lambda_1", "log10_mej_dyn", "KNtheta", "done"]
+    batch = chain.convert_to_multimessenger_parameters({"inc": np.linspace(0.0, 1.0, 5)})
+    assert np.allclose(batch["KNtheta"], np.linspace(0.0, 2.0, 5))
+    with pytest.raises(NotImplementedError):
+        MultimessengerConversion.from_dict({"ejecta": True})
+    with pytest.raises(NotImplementedError):
+        MultimessengerConversion.from_args(None)
+
+    ext = ExternalLogLikelihood("gw", lambda p: -1.0)
+    mm = MultiMessengerLikelihood([ext], {}, conversion_instructions={"custom": lambda p: dict(p, total=p["a"] + p["b"])})
+    assert mm.multi_conversion is not None and mm.parameter_conversion({"a": 1.0, "b": 2.0})["total"] == 3.0
+    plain = MultiMessengerLikelihood([ext], {})
+    assert plain.multi_conversion is None and plain.parameter_conversion({"a": 1.0}) == {"a": 1.0}
+
+
 def test_kernel_register_budget():
     """Code-object metadata of the built library: the lean kernels (em_logl<.., 1>, <.., 3>, <.., 4>, <.., 5>, <.., 6>) must not spill -- a change
     that made hipcc spill 2 600 registers in one of them went unnoticed by the parity tests and cost 50 % of its speed --
