@@ -326,6 +326,40 @@ int64_t nmma_gw_n_bins(const nmma_gw_handle* h);
 int32_t nmma_gw_profile_begin(nmma_gw_handle* h, int32_t max_launches);
 int32_t nmma_gw_profile_end(nmma_gw_handle* h, double* kernel_ms_total, int32_t* n_launches);
 
+/* ---- Lock-step ensemble walk on the device (the sampler-side batching seam; the reference builds dynesty's walker objects at
+ * core/mpi_setup.py:202-245 and evolves one chain per MPI task).  One MCMC step of n chains = nmma_walk_propose -> a likelihood
+ * launch on theta_dev -> nmma_walk_accept, all asynchronous on `stream`.  Random numbers: draw k of step s of the chain with key K
+ * is the SplitMix64 counter hash of (K, s, k) (nmma_amd/sampler.py:counter_uniforms computes the same numbers on the host). */
+#define NMMA_WALK_MAX_DIM 32
+enum nmma_prior_kind {        /* bilby/core/prior/analytical.py, by the formula of ``rescale`` */
+    NMMA_PRIOR_UNIFORM = 0,   /* a + u (b - a)                                  a = minimum, b = maximum */
+    NMMA_PRIOR_SINE = 1,      /* arccos(cos a - u (cos a - cos b))                                        */
+    NMMA_PRIOR_COSINE = 2,    /* arcsin(u (sin b - sin a) + sin a)                                        */
+    NMMA_PRIOR_POWERLAW = 3,  /* (a^(1+alpha) + u (b^(1+alpha) - a^(1+alpha)))^(1/(1+alpha)); alpha = -1: a exp(u ln(b/a)) (LogUniform) */
+    NMMA_PRIOR_GAUSSIAN = 4,  /* a + erfinv(2u - 1) sqrt(2) b                   a = mu, b = sigma         */
+    NMMA_PRIOR_DELTA = 5      /* a                                              a = peak                  */
+};
+enum nmma_boundary { NMMA_BOUNDARY_NONE = 0, NMMA_BOUNDARY_PERIODIC = 1, NMMA_BOUNDARY_REFLECTIVE = 2 };
+typedef struct nmma_walk_prior {
+    int32_t kind;      /* enum nmma_prior_kind */
+    int32_t boundary;  /* enum nmma_boundary: how a proposal that leaves [0, 1] in this dimension is folded back */
+    double a, b, alpha;
+} nmma_walk_prior;
+
+/* prop = u + gamma (live[j] - live[i]) with the boundary conditions applied; inside[c] = the proposal lies in the unit cube;
+ * theta = the prior transform of prop (the chain's current theta v where the proposal fell outside).  priors: HOST array [ndim]. */
+int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const double* u_dev,
+                          const double* v_dev, const uint64_t* key_dev, int64_t n, uint64_t step, double* prop_dev, double* theta_dev,
+                          int32_t* inside_dev, int32_t device, void* stream);
+/* accept where inside and logl_prop > loglstar: u <- prop, v <- theta, logl <- logl_prop; counts_dev[n][4] += {accept, reject,
+ * outside-the-cube, likelihood calls}. */
+int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
+                         const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
+                         int32_t* counts_dev, int32_t device, void* stream);
+/* theta = prior transform of u[n][ndim] (start points, fresh prior draws). */
+int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
+                          void* stream);
+
 /* MultiMessengerLikelihood.sub_log_likelihood for a batch (joint/joint_likelihood.py:62-67): out_dev[b] = sum_k parts[k][b] in
  * messenger order, NMMA_LOGL_FLOOR where the sum is not finite or a messenger already returned the floor.
  * parts_dev: HOST array of n_parts (1..8) device pointers to [B] doubles. */

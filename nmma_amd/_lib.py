@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMMA_HIP_LIB") or os.path.join(_HERE, "libnmma_hip.so")   # env: experiment builds
 SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: translation units of the library; every other file under csrc/ and include/ is a dependency of both
-SOURCES = ("em_kernels.hip", "gw_kernels.hip")
+SOURCES = ("em_kernels.hip", "gw_kernels.hip", "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
@@ -81,6 +81,16 @@ class EmConfig(C.Structure):
     ]
 
 
+class WalkPrior(C.Structure):
+    """Mirror of ``struct nmma_walk_prior``."""
+    _fields_ = [("kind", C.c_int32), ("boundary", C.c_int32), ("a", C.c_double), ("b", C.c_double), ("alpha", C.c_double)]
+
+
+WALK_MAX_DIM = 32
+PRIOR_UNIFORM, PRIOR_SINE, PRIOR_COSINE, PRIOR_POWERLAW, PRIOR_GAUSSIAN, PRIOR_DELTA = range(6)
+BOUNDARY_NONE, BOUNDARY_PERIODIC, BOUNDARY_REFLECTIVE = range(3)
+
+
 class GwConfig(C.Structure):
     """Mirror of ``struct nmma_gw_config`` (field order must match the header)."""
     _fields_ = [
@@ -123,6 +133,11 @@ PROTOTYPES = {
     "nmma_gw_loglike_ratio": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_double,
                                          C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_logl_sum_floor": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_walk_propose": (C.c_int32, [C.POINTER(WalkPrior), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_walk_accept": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_walk_rescale": (C.c_int32, [C.POINTER(WalkPrior), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
     "nmma_gw_destroy": (None, [C.c_void_p]),
     "nmma_gw_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

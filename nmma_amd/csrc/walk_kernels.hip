@@ -1,0 +1,173 @@
+// Lock-step ensemble walk on the device (the sampler-side batching seam).
+//
+// The host adapter (nmma_amd/sampler.py: _LockstepWalk.run_many) spends ~0.5 ms of numpy per MCMC step for 4 096 chains -- counter
+// hash, differential-evolution proposal, prior transform, accept bookkeeping -- around a 31 us likelihood launch.  These two
+// kernels move that bookkeeping next to the likelihood: one step is propose -> nmma_*_loglike -> accept, three launches on one
+// stream, no host round trip.  The random numbers are the SAME counter hash as sampler.py:counter_uniforms (SplitMix64 of
+// (chain key, step, draw)), the proposal is sampler.py:_propose (dynesty's "rwalk"-style differential evolution as
+// bilby/core/sampler/dynesty_utils.py implements it; the reference builds those walker objects at mpi_setup.py:202-245), and the
+// prior transform covers the analytic bilby priors by their published ``rescale`` formulas (bilby/core/prior/analytical.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+
+#include "../../include/nmma_hip.h"
+#include "nmma_common.h"
+
+namespace nmma {
+
+struct WalkSpec {
+    nmma_walk_prior p[NMMA_WALK_MAX_DIM];
+    int32_t ndim;
+};
+
+__device__ __forceinline__ uint64_t walk_mix64(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// draw k of step `step` of the chain with key `key`: sampler.py:counter_uniforms, bit for bit
+__device__ __forceinline__ double walk_uniform(const uint64_t key, const uint64_t step, const uint64_t k) {
+    const uint64_t G = 0x9E3779B97F4A7C15ull;
+    uint64_t x = walk_mix64(walk_mix64(key * G + G) ^ (step * 0xD1342543DE82EF95ull + k * 0xA0761D6478BD642Full + G));
+    x = walk_mix64(x);
+    return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double floored_mod(const double x, const double m) {       // np.mod for m > 0
+    const double r = fmod(x, m);
+    return r < 0.0 ? r + m : r;
+}
+// bilby/core/prior/analytical.py: rescale(val) of the analytic priors
+__device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) {
+    switch (p.kind) {
+        case NMMA_PRIOR_UNIFORM: return p.a + u * (p.b - p.a);
+        case NMMA_PRIOR_SINE: { const double norm = 1.0 / (cos(p.a) - cos(p.b)); return acos(cos(p.a) - u / norm); }
+        case NMMA_PRIOR_COSINE: { const double norm = 1.0 / (sin(p.b) - sin(p.a)); return asin(u / norm + sin(p.a)); }
+        case NMMA_PRIOR_POWERLAW:
+            if (p.alpha == -1.0) return p.a * exp(u * log(p.b / p.a));
+            return pow(pow(p.a, 1.0 + p.alpha) + u * (pow(p.b, 1.0 + p.alpha) - pow(p.a, 1.0 + p.alpha)), 1.0 / (1.0 + p.alpha));
+        case NMMA_PRIOR_GAUSSIAN: return p.a + erfinv(2.0 * u - 1.0) * 1.4142135623730951 * p.b;      // mu, sigma
+        default: return p.a;                                                                        // NMMA_PRIOR_DELTA: peak
+    }
+}
+
+// one thread per chain: proposal in the unit cube (differential evolution between two other live points), boundary conditions,
+// inside-the-cube flag, prior transform.  A proposal outside the cube keeps the chain's current point in `theta` (the lock-step
+// likelihood launch evaluates every chain; the accept kernel ignores that row).
+__global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
+                                                           const double* __restrict__ u, const double* __restrict__ v,
+                                                           const uint64_t* __restrict__ key, const long n, const uint64_t step,
+                                                           double* __restrict__ prop, double* __restrict__ theta, int32_t* __restrict__ inside) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int D = S.ndim;
+    double r[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) r[k] = walk_uniform(key[c], step, (uint64_t)k);
+    long i = (long)(r[0] * (double)n_live);
+    i = i > n_live - 1 ? n_live - 1 : i;
+    long jj = (long)(r[1] * (double)(n_live - 1));
+    jj = jj > n_live - 2 ? n_live - 2 : jj;
+    const long j = (i + 1 + jj) % n_live;                                         // a different live point
+    const double gamma = r[2] < 0.5 ? 1.0 : 2.38 / sqrt(2.0 * (double)D) * (-0.25 * log(r[3] * r[4] * r[5] * r[6]));   // Gamma(4, 1/4)
+    bool in = true;
+    for (int d = 0; d < D; ++d) {
+        double x = u[c * D + d] + gamma * (live[j * D + d] - live[i * D + d]);
+        if (S.p[d].boundary == NMMA_BOUNDARY_PERIODIC) x = floored_mod(x, 1.0);
+        else if (S.p[d].boundary == NMMA_BOUNDARY_REFLECTIVE) { const double q = floored_mod(x, 2.0); x = q > 1.0 ? 2.0 - q : q; }
+        prop[c * D + d] = x;
+        in = in && (x >= 0.0) && (x <= 1.0);
+    }
+    inside[c] = in ? 1 : 0;
+    for (int d = 0; d < D; ++d) theta[c * D + d] = in ? walk_rescale(S.p[d], prop[c * D + d]) : v[c * D + d];
+}
+
+// accept when the proposal was inside the cube and its likelihood beats the chain's bound (dynesty: logl > loglstar)
+__global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const long n, const double* __restrict__ prop,
+                                                          const double* __restrict__ theta, const int32_t* __restrict__ inside,
+                                                          const double* __restrict__ l_prop, const double* __restrict__ loglstar,
+                                                          double* __restrict__ u, double* __restrict__ v, double* __restrict__ logl,
+                                                          int32_t* __restrict__ counts) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int32_t* cnt = counts + 4 * c;                          // {accept, reject, nfail, ncall}
+    if (!inside[c]) { cnt[2] += 1; return; }
+    cnt[3] += 1;
+    if (l_prop[c] > loglstar[c]) {
+        for (int d = 0; d < D; ++d) { u[c * D + d] = prop[c * D + d]; v[c * D + d] = theta[c * D + d]; }
+        logl[c] = l_prop[c];
+        cnt[0] += 1;
+    } else cnt[1] += 1;
+}
+
+// the prior transform alone (start points, fresh draws): theta = rescale(u)
+__global__ __launch_bounds__(256) void walk_rescale_kernel(const WalkSpec S, const long n, const double* __restrict__ u, double* __restrict__ theta) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    for (int d = 0; d < S.ndim; ++d) theta[c * S.ndim + d] = walk_rescale(S.p[d], u[c * S.ndim + d]);
+}
+
+static int walk_spec(const nmma_walk_prior* priors, int32_t ndim, WalkSpec* S, const char* what) {
+    if (!priors || ndim < 1 || ndim > NMMA_WALK_MAX_DIM) return fail(std::string(what) + ": 1 .. NMMA_WALK_MAX_DIM dimensions");
+    S->ndim = ndim;
+    for (int d = 0; d < ndim; ++d) {
+        if (priors[d].kind < NMMA_PRIOR_UNIFORM || priors[d].kind > NMMA_PRIOR_DELTA) return fail(std::string(what) + ": unknown prior kind");
+        S->p[d] = priors[d];
+    }
+    return 0;
+}
+
+}  // namespace nmma
+
+extern "C" {
+
+int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const double* u_dev,
+                          const double* v_dev, const uint64_t* key_dev, int64_t n, uint64_t step, double* prop_dev, double* theta_dev,
+                          int32_t* inside_dev, int32_t device, void* stream) {
+    using namespace nmma;
+    WalkSpec S;
+    if (walk_spec(priors, ndim, &S, "nmma_walk_propose")) return 1;
+    if (!live_dev || !u_dev || !v_dev || !key_dev || !prop_dev || !theta_dev || !inside_dev || n < 0 || n_live < 3)
+        return fail("nmma_walk_propose: bad argument (at least three live points)");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_propose: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev,
+                       (long)n_live, u_dev, v_dev, key_dev, (long)n, step, prop_dev, theta_dev, inside_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_propose launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
+                         const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
+                         int32_t* counts_dev, int32_t device, void* stream) {
+    using namespace nmma;
+    if (ndim < 1 || ndim > NMMA_WALK_MAX_DIM || n < 0 || !prop_dev || !theta_dev || !inside_dev || !logl_prop_dev || !loglstar_dev || !u_dev ||
+        !v_dev || !logl_dev || !counts_dev) return fail("nmma_walk_accept: bad argument");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_accept: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_accept_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim, (long)n,
+                       prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_accept launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
+                          void* stream) {
+    using namespace nmma;
+    WalkSpec S;
+    if (walk_spec(priors, ndim, &S, "nmma_walk_rescale")) return 1;
+    if (!u_dev || !theta_dev || n < 0) return fail("nmma_walk_rescale: bad argument");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_rescale: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_rescale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), S, (long)n, u_dev,
+                       theta_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_rescale launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -13,7 +13,8 @@ Usage with dynesty / parallel-bilby style drivers::
 ``pool.map(pool.log_likelihood, thetas)`` recognises its own callable and sends the list
 to the GPU as one batch; ``pool.map(walker, sampler_arguments)`` with a lock-step walker
 (:class:`nmma_amd.sampler.LockstepEnsembleWalk`, the ``sample=`` object) advances all chains of the queue
-together, one launch per MCMC step; any other function is mapped serially on the host.
+together, one launch per MCMC step -- on the GPU end to end (proposal, prior transform, likelihood, accept) when the pool knows
+the sampled ``priors`` and they are analytic bilby priors; any other function is mapped serially on the host.
 """
 from __future__ import annotations
 
@@ -21,11 +22,17 @@ import numpy as np
 
 
 class GPUPool:
-    def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None):
+    def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None, priors=None, device=0, device_walk=True):
         self.likelihood = likelihood
         self.size = int(queue_size)
         self.names = names
         self.prior_transform_many = prior_transform_many     # e.g. nmma_amd.sampler.BatchedPriorTransform
+        # with the sampled priors (dict name -> bilby prior, `names` = the column order) a fixed-length ensemble walk runs ENTIRELY
+        # on the GPU -- propose -> likelihood -> accept, three launches per MCMC step (nmma_amd.sampler.device_walk) -- when every
+        # prior has a device formula; otherwise, and for the ACT-tracking walkers, the host walk below
+        self.priors = priors
+        self.device = int(device)
+        self.device_walk = bool(device_walk)
         self.n_batches = 0
         self.n_evals = 0
 
@@ -64,6 +71,10 @@ class GPUPool:
         self.n_evals += len(theta)
         return np.asarray(out)
 
+    def _log_likelihood_device(self, theta):
+        """theta[n, D] CUDA tensor -> logL[n] CUDA tensor (the device walk's likelihood step)."""
+        return self.likelihood.log_likelihood_batch(theta, self.names)
+
     def map(self, func, iterable, callback=None):
         items = list(iterable)
         if not items:
@@ -74,7 +85,13 @@ class GPUPool:
             # a lock-step walker of nmma_amd.sampler -- the `sample=` object itself (dynesty 2) or its bound `sample` method
             # (dynesty 3): the queue of chains advances together, one likelihood launch per MCMC step
             walker = func if hasattr(func, "run_many") else func.__self__
-            res = walker.run_many(items, self.log_likelihood_many, self.prior_transform_many)
+            if self.device_walk and self.priors is not None and self.names is not None and hasattr(walker, "run_many_device"):
+                res = walker.run_many_device(items, self._log_likelihood_device, self.priors, self.names, device=self.device,
+                                             loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many)
+                self.n_batches += getattr(walker, "n_batches", 0)
+                self.n_evals += getattr(walker, "n_evals", 0)
+            else:
+                res = walker.run_many(items, self.log_likelihood_many, self.prior_transform_many)
         else:
             res = [func(it) for it in items]
         if callback is not None:

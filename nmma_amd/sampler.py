@@ -272,6 +272,97 @@ class _LockstepWalk:
         return {"accept": int(st["accept"][q]), "reject": int(st["reject"][q] + st["nfail"][q]), "scale": getattr(args, "scale", 1.0)}
 
 
+# -----------------------------------------------------------------------------------------------------------------------
+# The walk on the device: propose -> likelihood -> accept as three launches per MCMC step, no host round trip
+# -----------------------------------------------------------------------------------------------------------------------
+_PRIOR_KINDS = {"Uniform": "uniform", "Sine": "sine", "Cosine": "cosine", "PowerLaw": "powerlaw", "LogUniform": "loguniform",
+                "Gaussian": "gaussian", "Normal": "gaussian", "DeltaFunction": "delta"}
+
+
+def device_prior_table(priors, keys, periodic=(), reflective=()):
+    """The analytic bilby priors of ``keys`` as the device's table (``nmma_walk_prior``: kind, boundary, a, b, alpha), recognised
+    by class name (bilby/core/prior/analytical.py: Uniform, Sine, Cosine, PowerLaw, LogUniform, Gaussian / Normal, DeltaFunction;
+    a class whose name ends in one of these counts too).  Returns ``None`` when a prior has no device formula -- the caller then
+    stays on the host path."""
+    from . import _lib as L
+    keys = list(keys)
+    if not 1 <= len(keys) <= L.WALK_MAX_DIM:
+        return None
+    table = (L.WalkPrior * len(keys))()
+    periodic, reflective = set(int(i) for i in periodic), set(int(i) for i in reflective)
+    for d, key in enumerate(keys):
+        pr = priors[key]
+        name = type(pr).__name__
+        kind = _PRIOR_KINDS.get(name)
+        if kind is None:        # (a subclass / stand-in named after the bilby class: the longest matching name wins -- LogUniform, not Uniform)
+            kind = next((_PRIOR_KINDS[k] for k in sorted(_PRIOR_KINDS, key=len, reverse=True)
+                         if name.endswith(k) or name.endswith(k + "Prior")), None)
+        if kind is None and hasattr(pr, "peak") and getattr(pr, "minimum", None) is None:
+            kind = "delta"
+        try:
+            if kind == "uniform":
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_UNIFORM, float(pr.minimum), float(pr.maximum)
+            elif kind == "sine":
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_SINE, float(pr.minimum), float(pr.maximum)
+            elif kind == "cosine":
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_COSINE, float(pr.minimum), float(pr.maximum)
+            elif kind == "powerlaw":
+                table[d].kind, table[d].a, table[d].b, table[d].alpha = L.PRIOR_POWERLAW, float(pr.minimum), float(pr.maximum), float(pr.alpha)
+            elif kind == "loguniform":
+                table[d].kind, table[d].a, table[d].b, table[d].alpha = L.PRIOR_POWERLAW, float(pr.minimum), float(pr.maximum), -1.0
+            elif kind == "gaussian":
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_GAUSSIAN, float(pr.mu), float(pr.sigma)
+            elif kind == "delta":
+                table[d].kind, table[d].a = L.PRIOR_DELTA, float(pr.peak)
+            else:
+                return None
+        except (AttributeError, TypeError):
+            return None
+        table[d].boundary = L.BOUNDARY_PERIODIC if d in periodic else (L.BOUNDARY_REFLECTIVE if d in reflective else L.BOUNDARY_NONE)
+    return table
+
+
+def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device=0, first_step=1):
+    """``n_steps`` lock-step MCMC steps of ``len(u0)`` chains on the GPU.  ``loglike_device(theta[n, D] CUDA tensor) -> logL[n]``
+    (e.g. ``lambda t: likelihood.log_likelihood_batch(t, names)``).  Returns host arrays (u, v, logl, counts[n, 4] = accept,
+    reject, outside-the-cube, likelihood calls); ``logl`` is NaN for a chain that never moved, like the host walk's."""
+    import torch
+    from . import _lib as L
+    lib = L.load_library()
+    dev = torch.device(f"cuda:{int(device)}")
+    f64 = dict(dtype=torch.float64, device=dev)
+    live_d = torch.as_tensor(np.ascontiguousarray(live, dtype=np.float64), device=dev)
+    u = torch.as_tensor(np.ascontiguousarray(u0, dtype=np.float64), device=dev)
+    n, ndim = u.shape
+    star = torch.as_tensor(np.ascontiguousarray(loglstar, dtype=np.float64), device=dev)
+    key = torch.as_tensor(np.ascontiguousarray(keys, dtype=np.uint64).view(np.int64), device=dev)
+    v, prop, theta = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    logl = torch.full((n,), float("nan"), **f64)
+    inside = torch.empty(n, dtype=torch.int32, device=dev)
+    counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    stream = C_void(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: C_void(t.data_ptr())
+    L.check(lib.nmma_walk_rescale(table, ndim, ptr(u), n, ptr(v), int(device), stream), "nmma_walk_rescale")
+    # (the buffers do not move: their addresses are taken once -- a step then costs three ctypes calls and the likelihood's wrapper)
+    p_live, p_u, p_v, p_key, p_prop, p_theta, p_in = ptr(live_d), ptr(u), ptr(v), ptr(key), ptr(prop), ptr(theta), ptr(inside)
+    p_star, p_logl, p_cnt, n_live, dev_i = ptr(star), ptr(logl), ptr(counts), live_d.shape[0], int(device)
+    propose, accept = lib.nmma_walk_propose, lib.nmma_walk_accept
+    for s in range(int(first_step), int(first_step) + int(n_steps)):
+        if propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, s, p_prop, p_theta, p_in, dev_i, stream):
+            L.check(1, "nmma_walk_propose")
+        l_prop = loglike_device(theta)
+        if l_prop.dtype != torch.float64 or not l_prop.is_contiguous():
+            l_prop = l_prop.to(torch.float64).contiguous()
+        if accept(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, dev_i, stream):
+            L.check(1, "nmma_walk_accept")
+    return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy()
+
+
+def C_void(x):
+    import ctypes
+    return ctypes.c_void_p(int(x))
+
+
 class EnsembleWalkSampler(_LockstepWalk):
     """``sample="acceptance-walk"`` (mpi_setup.py:221-232): ``int(walks)`` differential-evolution steps per chain; ``tune`` moves
     ``walks`` so that a chain accepts ``naccept`` steps on average (bilby: ``EnsembleWalkSampler.tune``), capped at ``maxmcmc``."""
@@ -292,6 +383,51 @@ class EnsembleWalkSampler(_LockstepWalk):
         # (bilby counts every step that did not accept as a rejection, out-of-cube proposals included)
         return {"accept": int(st["accept"][q]), "reject": int(st["walks"][q] - st["accept"][q]), "scale": getattr(args, "scale", 1.0),
                 "walks": int(st["walks"][q])}
+
+    def run_many_device(self, args_list, loglike_device, priors, keys, device=0, loglike_many=None, prior_transform_many=None):
+        """``run_many`` with the whole walk on the GPU: ``int(walks)`` steps of propose -> ``loglike_device(theta)`` -> accept with
+        no host round trip (``device_walk``).  ``priors`` / ``keys``: the sampled priors in column order, needed as a device table
+        (``device_prior_table``); a prior without a device formula, chains with their own ensembles or differing walk lengths send
+        the queue to the host walk ``run_many(args_list, loglike_many, prior_transform_many)``.  The random numbers and the
+        proposal are the host walk's; only the libm of ``log`` / the prior transform differs in the last bits."""
+        n = len(args_list)
+        if n == 0:
+            return []
+        first = args_list[0]
+        live = _live_points(first)
+        shared = all(_live_points(a) is live for a in args_list[1:])
+        walks = [int(a.kwargs.get("walks") or self.walks) for a in args_list]
+        table = device_prior_table(priors, keys, self.periodic, self.reflective)
+        if table is None or not shared or len(set(walks)) != 1 or np.asarray(live).shape[0] < 3:
+            if loglike_many is None:
+                raise ValueError("this queue needs the host walk: pass loglike_many (and prior_transform_many)")
+            return self.run_many(args_list, loglike_many, prior_transform_many)
+        rseeds = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
+        u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
+        loglstar = np.array([a.loglstar for a in args_list], dtype=float)
+        u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, walks[0], loglike_device, device=device)
+        self.n_batches, self.n_evals = walks[0], int(counts[:, 3].sum())
+        stuck = np.nonzero(counts[:, 0] == 0)[0]
+        if stuck.size:        # a chain that never moved returns a fresh draw from the prior, as on the host
+            import torch
+            from . import _lib as L
+            lib = L.load_library()
+            fresh = counter_uniforms(rseeds[stuck], np.zeros(stuck.size, dtype=np.uint64), max(N_DRAWS, u.shape[1]))[:, :u.shape[1]]
+            fu = torch.as_tensor(np.ascontiguousarray(fresh), device=f"cuda:{int(device)}")
+            fv = torch.empty_like(fu)
+            L.check(lib.nmma_walk_rescale(table, u.shape[1], C_void(fu.data_ptr()), stuck.size, C_void(fv.data_ptr()), int(device),
+                                          C_void(torch.cuda.current_stream(fu.device).cuda_stream)), "nmma_walk_rescale")
+            u[stuck], v[stuck] = fresh, fv.cpu().numpy()
+            logl[stuck] = loglike_device(fv).cpu().numpy()
+            counts[stuck, 3] += 1
+            self.n_batches += 1
+            self.n_evals += int(stuck.size)
+        out = []
+        for q in range(n):
+            blob = {"accept": int(counts[q, 0]), "reject": int(walks[0] - counts[q, 0]), "scale": getattr(args_list[q], "scale", 1.0),
+                    "walks": int(walks[0])}
+            out.append(SamplerReturn(u[q], v[q], float(logl[q]), int(counts[q, 3]), blob))
+        return out
 
     def tune(self, tuning_info, update=True):
         """Steer the walk length towards ``naccept`` accepted steps; ``delay`` averages over about a tenth of the live points.
