@@ -293,6 +293,8 @@ def device_prior_table(priors, keys, periodic=(), reflective=()):
     for d, key in enumerate(keys):
         pr = priors[key]
         name = type(pr).__name__
+        if name.startswith("Conditional") or hasattr(pr, "condition_func") or hasattr(pr, "required_variables"):
+            return None         # (bilby's conditional priors depend on other parameters: host transform)
         kind = _PRIOR_KINDS.get(name)
         if kind is None:        # (a subclass / stand-in named after the bilby class: the longest matching name wins -- LogUniform, not Uniform)
             kind = next((_PRIOR_KINDS[k] for k in sorted(_PRIOR_KINDS, key=len, reverse=True)
