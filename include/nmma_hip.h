@@ -352,10 +352,11 @@ int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const dou
                           const double* v_dev, const uint64_t* key_dev, int64_t n, uint64_t step, double* prop_dev, double* theta_dev,
                           int32_t* inside_dev, int32_t device, void* stream);
 /* accept where inside and logl_prop > loglstar: u <- prop, v <- theta, logl <- logl_prop; counts_dev[n][4] += {accept, reject,
- * outside-the-cube, likelihood calls}. */
+ * outside-the-cube, likelihood calls}.  n_steps_dev (or NULL): chain c takes part only while step <= n_steps_dev[c] (chains queued
+ * with different walk lengths share the launches). */
 int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
                          const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
-                         int32_t* counts_dev, int32_t device, void* stream);
+                         int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step, int32_t device, void* stream);
 /* theta = prior transform of u[n][ndim] (start points, fresh prior draws). */
 int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
                           void* stream);

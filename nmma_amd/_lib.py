@@ -136,7 +136,7 @@ PROTOTYPES = {
     "nmma_walk_propose": (C.c_int32, [C.POINTER(WalkPrior), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_walk_accept": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "nmma_walk_rescale": (C.c_int32, [C.POINTER(WalkPrior), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
     "nmma_gw_destroy": (None, [C.c_void_p]),

@@ -89,9 +89,11 @@ __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const lon
                                                           const double* __restrict__ theta, const int32_t* __restrict__ inside,
                                                           const double* __restrict__ l_prop, const double* __restrict__ loglstar,
                                                           double* __restrict__ u, double* __restrict__ v, double* __restrict__ logl,
-                                                          int32_t* __restrict__ counts) {
+                                                          int32_t* __restrict__ counts, const int32_t* __restrict__ n_steps,
+                                                          const uint64_t step) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
+    if (n_steps != nullptr && step > (uint64_t)n_steps[c]) return;       // this chain's walk is over (walk lengths may differ per chain)
     int32_t* cnt = counts + 4 * c;                          // {accept, reject, nfail, ncall}
     if (!inside[c]) { cnt[2] += 1; return; }
     cnt[3] += 1;
@@ -142,14 +144,14 @@ int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const dou
 
 int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
                          const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
-                         int32_t* counts_dev, int32_t device, void* stream) {
+                         int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step, int32_t device, void* stream) {
     using namespace nmma;
     if (ndim < 1 || ndim > NMMA_WALK_MAX_DIM || n < 0 || !prop_dev || !theta_dev || !inside_dev || !logl_prop_dev || !loglstar_dev || !u_dev ||
         !v_dev || !logl_dev || !counts_dev) return fail("nmma_walk_accept: bad argument");
     if (n == 0) return 0;
     if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_accept: hipSetDevice failed");
     hipLaunchKernelGGL(walk_accept_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim, (long)n,
-                       prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev);
+                       prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, n_steps_dev, step);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_accept launch failed: ") + hipGetErrorString(e));
     return 0;

@@ -325,7 +325,8 @@ def device_prior_table(priors, keys, periodic=(), reflective=()):
 
 
 def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device=0, first_step=1):
-    """``n_steps`` lock-step MCMC steps of ``len(u0)`` chains on the GPU.  ``loglike_device(theta[n, D] CUDA tensor) -> logL[n]``
+    """``n_steps`` lock-step MCMC steps of ``len(u0)`` chains on the GPU (an int, or one walk length per chain: the launches run to
+    the longest and a chain stops taking part after its own).  ``loglike_device(theta[n, D] CUDA tensor) -> logL[n]``
     (e.g. ``lambda t: likelihood.log_likelihood_batch(t, names)``).  Returns host arrays (u, v, logl, counts[n, 4] = accept,
     reject, outside-the-cube, likelihood calls); ``logl`` is NaN for a chain that never moved, like the host walk's."""
     import torch
@@ -343,11 +344,15 @@ def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device
     inside = torch.empty(n, dtype=torch.int32, device=dev)
     counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     stream = C_void(torch.cuda.current_stream(dev).cuda_stream)
+    per_chain = np.ndim(n_steps) > 0
+    lengths = torch.as_tensor(np.ascontiguousarray(n_steps, dtype=np.int32), device=dev) if per_chain else None
+    n_steps = int(np.max(n_steps)) if per_chain else int(n_steps)
     ptr = lambda t: C_void(t.data_ptr())
     L.check(lib.nmma_walk_rescale(table, ndim, ptr(u), n, ptr(v), int(device), stream), "nmma_walk_rescale")
     # (the buffers do not move: their addresses are taken once -- a step then costs three ctypes calls and the likelihood's wrapper)
     p_live, p_u, p_v, p_key, p_prop, p_theta, p_in = ptr(live_d), ptr(u), ptr(v), ptr(key), ptr(prop), ptr(theta), ptr(inside)
     p_star, p_logl, p_cnt, n_live, dev_i = ptr(star), ptr(logl), ptr(counts), live_d.shape[0], int(device)
+    p_len = ptr(lengths) if per_chain else None
     propose, accept = lib.nmma_walk_propose, lib.nmma_walk_accept
     for s in range(int(first_step), int(first_step) + int(n_steps)):
         if propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, s, p_prop, p_theta, p_in, dev_i, stream):
@@ -355,7 +360,7 @@ def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device
         l_prop = loglike_device(theta)
         if l_prop.dtype != torch.float64 or not l_prop.is_contiguous():
             l_prop = l_prop.to(torch.float64).contiguous()
-        if accept(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, dev_i, stream):
+        if accept(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_len, s - int(first_step) + 1, dev_i, stream):
             L.check(1, "nmma_walk_accept")
     return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy()
 
@@ -389,7 +394,7 @@ class EnsembleWalkSampler(_LockstepWalk):
     def run_many_device(self, args_list, loglike_device, priors, keys, device=0, loglike_many=None, prior_transform_many=None):
         """``run_many`` with the whole walk on the GPU: ``int(walks)`` steps of propose -> ``loglike_device(theta)`` -> accept with
         no host round trip (``device_walk``).  ``priors`` / ``keys``: the sampled priors in column order, needed as a device table
-        (``device_prior_table``); a prior without a device formula, chains with their own ensembles or differing walk lengths send
+        (``device_prior_table``); a prior without a device formula or chains with their own ensembles send
         the queue to the host walk ``run_many(args_list, loglike_many, prior_transform_many)``.  The random numbers and the
         proposal are the host walk's; only the libm of ``log`` / the prior transform differs in the last bits."""
         n = len(args_list)
@@ -400,15 +405,16 @@ class EnsembleWalkSampler(_LockstepWalk):
         shared = all(_live_points(a) is live for a in args_list[1:])
         walks = [int(a.kwargs.get("walks") or self.walks) for a in args_list]
         table = device_prior_table(priors, keys, self.periodic, self.reflective)
-        if table is None or not shared or len(set(walks)) != 1 or np.asarray(live).shape[0] < 3:
+        if table is None or not shared or np.asarray(live).shape[0] < 3:
             if loglike_many is None:
                 raise ValueError("this queue needs the host walk: pass loglike_many (and prior_transform_many)")
             return self.run_many(args_list, loglike_many, prior_transform_many)
         rseeds = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
         u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
         loglstar = np.array([a.loglstar for a in args_list], dtype=float)
-        u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, walks[0], loglike_device, device=device)
-        self.n_batches, self.n_evals = walks[0], int(counts[:, 3].sum())
+        same = len(set(walks)) == 1
+        u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, walks[0] if same else np.array(walks), loglike_device, device=device)
+        self.n_batches, self.n_evals = max(walks), int(counts[:, 3].sum())
         stuck = np.nonzero(counts[:, 0] == 0)[0]
         if stuck.size:        # a chain that never moved returns a fresh draw from the prior, as on the host
             import torch
@@ -426,8 +432,8 @@ class EnsembleWalkSampler(_LockstepWalk):
             self.n_evals += int(stuck.size)
         out = []
         for q in range(n):
-            blob = {"accept": int(counts[q, 0]), "reject": int(walks[0] - counts[q, 0]), "scale": getattr(args_list[q], "scale", 1.0),
-                    "walks": int(walks[0])}
+            blob = {"accept": int(counts[q, 0]), "reject": int(walks[q] - counts[q, 0]), "scale": getattr(args_list[q], "scale", 1.0),
+                    "walks": int(walks[q])}
             out.append(SamplerReturn(u[q], v[q], float(logl[q]), int(counts[q, 3]), blob))
         return out
 

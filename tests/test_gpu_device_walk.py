@@ -194,6 +194,13 @@ def test_pool_map_takes_the_device_walk(torch_cuda):
     assert du < 1e-9
     assert [g[4]["accept"] for g in got] == [r[4]["accept"] for r in ref]
 
+    # chains queued with different walk lengths share the launches: each stops after its own
+    args_mixed = [smp.SamplerArgument(live[i].copy(), -1e6, 50 + i, pt, None, dict(live=live, walks=4 + (i % 9))) for i in range(n)]
+    got_m, ref_m = pool.map(w.sample, args_mixed), host_pool.map(w.sample, args_mixed)
+    assert [g[4]["walks"] for g in got_m] == [4 + (i % 9) for i in range(n)]
+    assert [g[4]["accept"] for g in got_m] == [r[4]["accept"] for r in ref_m]
+    assert np.max(np.abs(np.stack([g[0] for g in got_m]) - np.stack([r[0] for r in ref_m]))) < 1e-9
+
     class Odd(UniformPrior):            # a prior the device has no formula for: the pool falls back to the host walk
         pass
     Odd.__name__ = "Tabulated"
