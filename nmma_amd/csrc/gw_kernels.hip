@@ -910,7 +910,7 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
         }
         const int N2 = (int)(N / GW_TM_N1);
         if (h->tm_buf == nullptr) {
-            const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)1 << 28) / (N * 16)));      // 2 x <= 256 MiB
+            const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)1 << 30) / (N * 16)));      // 2 x <= 1 GiB (of 288 GB)
             GW_HIP(hipMalloc(reinterpret_cast<void**>(&h->tm_buf), (size_t)2 * batch * N * sizeof(double2)));
             h->tm_batch = batch;
         }
