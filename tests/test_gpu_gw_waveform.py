@@ -262,6 +262,26 @@ def test_reference_constructor_with_time_marginalisation(torch_cuda):
     assert np.abs(gotj - got).max() > 1e-6 * np.abs(got).max() * 1e-3        # the jitter does move the value
 
 
+def test_time_marginalisation_on_a_long_segment(torch_cuda):
+    """65 536 time shifts (a 1024 x 64 decomposition), prior support 0.3 s wide away from the segment's ends: index arithmetic of
+    the pruned second stage at a size close to config 5's (1024 x 256)."""
+    from nmma_amd.gw import GWEngine
+    from nmma_amd.gw.gw_likelihood import time_marginalization_weights
+    from tests.helpers import UniformPrior
+    case = make_case(duration=32.0, sampling_frequency=4096.0, ifo_names=("H1",))
+    names = [n for n in syn.GW_NAMES if n != "geocent_time"]
+    t0 = case["injection"]["geocent_time"]
+    tm = time_marginalization_weights(UniformPrior(t0 - 0.2, t0 + 0.1), case["start_time"], case["duration"], len(case["frequency_array"]))
+    assert tm.shape == (65536,)
+    _, theta = syn.draw_gw_theta(44, 3, centre=case["injection"], names=names)
+    fixed = dict(geocent_time=case["start_time"])
+    eng = GWEngine(case["ifos"], names, fixed=fixed, waveform_arguments=case["waveform_arguments"], time_marginalization=tm)
+    got = eng.loglike_ratio(theta).cpu().numpy()
+    want = oracle_loglike_ratio(case, names, theta, fixed, time_marginalization=tm)
+    assert _rel(got, want).max() <= GW_RTOL and want.max() > 10.0
+    eng.close()
+
+
 def test_reference_shaped_likelihood_and_joint_sum(torch_cuda):
     """GravitationalWaveTransientLikelihood (the reference's constructor) per sample and batched, alone and inside
     MultiMessengerLikelihood next to an external messenger."""
