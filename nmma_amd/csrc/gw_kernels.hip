@@ -453,40 +453,47 @@ __global__ __launch_bounds__(256) void gw_strain_kernel(const GwDev* __restrict_
 // gw_tm_fft_kernel / gw_tm_shift_kernel: its FFT, pruned to the shifts the time prior supports; gw_tm_term_kernel: the terms of the
 //   time sum, one thread per (row, shift); gw_tm_logsum_kernel: log sum_j w_j exp(x_j), one workgroup per row.
 // =======================================================================================
+constexpr int GW_TM_ROWS = 16;      // rows per workgroup of gw_integrand_kernel: a bin's basis and data are loaded once for all of them
 template <int NIFO>
 __global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restrict__ Pp, const gw::GwSource* __restrict__ src, const long b0,
                                                            const long nb, double2* __restrict__ out) {
     const GwDev& P = *Pp;
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long bl = blockIdx.y;
     const long N = P.n_freq - 1;
     if (k >= N) return;
-    double2 acc = make_double2(0.0, 0.0);
     const long i = k - P.k0;
-    if (bl < nb && i >= 0 && i < P.n_bins) {
+    const bool in_band = i >= 0 && i < P.n_bins;
+    gw::GwBin bin;
+    bin.f = (double)k * P.df;
+    double4 wd[NIFO];
+    if (in_band) {
+        const double4 bs = P.basis[i];
+        bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
+        bin.p578 = P.basis5[i];
+#pragma unroll
+        for (int d = 0; d < NIFO; ++d) wd[d] = P.dat[(long)d * P.n_bins + i];      // {w d_re, w d_im, w, 0}
+    }
+    for (int r = 0; r < GW_TM_ROWS; ++r) {
+        const long bl = (long)blockIdx.y * GW_TM_ROWS + r;
+        if (bl >= nb) break;
+        double2 acc = make_double2(0.0, 0.0);
         const gw::GwSource& S = src[b0 + bl];
-        if (S.valid != 0.0) {
-            gw::GwBin bin;
-            bin.f = (double)k * P.df;
-            const double4 bs = P.basis[i];
-            bin.f13 = bs.x; bin.inv13 = bs.y; bin.lnf13 = bs.z; bin.fm76 = bs.w;
-            bin.p578 = P.basis5[i];
+        if (in_band && S.valid != 0.0) {
             double amp = 0.0, ph = 0.0;
             gw::eval_bin(S, bin, amp, ph);
 #pragma unroll
             for (int d = 0; d < NIFO; ++d) {
-                const double4 wd = P.dat[(long)d * P.n_bins + i];      // {w d_re, w d_im, w, 0}
                 double t = -(ph + 2.0 * bin.f * S.dt[d]);
                 t -= 2.0 * rint(0.5 * t);
                 double sn, cs;
                 sincospi(t, &sn, &cs);
                 const double hr = amp * (S.k_re[d] * cs - S.k_im[d] * sn), hi = amp * (S.k_re[d] * sn + S.k_im[d] * cs);
-                acc.x += wd.x * hr + wd.y * hi;                        // conj(d) h w
-                acc.y += wd.x * hi - wd.y * hr;
+                acc.x += wd[d].x * hr + wd[d].y * hi;                        // conj(d) h w
+                acc.y += wd[d].x * hi - wd[d].y * hr;
             }
         }
+        out[bl * N + k] = acc;
     }
-    out[bl * N + k] = acc;
 }
 
 // First stage of the N = GW_TM_N1 x N2 decomposition (k = N2 k1 + k2, j = j1 + GW_TM_N1 j2): one workgroup per (k2, row) gathers
@@ -494,31 +501,45 @@ __global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restri
 // exp(-2 pi i j1 k2 / N) and stores G[row][k2][j1].  The second stage is pruned: gw_tm_shift_kernel sums over k2 only for the shifts
 // j the time prior supports (a few hundred of the 2.6e5 of config 5).
 constexpr int GW_TM_N1 = 1024;
+constexpr int GW_TM_K2B = 4;        // residues k2 per workgroup: the gather then reads whole 64-byte sectors (one k2 alone reads 16 of every 64)
 __global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restrict__ I, const long N, const int N2, double2* __restrict__ G) {
-    __shared__ double2 x[GW_TM_N1];
-    const int k2 = blockIdx.x;
+    __shared__ double2 x[GW_TM_K2B][GW_TM_N1];
+    __shared__ double2 tw[GW_TM_N1 / 2];                  // exp(-2 pi i k / 1024), k < 512: every stage's twiddles (stride 1024 / len)
+    for (int k = threadIdx.x; k < GW_TM_N1 / 2; k += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)k / (double)GW_TM_N1, &sn, &cs);
+        tw[k] = make_double2(cs, sn);
+    }
+    const int k2b = blockIdx.x * GW_TM_K2B;
     const long bl = blockIdx.y;
     const double2* Ib = I + bl * N;
-    for (int t = threadIdx.x; t < GW_TM_N1; t += 256) x[__brev((unsigned)t) >> 22] = Ib[(long)N2 * t + k2];      // bit-reversed (10 bits)
+    for (int idx = threadIdx.x; idx < GW_TM_K2B * GW_TM_N1; idx += 256) {
+        const int q = idx % GW_TM_K2B, t = idx / GW_TM_K2B;
+        x[q][__brev((unsigned)t) >> 22] = (k2b + q < N2) ? Ib[(long)N2 * t + k2b + q] : make_double2(0.0, 0.0);      // bit-reversed (10 bits)
+    }
     __syncthreads();
     for (int len = 2; len <= GW_TM_N1; len <<= 1) {
         const int half = len >> 1;
-        for (int t = threadIdx.x; t < GW_TM_N1 / 2; t += 256) {
+        for (int idx = threadIdx.x; idx < GW_TM_K2B * (GW_TM_N1 / 2); idx += 256) {
+            const int q = idx / (GW_TM_N1 / 2), t = idx - q * (GW_TM_N1 / 2);
             const int grp = t / half, pos = t - grp * half;
             const int i0 = grp * len + pos, i1 = i0 + half;
-            double sn, cs;
-            sincospi(-2.0 * (double)pos / (double)len, &sn, &cs);
-            const double2 a = x[i0], c = x[i1];
+            const double2 e = tw[pos * (GW_TM_N1 / len)];
+            const double cs = e.x, sn = e.y;
+            const double2 a = x[q][i0], c = x[q][i1];
             const double2 w = make_double2(c.x * cs - c.y * sn, c.x * sn + c.y * cs);
-            x[i0] = make_double2(a.x + w.x, a.y + w.y);
-            x[i1] = make_double2(a.x - w.x, a.y - w.y);
+            x[q][i0] = make_double2(a.x + w.x, a.y + w.y);
+            x[q][i1] = make_double2(a.x - w.x, a.y - w.y);
         }
         __syncthreads();
     }
-    for (int j1 = threadIdx.x; j1 < GW_TM_N1; j1 += 256) {
+    for (int idx = threadIdx.x; idx < GW_TM_K2B * GW_TM_N1; idx += 256) {
+        const int q = idx / GW_TM_N1, j1 = idx - q * GW_TM_N1;
+        const int k2 = k2b + q;
+        if (k2 >= N2) continue;
         double sn, cs;
         sincospi(-2.0 * ((double)j1 * (double)k2) / (double)N, &sn, &cs);
-        const double2 v = x[j1];
+        const double2 v = x[q][j1];
         G[(bl * N2 + k2) * GW_TM_N1 + j1] = make_double2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
     }
 }
@@ -920,14 +941,15 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
                            P.n_chunks, h->tm_parts);
         for (int64_t b0 = 0; b0 < B; b0 += h->tm_batch) {
             const int64_t nb = std::min<int64_t>(h->tm_batch, B - b0);
-            const dim3 g((unsigned)((N + 255) / 256), (unsigned)nb);
+            const dim3 g((unsigned)((N + 255) / 256), (unsigned)((nb + GW_TM_ROWS - 1) / GW_TM_ROWS));
             switch (P.n_ifo) {
                 case 1: hipLaunchKernelGGL(gw_integrand_kernel<1>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
                 case 2: hipLaunchKernelGGL(gw_integrand_kernel<2>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
                 case 3: hipLaunchKernelGGL(gw_integrand_kernel<3>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
                 default: hipLaunchKernelGGL(gw_integrand_kernel<4>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
             }
-            hipLaunchKernelGGL(gw_tm_fft_kernel, dim3((unsigned)N2, (unsigned)nb), dim3(256), 0, s, integrand, (long)N, N2, stage1);
+            hipLaunchKernelGGL(gw_tm_fft_kernel, dim3((unsigned)((N2 + GW_TM_K2B - 1) / GW_TM_K2B), (unsigned)nb), dim3(256), 0, s, integrand, (long)N, N2,
+                               stage1);
             hipLaunchKernelGGL(gw_tm_shift_kernel, dim3((unsigned)nb), dim3(256), 0, s, h->dev_d, stage1, (long)b0, N2, h->tm_F);
         }
         const int64_t pairs = B * (P.tm_hi - P.tm_lo);
