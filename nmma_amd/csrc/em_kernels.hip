@@ -31,7 +31,12 @@
 //   Downstream: lane groups walk the ragged data of a filter; every datum brackets its
 //   epoch on the redshifted grid and reconstructs ONLY the light-curve nodes it
 //   interpolates between (2, or 4 when sample_times differ from the SVD grid) -- the
-//   same arithmetic per node as the dense reconstruction.
+//   same arithmetic per node as the dense reconstruction.  Filters with so many points that
+//   this reconstructs more rows per sample than the sample grid has nodes take the dense task
+//   instead (FASTM = 6): the four tasks of (item, 16 samples) reconstruct every node on the fp64
+//   matrix cores into an LDS buffer and a datum reads its two node magnitudes.  Small batches
+//   are launched one workgroup per (tile, observed band); the band that finishes a tile last
+//   adds the bands in the fused epilogue's order (release / acquire at agent scope).
 //
 // em_fused<MODE, R, WPB, KP>  (auxiliary outputs: coefficients, full light curves for
 //   gen_detector_lc) shares the MLP scheme with all waves on the MFMA pipe first.
