@@ -260,6 +260,9 @@ def main():
                                      "exchange": exchange_label(other), "kernel_ms": o_ms}
         if not args.no_cpu_baseline and world == 1:      # (the profiled command lines pass --no-cpu-baseline: device launches only)
             line["host_call_ms"] = host_call_ms(eng, case, syn)
+            ms = device_walk_step_ms(eng, case, syn)
+            line["device_walk"] = {"chains": 4096, "ms_per_mcmc_step": ms, "evals_per_s": 4096 / (ms * 1e-3),
+                                   "what": "lock-step ensemble walk on the device: propose -> likelihood -> accept, three launches per step"}
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)
@@ -291,6 +294,31 @@ def host_call_ms(eng, case, syn):
             vals.append(1e3 * (time.perf_counter() - t0) / per_chunk)
         res[f"batch_{b}"] = float(np.median(vals))
     return res
+
+
+def device_walk_step_ms(eng, case, syn, n=4096, steps=200):
+    """One MCMC step of the lock-step ensemble walk on the device -- proposal + prior transform, the likelihood launch, accept:
+    three launches (nmma_amd.sampler.device_walk) -- for `n` chains.  Context for the sampler seam; never `value`."""
+    import numpy as np
+    import torch
+    from nmma_amd import sampler as smp
+
+    class Uniform:          # (the analytic prior the device table recognises by name)
+        def __init__(self, lo, hi):
+            self.minimum, self.maximum = float(lo), float(hi)
+
+    names = case["names"]
+    th = syn.draw_theta(3, 20000, names)[1]
+    table = smp.device_prior_table({k: Uniform(a, b) for k, a, b in zip(names, th.min(axis=0), th.max(axis=0))}, names)
+    live = np.random.default_rng(11).uniform(0.3, 0.7, (n, len(names)))
+    bound = np.full(n, -1e5)
+    keys = np.arange(1000, 1000 + n, dtype=np.uint64)
+    buf = torch.empty(n, dtype=torch.float64, device=f"cuda:{eng.device}")
+    ll = lambda t: eng.loglike(t, out=buf)
+    smp.device_walk(table, live, live, bound, keys, 20, ll, device=eng.device)
+    t0 = time.perf_counter()
+    smp.device_walk(table, live, live, bound, keys, steps, ll, device=eng.device)
+    return 1e3 * (time.perf_counter() - t0) / steps
 
 
 def _oracle_rows():
