@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void gw_integrand_kernel(const GwDev* __restri
 // j the time prior supports (a few hundred of the 2.6e5 of config 5).
 constexpr int GW_TM_N1 = 1024;
 constexpr int GW_TM_K2B = 4;        // residues k2 per workgroup: the gather then reads whole 64-byte sectors (one k2 alone reads 16 of every 64)
-__global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restrict__ I, const long N, const int N2, double2* __restrict__ G) {
+__global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restrict__ I, const long N, const int N2, const int j1_first,
+                                                       const int j1_count, double2* __restrict__ G) {
     __shared__ double2 x[GW_TM_K2B][GW_TM_N1];
     __shared__ double2 tw[GW_TM_N1 / 2];                  // exp(-2 pi i k / 1024), k < 512: every stage's twiddles (stride 1024 / len)
     for (int k = threadIdx.x; k < GW_TM_N1 / 2; k += 256) {
@@ -537,6 +538,8 @@ __global__ __launch_bounds__(256) void gw_tm_fft_kernel(const double2* __restric
         const int q = idx / GW_TM_N1, j1 = idx - q * GW_TM_N1;
         const int k2 = k2b + q;
         if (k2 >= N2) continue;
+        // (only the residues j1 = j mod 1024 of the shifts the time prior supports are read by the second stage)
+        if (((j1 - j1_first) & (GW_TM_N1 - 1)) >= j1_count) continue;
         double sn, cs;
         sincospi(-2.0 * ((double)j1 * (double)k2) / (double)N, &sn, &cs);
         const double2 v = x[q][j1];
@@ -948,8 +951,9 @@ static int32_t gw_run(nmma_gw_handle* h, const double* theta_dev, int64_t B, int
                 case 3: hipLaunchKernelGGL(gw_integrand_kernel<3>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
                 default: hipLaunchKernelGGL(gw_integrand_kernel<4>, g, dim3(256), 0, s, h->dev_d, h->src, (long)b0, (long)nb, integrand); break;
             }
+            const int64_t n_sup = P.tm_hi - P.tm_lo;
             hipLaunchKernelGGL(gw_tm_fft_kernel, dim3((unsigned)((N2 + GW_TM_K2B - 1) / GW_TM_K2B), (unsigned)nb), dim3(256), 0, s, integrand, (long)N, N2,
-                               stage1);
+                               (int)(P.tm_lo & (GW_TM_N1 - 1)), (int)std::min<int64_t>(n_sup, GW_TM_N1), stage1);
             hipLaunchKernelGGL(gw_tm_shift_kernel, dim3((unsigned)nb), dim3(256), 0, s, h->dev_d, stage1, (long)b0, N2, h->tm_F);
         }
         const int64_t pairs = B * (P.tm_hi - P.tm_lo);
