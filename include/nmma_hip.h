@@ -357,6 +357,14 @@ int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const dou
 int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
                          const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
                          int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step, int32_t device, void* stream);
+/* The accept step of AcceptanceTrackingRWalk ("rwalk", core/mpi_setup.py:234-245): chains with active_dev[c] != 0 are accepted /
+ * rejected as in nmma_walk_accept, then act_dev[c] (the autocorrelation estimate from the running acceptance ratio, bilby's
+ * estimate_nmcmc with safety 1, smoothed over tau calls with old_act; old_act < 0: none) and active_dev[c] = (step < nact * act and
+ * accept + reject <= maxmcmc) are updated.  Start with act = +inf, active = 1. */
+int32_t nmma_walk_accept_rwalk(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
+                               const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
+                               int32_t* counts_dev, double* act_dev, int32_t* active_dev, uint64_t step, double nact, int32_t maxmcmc,
+                               double tau, double old_act, int32_t device, void* stream);
 /* theta = prior transform of u[n][ndim] (start points, fresh prior draws). */
 int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
                           void* stream);

@@ -104,6 +104,44 @@ __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const lon
     } else cnt[1] += 1;
 }
 
+// The accept step of bilby's AcceptanceTrackingRWalk ("rwalk", mpi_setup.py:234-245): as walk_accept_kernel for the chains still
+// running, then the chain's autocorrelation estimate from its running acceptance ratio (bilby dynesty_utils.estimate_nmcmc with
+// safety = 1, smoothed over tau calls with the estimate old_act the previous queue left behind; old_act < 0: none) and whether it
+// goes on: step < nact * act and accept + reject <= maxmcmc (sampler.py: AcceptanceTrackingRWalk._after_step / _continues).
+__global__ __launch_bounds__(256) void walk_accept_rwalk_kernel(const int D, const long n, const double* __restrict__ prop,
+                                                                const double* __restrict__ theta, const int32_t* __restrict__ inside,
+                                                                const double* __restrict__ l_prop, const double* __restrict__ loglstar,
+                                                                double* __restrict__ u, double* __restrict__ v, double* __restrict__ logl,
+                                                                int32_t* __restrict__ counts, double* __restrict__ act,
+                                                                int32_t* __restrict__ active, const uint64_t step, const double nact,
+                                                                const int32_t maxmcmc, const double tau, const double old_act) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n || !active[c]) return;
+    int32_t* cnt = counts + 4 * c;                          // {accept, reject, nfail, ncall}
+    if (!inside[c]) cnt[2] += 1;
+    else {
+        cnt[3] += 1;
+        if (l_prop[c] > loglstar[c]) {
+            for (int d = 0; d < D; ++d) { u[c * D + d] = prop[c * D + d]; v[c * D + d] = theta[c * D + d]; }
+            logl[c] = l_prop[c];
+            cnt[0] += 1;
+        } else cnt[1] += 1;
+    }
+    const double a = (double)cnt[0], r = (double)cnt[1], f = (double)cnt[2];
+    if (a + r > nact) {
+        const double ratio = a / (a + r + f);
+        double n_exact;
+        if (ratio == 0.0) n_exact = old_act < 0.0 ? HUGE_VAL : (1.0 + 1.0 / tau) * old_act;
+        else {
+            n_exact = 2.0 / ratio - 1.0;                      // safety = 1
+            if (old_act >= 0.0) n_exact = (1.0 - 1.0 / tau) * old_act + n_exact / tau;
+        }
+        const double capped = n_exact < (double)maxmcmc ? n_exact : (double)maxmcmc;
+        act[c] = capped > 1.0 ? capped : 1.0;
+    }
+    active[c] = ((double)step < nact * act[c] && cnt[0] + cnt[1] <= maxmcmc) ? 1 : 0;
+}
+
 // the prior transform alone (start points, fresh draws): theta = rescale(u)
 __global__ __launch_bounds__(256) void walk_rescale_kernel(const WalkSpec S, const long n, const double* __restrict__ u, double* __restrict__ theta) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +192,23 @@ int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const 
                        prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, n_steps_dev, step);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_accept launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_walk_accept_rwalk(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
+                               const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
+                               int32_t* counts_dev, double* act_dev, int32_t* active_dev, uint64_t step, double nact, int32_t maxmcmc,
+                               double tau, double old_act, int32_t device, void* stream) {
+    using namespace nmma;
+    if (ndim < 1 || ndim > NMMA_WALK_MAX_DIM || n < 0 || !prop_dev || !theta_dev || !inside_dev || !logl_prop_dev || !loglstar_dev || !u_dev ||
+        !v_dev || !logl_dev || !counts_dev || !act_dev || !active_dev || !(tau > 0) || maxmcmc < 1) return fail("nmma_walk_accept_rwalk: bad argument");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_accept_rwalk: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_accept_rwalk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim,
+                       (long)n, prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, act_dev, active_dev,
+                       step, nact, maxmcmc, tau, old_act);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_accept_rwalk launch failed: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -255,6 +255,24 @@ class _LockstepWalk:
         self._finish(st)
         return [SamplerReturn(u[q], v[q], float(logl[q]), int(st["ncall"][q]), self._blob(st, q, args_list[q])) for q in range(n)]
 
+    def _device_fresh_draws(self, stuck, table, rseeds, u, v, logl, counts, loglike_device, device):
+        """A chain of a device walk that never moved returns a fresh draw from the prior, as on the host (``run_many``)."""
+        if not stuck.size:
+            return
+        import torch
+        from . import _lib as L
+        lib = L.load_library()
+        fresh = counter_uniforms(rseeds[stuck], np.zeros(stuck.size, dtype=np.uint64), max(N_DRAWS, u.shape[1]))[:, :u.shape[1]]
+        fu = torch.as_tensor(np.ascontiguousarray(fresh), device=f"cuda:{int(device)}")
+        fv = torch.empty_like(fu)
+        L.check(lib.nmma_walk_rescale(table, u.shape[1], C_void(fu.data_ptr()), stuck.size, C_void(fv.data_ptr()), int(device),
+                                      C_void(torch.cuda.current_stream(fu.device).cuda_stream)), "nmma_walk_rescale")
+        u[stuck], v[stuck] = fresh, fv.cpu().numpy()
+        logl[stuck] = loglike_device(fv).cpu().numpy()
+        counts[stuck, 3] += 1
+        self.n_batches += 1
+        self.n_evals += int(stuck.size)
+
     # ---- hooks ----------------------------------------------------------------------------------------------------------
     def _init_state(self, st, args_list, u):
         pass
@@ -365,6 +383,46 @@ def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device
     return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy()
 
 
+def device_rwalk(table, live, u0, loglstar, keys, nact, maxmcmc, tau, old_act, loglike_device, device=0, poll=8):
+    """The acceptance-tracking walk (``AcceptanceTrackingRWalk``) of ``len(u0)`` chains on the GPU: each chain runs until ``nact``
+    of its autocorrelation estimates have passed (``nmma_walk_accept_rwalk``); the host only reads the number of chains still
+    running every ``poll`` steps (a finished chain's remaining launches are no-ops for it).  Returns host arrays (u, v, logl,
+    counts[n, 4], act[n], steps taken)."""
+    import torch
+    from . import _lib as L
+    lib = L.load_library()
+    dev = torch.device(f"cuda:{int(device)}")
+    live_d = torch.as_tensor(np.ascontiguousarray(live, dtype=np.float64), device=dev)
+    u = torch.as_tensor(np.ascontiguousarray(u0, dtype=np.float64), device=dev)
+    n, ndim = u.shape
+    star = torch.as_tensor(np.ascontiguousarray(loglstar, dtype=np.float64), device=dev)
+    key = torch.as_tensor(np.ascontiguousarray(keys, dtype=np.uint64).view(np.int64), device=dev)
+    v, prop, theta = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    logl = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    act = torch.full((n,), float("inf"), dtype=torch.float64, device=dev)
+    inside = torch.empty(n, dtype=torch.int32, device=dev)
+    active = torch.ones(n, dtype=torch.int32, device=dev)
+    counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    stream = C_void(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: C_void(t.data_ptr())
+    L.check(lib.nmma_walk_rescale(table, ndim, ptr(u), n, ptr(v), int(device), stream), "nmma_walk_rescale")
+    p_live, p_u, p_v, p_key, p_prop, p_theta, p_in = ptr(live_d), ptr(u), ptr(v), ptr(key), ptr(prop), ptr(theta), ptr(inside)
+    p_star, p_logl, p_cnt, p_act, p_on, n_live, dev_i = ptr(star), ptr(logl), ptr(counts), ptr(act), ptr(active), live_d.shape[0], int(device)
+    old = -1.0 if old_act is None else float(old_act)
+    s = 0
+    while True:
+        s += 1
+        L.check(lib.nmma_walk_propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, s, p_prop, p_theta, p_in, dev_i, stream), "nmma_walk_propose")
+        l_prop = loglike_device(theta)
+        if l_prop.dtype != torch.float64 or not l_prop.is_contiguous():
+            l_prop = l_prop.to(torch.float64).contiguous()
+        L.check(lib.nmma_walk_accept_rwalk(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_act, p_on, s, float(nact),
+                                           int(maxmcmc), float(tau), old, dev_i, stream), "nmma_walk_accept_rwalk")
+        if s % int(poll) == 0 and int(active.sum().item()) == 0:
+            break
+    return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy(), act.cpu().numpy(), s
+
+
 def C_void(x):
     import ctypes
     return ctypes.c_void_p(int(x))
@@ -415,21 +473,7 @@ class EnsembleWalkSampler(_LockstepWalk):
         same = len(set(walks)) == 1
         u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, walks[0] if same else np.array(walks), loglike_device, device=device)
         self.n_batches, self.n_evals = max(walks), int(counts[:, 3].sum())
-        stuck = np.nonzero(counts[:, 0] == 0)[0]
-        if stuck.size:        # a chain that never moved returns a fresh draw from the prior, as on the host
-            import torch
-            from . import _lib as L
-            lib = L.load_library()
-            fresh = counter_uniforms(rseeds[stuck], np.zeros(stuck.size, dtype=np.uint64), max(N_DRAWS, u.shape[1]))[:, :u.shape[1]]
-            fu = torch.as_tensor(np.ascontiguousarray(fresh), device=f"cuda:{int(device)}")
-            fv = torch.empty_like(fu)
-            L.check(lib.nmma_walk_rescale(table, u.shape[1], C_void(fu.data_ptr()), stuck.size, C_void(fv.data_ptr()), int(device),
-                                          C_void(torch.cuda.current_stream(fu.device).cuda_stream)), "nmma_walk_rescale")
-            u[stuck], v[stuck] = fresh, fv.cpu().numpy()
-            logl[stuck] = loglike_device(fv).cpu().numpy()
-            counts[stuck, 3] += 1
-            self.n_batches += 1
-            self.n_evals += int(stuck.size)
+        self._device_fresh_draws(np.nonzero(counts[:, 0] == 0)[0], table, rseeds, u, v, logl, counts, loglike_device, device)
         # (plain Python numbers from three tolist() calls: building 4096 records costs ~2 ms this way, ~5 ms through numpy scalars)
         acc, ncall, ll = counts[:, 0].tolist(), counts[:, 3].tolist(), logl.tolist()
         scales = [getattr(a, "scale", 1.0) for a in args_list]
@@ -479,6 +523,34 @@ class AcceptanceTrackingRWalk(_LockstepWalk):
 
     def _stuck(self, st):
         return ~(np.isfinite(st["act"]) & (st["accept"] > 0))
+
+    def run_many_device(self, args_list, loglike_device, priors, keys, device=0, loglike_many=None, prior_transform_many=None):
+        """``run_many`` with the walk on the GPU (``device_rwalk``): the per-chain autocorrelation estimate and stop rule are
+        evaluated in the accept kernel.  Queues the device cannot take (a prior without a device formula, per-chain ensembles or
+        smoothing lengths) go to the host walk."""
+        n = len(args_list)
+        if n == 0:
+            return []
+        live = _live_points(args_list[0])
+        shared = all(_live_points(a) is live for a in args_list[1:])
+        taus = {float(a.kwargs.get("nlive") or a.kwargs.get("walks") or 100) for a in args_list}
+        table = device_prior_table(priors, keys, self.periodic, self.reflective)
+        if table is None or not shared or len(taus) != 1 or np.asarray(live).shape[0] < 3:
+            if loglike_many is None:
+                raise ValueError("this queue needs the host walk: pass loglike_many (and prior_transform_many)")
+            return self.run_many(args_list, loglike_many, prior_transform_many)
+        rseeds = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
+        u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
+        loglstar = np.array([a.loglstar for a in args_list], dtype=float)
+        u, v, logl, counts, act, steps = device_rwalk(table, live, u0, loglstar, rseeds, self.nact, self.maxmcmc, taus.pop(), type(self).old_act,
+                                                      loglike_device, device=device)
+        self.n_batches, self.n_evals = steps, int(counts[:, 3].sum())
+        st = dict(act=act, accept=counts[:, 0])
+        self._device_fresh_draws(np.nonzero(self._stuck(st))[0], table, rseeds, u, v, logl, counts, loglike_device, device)
+        self._finish(st)
+        acc, rej, ncall, ll = counts[:, 0].tolist(), (counts[:, 1] + counts[:, 2]).tolist(), counts[:, 3].tolist(), logl.tolist()
+        return [SamplerReturn(u[q], v[q], ll[q], ncall[q], {"accept": acc[q], "reject": rej[q], "scale": getattr(args_list[q], "scale", 1.0)})
+                for q in range(n)]
 
     def _finish(self, st):
         fin = st["act"][np.isfinite(st["act"])]

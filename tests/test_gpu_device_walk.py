@@ -207,3 +207,66 @@ def test_pool_map_takes_the_device_walk(torch_cuda):
     pool2 = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri2)
     again = pool2.map(w.sample, args)
     assert [g[4]["accept"] for g in again] == [r[4]["accept"] for r in ref]
+
+
+def test_acceptance_tracking_rwalk_on_the_device(torch_cuda):
+    """``sample="rwalk"``: the per-chain autocorrelation estimate and stop rule evaluated in the accept kernel give the host walk's
+    chains -- same accept / reject counts, same number of likelihood calls per chain, same estimate left behind for the next queue
+    (first queue: no previous estimate; second queue: smoothed with the first's)."""
+    torch = torch_cuda
+    ndim, n, n_live = 5, 1500, 1500
+    pri = {f"p{i}": UniformPrior(-1.0 - i, 2.0 + i) for i in range(ndim)}
+    names = list(pri)
+    pt = smp.BatchedPriorTransform(pri, names)
+    lo = np.array([pri[k].minimum for k in names]); width = np.array([pri[k].maximum - pri[k].minimum for k in names])
+    host_ll = lambda th: -np.sum(((np.asarray(th) - lo) / width - 0.5) ** 2, axis=1) * 40.0
+    lo_d, w_d = torch.as_tensor(lo, device="cuda:0"), torch.as_tensor(width, device="cuda:0")
+    dev_ll = lambda th: -torch.sum(((th - lo_d) / w_d - 0.5) ** 2, dim=1) * 40.0
+    rng = np.random.default_rng(21)
+    live = 0.5 + 0.12 * rng.standard_normal((n_live, ndim))
+    live = np.clip(live, 0.01, 0.99)
+    bound = np.quantile(host_ll(pt(live)), 0.3)
+    kw = dict(live=live, nlive=n_live)
+    args = [smp.SamplerArgument(live[i].copy(), bound, 7000 + i, pt, None, kw) for i in range(n)]
+    cls = smp.AcceptanceTrackingRWalk
+    results = {}
+    for where in ("host", "device"):
+        cls.old_act = None
+        w = cls(ndim=ndim, periodic=[0], reflective=[2], maxmcmc=400, nact=6)
+        out = []
+        for _ in range(2):
+            if where == "host":
+                out.append(w.run_many(args, host_ll, pt))
+            else:
+                out.append(w.run_many_device(args, dev_ll, pri, names))
+            out.append(cls.old_act)
+        results[where] = out
+    cls.old_act = None
+    for q in (0, 2):
+        got, ref = results["device"][q], results["host"][q]
+        same = [g[4] == r[4] and g[3] == r[3] for g, r in zip(got, ref)]
+        assert np.mean(same) > 0.995                     # (a proposal within an ulp of the bound may fall either way)
+        ok = np.nonzero(same)[0]
+        du = np.max(np.abs(np.stack([got[i][0] for i in ok]) - np.stack([ref[i][0] for i in ok])))
+        assert du < 1e-9
+        assert results["device"][q + 1] == pytest.approx(results["host"][q + 1], rel=1e-3)
+        logl = np.array([g[2] for g in got])
+        moved = np.array([g[4]["accept"] > 0 for g in got])       # (a chain that never moved returns a fresh prior draw)
+        assert moved.mean() > 0.9 and np.all(logl[moved] > bound)
+        assert np.allclose(logl, host_ll(np.stack([g[1] for g in got])), rtol=1e-12)
+    lengths = np.array([g[3] for g in results["device"][0]])
+    assert lengths.min() < lengths.max()                 # chains stop at their own times
+    assert results["device"][1] != results["device"][3]  # and the second queue was smoothed with the first's estimate
+
+    # through the pool: the unmodified pool.map(sample, queue) takes the device walk for this walker too
+    from nmma_amd.pool import GPUPool
+
+    class _Lik:
+        def log_likelihood_batch(self, th, names=None):
+            return dev_ll(th)
+    pool = GPUPool(_Lik(), queue_size=n, names=names, prior_transform_many=pt, priors=pri)
+    cls.old_act = None
+    w = cls(ndim=ndim, periodic=[0], reflective=[2], maxmcmc=400, nact=6)
+    via_pool = pool.map(w.sample, args)
+    cls.old_act = None
+    assert [g[4] for g in via_pool] == [g[4] for g in results["device"][0]]
