@@ -262,7 +262,7 @@ def main():
             line["host_call_ms"] = host_call_ms(eng, case, syn)
             ms = device_walk_step_ms(eng, case, syn)
             line["device_walk"] = {"chains": 4096, "ms_per_mcmc_step": ms, "evals_per_s": 4096 / (ms * 1e-3),
-                                   "what": "lock-step ensemble walk on the device: propose -> likelihood -> accept, three launches per step"}
+                                   "what": "lock-step ensemble walk on the device: likelihood -> accept + next proposal, two launches per step"}
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)
@@ -298,7 +298,7 @@ def host_call_ms(eng, case, syn):
 
 def device_walk_step_ms(eng, case, syn, n=4096, steps=200):
     """One MCMC step of the lock-step ensemble walk on the device -- proposal + prior transform, the likelihood launch, accept:
-    three launches (nmma_amd.sampler.device_walk) -- for `n` chains.  Context for the sampler seam; never `value`."""
+    two launches (nmma_amd.sampler.device_walk) -- for `n` chains.  Context for the sampler seam; never `value`."""
     import numpy as np
     import torch
     from nmma_amd import sampler as smp

@@ -357,6 +357,12 @@ int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const dou
 int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const double* theta_dev, const int32_t* inside_dev,
                          const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
                          int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step, int32_t device, void* stream);
+/* nmma_walk_accept for the walk's step number `step` (1-based) followed by nmma_walk_propose for the next one (random-number step
+ * first_step + step) in ONE launch: an MCMC step of the queue is then this launch and the likelihood's. */
+int32_t nmma_walk_step(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const uint64_t* key_dev, int64_t n,
+                       double* prop_dev, double* theta_dev, int32_t* inside_dev, const double* logl_prop_dev, const double* loglstar_dev,
+                       double* u_dev, double* v_dev, double* logl_dev, int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step,
+                       uint64_t first_step, int32_t device, void* stream);
 /* The accept step of AcceptanceTrackingRWalk ("rwalk", core/mpi_setup.py:234-245): chains with active_dev[c] != 0 are accepted /
  * rejected as in nmma_walk_accept, then act_dev[c] (the autocorrelation estimate from the running acceptance ratio, bilby's
  * estimate_nmcmc with safety 1, smoothed over tau calls with old_act; old_act < 0: none) and active_dev[c] = (step < nact * act and

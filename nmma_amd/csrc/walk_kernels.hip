@@ -1,9 +1,9 @@
 // Lock-step ensemble walk on the device (the sampler-side batching seam).
 //
 // The host adapter (nmma_amd/sampler.py: _LockstepWalk.run_many) spends ~0.5 ms of numpy per MCMC step for 4 096 chains -- counter
-// hash, differential-evolution proposal, prior transform, accept bookkeeping -- around a 31 us likelihood launch.  These two
-// kernels move that bookkeeping next to the likelihood: one step is propose -> nmma_*_loglike -> accept, three launches on one
-// stream, no host round trip.  The random numbers are the SAME counter hash as sampler.py:counter_uniforms (SplitMix64 of
+// hash, differential-evolution proposal, prior transform, accept bookkeeping -- around a 31 us likelihood launch.  These
+// kernels move that bookkeeping next to the likelihood: one step is nmma_*_loglike -> accept + next proposal (nmma_walk_step), two
+// launches on one stream, no host round trip.  The random numbers are the SAME counter hash as sampler.py:counter_uniforms (SplitMix64 of
 // (chain key, step, draw)), the proposal is sampler.py:_propose (dynesty's "rwalk"-style differential evolution as
 // bilby/core/sampler/dynesty_utils.py implements it; the reference builds those walker objects at mpi_setup.py:202-245), and the
 // prior transform covers the analytic bilby priors by their published ``rescale`` formulas (bilby/core/prior/analytical.py).
@@ -53,55 +53,111 @@ __device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) 
     }
 }
 
-// one thread per chain: proposal in the unit cube (differential evolution between two other live points), boundary conditions,
-// inside-the-cube flag, prior transform.  A proposal outside the cube keeps the chain's current point in `theta` (the lock-step
-// likelihood launch evaluates every chain; the accept kernel ignores that row).
-__global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
-                                                           const double* __restrict__ u, const double* __restrict__ v,
-                                                           const uint64_t* __restrict__ key, const long n, const uint64_t step,
-                                                           double* __restrict__ prop, double* __restrict__ theta, int32_t* __restrict__ inside) {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const int D = S.ndim;
+// A GROUP of T = 8 / 16 / 32 lanes per chain (the smallest that holds the dimensions: lane d owns dimension d), 256 / T chains per
+// workgroup.  One thread per chain made this kernel a 10 us chain of dependent loads and a serial loop over the dimensions around a
+// 29 us likelihood launch; with a lane per dimension the loads of a row are one coalesced access and the prior transforms run side by
+// side (rocprofv3: 10.1 -> see DESIGN.md section 6).  Every lane draws the chain's seven uniforms itself (integer hashing, no traffic).
+// The prior table is staged from the kernel arguments into LDS so that lanes can index it by their dimension.
+__device__ __forceinline__ int walk_group(const int D) { return D <= 8 ? 8 : D <= 16 ? 16 : 32; }
+
+__device__ __forceinline__ void walk_stage_spec(const WalkSpec& S, nmma_walk_prior* sp) {
+    if (threadIdx.x == 0)
+        for (int d = 0; d < S.ndim; ++d) sp[d] = S.p[d];
+    __syncthreads();
+}
+
+// proposal in the unit cube (differential evolution between two other live points), boundary conditions, inside-the-cube flag, prior
+// transform.  A proposal outside the cube keeps the chain's current point in `theta` (the lock-step likelihood launch evaluates every
+// chain; the accept kernel ignores that row).
+__device__ __forceinline__ void walk_propose_one(const nmma_walk_prior* sp, const int D, const int T, const long c, const int lane,
+                                                 const double* __restrict__ live, const long n_live, const double* u, const double* v,
+                                                 const uint64_t* __restrict__ key, const uint64_t step, double* prop, double* theta,
+                                                 int32_t* inside) {
+    const uint64_t kc = key[c];
     double r[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) r[k] = walk_uniform(key[c], step, (uint64_t)k);
+    for (int k = 0; k < 7; ++k) r[k] = walk_uniform(kc, step, (uint64_t)k);
     long i = (long)(r[0] * (double)n_live);
     i = i > n_live - 1 ? n_live - 1 : i;
     long jj = (long)(r[1] * (double)(n_live - 1));
     jj = jj > n_live - 2 ? n_live - 2 : jj;
     const long j = (i + 1 + jj) % n_live;                                         // a different live point
     const double gamma = r[2] < 0.5 ? 1.0 : 2.38 / sqrt(2.0 * (double)D) * (-0.25 * log(r[3] * r[4] * r[5] * r[6]));   // Gamma(4, 1/4)
-    bool in = true;
-    for (int d = 0; d < D; ++d) {
-        double x = u[c * D + d] + gamma * (live[j * D + d] - live[i * D + d]);
-        if (S.p[d].boundary == NMMA_BOUNDARY_PERIODIC) x = floored_mod(x, 1.0);
-        else if (S.p[d].boundary == NMMA_BOUNDARY_REFLECTIVE) { const double q = floored_mod(x, 2.0); x = q > 1.0 ? 2.0 - q : q; }
-        prop[c * D + d] = x;
-        in = in && (x >= 0.0) && (x <= 1.0);
+    int in = 1;
+    double x = 0.0;
+    if (lane < D) {
+        x = u[c * D + lane] + gamma * (live[j * D + lane] - live[i * D + lane]);
+        const int32_t bc = sp[lane].boundary;
+        if (bc == NMMA_BOUNDARY_PERIODIC) x = floored_mod(x, 1.0);
+        else if (bc == NMMA_BOUNDARY_REFLECTIVE) { const double q = floored_mod(x, 2.0); x = q > 1.0 ? 2.0 - q : q; }
+        prop[c * D + lane] = x;
+        in = (x >= 0.0) && (x <= 1.0);
     }
-    inside[c] = in ? 1 : 0;
-    for (int d = 0; d < D; ++d) theta[c * D + d] = in ? walk_rescale(S.p[d], prop[c * D + d]) : v[c * D + d];
+    for (int m = T >> 1; m > 0; m >>= 1) in &= __shfl_xor(in, m, 64);           // (groups are aligned powers of two: the exchange stays inside)
+    if (lane == 0) inside[c] = in;
+    if (lane < D) theta[c * D + lane] = in ? walk_rescale(sp[lane], x) : v[c * D + lane];
+}
+
+__global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
+                                                           const double* __restrict__ u, const double* __restrict__ v,
+                                                           const uint64_t* __restrict__ key, const long n, const uint64_t step,
+                                                           double* __restrict__ prop, double* __restrict__ theta, int32_t* __restrict__ inside) {
+    __shared__ nmma_walk_prior sp[NMMA_WALK_MAX_DIM];
+    walk_stage_spec(S, sp);
+    const int T = walk_group(S.ndim);
+    const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
+    if (c < n) walk_propose_one(sp, S.ndim, T, c, threadIdx.x % T, live, n_live, u, v, key, step, prop, theta, inside);
 }
 
 // accept when the proposal was inside the cube and its likelihood beats the chain's bound (dynesty: logl > loglstar)
+__device__ __forceinline__ void walk_accept_one(const int D, const long c, const int lane, const double* prop, const double* theta,
+                                                const int32_t* inside, const double* __restrict__ l_prop, const double* __restrict__ loglstar,
+                                                double* u, double* v, double* __restrict__ logl, int32_t* __restrict__ counts,
+                                                const int32_t* __restrict__ n_steps, const uint64_t step) {
+    if (n_steps != nullptr && step > (uint64_t)n_steps[c]) return;       // this chain's walk is over (walk lengths may differ per chain)
+    const int in = inside[c];
+    const double lp = l_prop[c];
+    const bool acc = in && lp > loglstar[c];
+    if (acc && lane < D) { u[c * D + lane] = prop[c * D + lane]; v[c * D + lane] = theta[c * D + lane]; }
+    if (lane == 0) {
+        int32_t* cnt = counts + 4 * c;                      // {accept, reject, nfail, ncall}
+        if (!in) cnt[2] += 1;
+        else {
+            cnt[3] += 1;
+            if (acc) { logl[c] = lp; cnt[0] += 1; }
+            else cnt[1] += 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const long n, const double* __restrict__ prop,
                                                           const double* __restrict__ theta, const int32_t* __restrict__ inside,
                                                           const double* __restrict__ l_prop, const double* __restrict__ loglstar,
                                                           double* __restrict__ u, double* __restrict__ v, double* __restrict__ logl,
                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ n_steps,
                                                           const uint64_t step) {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = walk_group(D);
+    const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
+    if (c < n) walk_accept_one(D, c, threadIdx.x % T, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step);
+}
+
+// accept of step `step` and proposal of step `step + 1` in one launch (a chain's accept touches only its own row, and its next proposal
+// reads that row and the fixed live points; lane d of the group owns element d of both): an MCMC step is then two launches -- this one
+// and the likelihood.  (The group reads inside[c] for the accept before its lane 0 stores the next flag: one wavefront, program order.)
+__global__ __launch_bounds__(256) void walk_step_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
+                                                        const uint64_t* __restrict__ key, const long n, double* prop, double* theta,
+                                                        int32_t* inside, const double* __restrict__ l_prop,
+                                                        const double* __restrict__ loglstar, double* u, double* v, double* __restrict__ logl,
+                                                        int32_t* __restrict__ counts, const int32_t* __restrict__ n_steps, const uint64_t step,
+                                                        const uint64_t first_step) {
+    __shared__ nmma_walk_prior sp[NMMA_WALK_MAX_DIM];
+    walk_stage_spec(S, sp);
+    const int T = walk_group(S.ndim);
+    const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
     if (c >= n) return;
-    if (n_steps != nullptr && step > (uint64_t)n_steps[c]) return;       // this chain's walk is over (walk lengths may differ per chain)
-    int32_t* cnt = counts + 4 * c;                          // {accept, reject, nfail, ncall}
-    if (!inside[c]) { cnt[2] += 1; return; }
-    cnt[3] += 1;
-    if (l_prop[c] > loglstar[c]) {
-        for (int d = 0; d < D; ++d) { u[c * D + d] = prop[c * D + d]; v[c * D + d] = theta[c * D + d]; }
-        logl[c] = l_prop[c];
-        cnt[0] += 1;
-    } else cnt[1] += 1;
+    const int lane = threadIdx.x % T;
+    walk_accept_one(S.ndim, c, lane, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step);
+    walk_propose_one(sp, S.ndim, T, c, lane, live, n_live, u, v, key, first_step + step, prop, theta, inside);
 }
 
 // The accept step of bilby's AcceptanceTrackingRWalk ("rwalk", mpi_setup.py:234-245): as walk_accept_kernel for the chains still
@@ -149,6 +205,11 @@ __global__ __launch_bounds__(256) void walk_rescale_kernel(const WalkSpec S, con
     for (int d = 0; d < S.ndim; ++d) theta[c * S.ndim + d] = walk_rescale(S.p[d], u[c * S.ndim + d]);
 }
 
+static unsigned walk_blocks(int64_t n, int32_t ndim) {       // 256 / T chains per workgroup (walk_group)
+    const int per = 256 / (ndim <= 8 ? 8 : ndim <= 16 ? 16 : 32);
+    return (unsigned)((n + per - 1) / per);
+}
+
 static int walk_spec(const nmma_walk_prior* priors, int32_t ndim, WalkSpec* S, const char* what) {
     if (!priors || ndim < 1 || ndim > NMMA_WALK_MAX_DIM) return fail(std::string(what) + ": 1 .. NMMA_WALK_MAX_DIM dimensions");
     S->ndim = ndim;
@@ -173,7 +234,7 @@ int32_t nmma_walk_propose(const nmma_walk_prior* priors, int32_t ndim, const dou
         return fail("nmma_walk_propose: bad argument (at least three live points)");
     if (n == 0) return 0;
     if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_propose: hipSetDevice failed");
-    hipLaunchKernelGGL(walk_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev,
+    hipLaunchKernelGGL(walk_propose_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev,
                        (long)n_live, u_dev, v_dev, key_dev, (long)n, step, prop_dev, theta_dev, inside_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_propose launch failed: ") + hipGetErrorString(e));
@@ -188,10 +249,29 @@ int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const 
         !v_dev || !logl_dev || !counts_dev) return fail("nmma_walk_accept: bad argument");
     if (n == 0) return 0;
     if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_accept: hipSetDevice failed");
-    hipLaunchKernelGGL(walk_accept_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim, (long)n,
+    hipLaunchKernelGGL(walk_accept_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim, (long)n,
                        prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, n_steps_dev, step);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_accept launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_walk_step(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const uint64_t* key_dev, int64_t n,
+                       double* prop_dev, double* theta_dev, int32_t* inside_dev, const double* logl_prop_dev, const double* loglstar_dev,
+                       double* u_dev, double* v_dev, double* logl_dev, int32_t* counts_dev, const int32_t* n_steps_dev, uint64_t step,
+                       uint64_t first_step, int32_t device, void* stream) {
+    using namespace nmma;
+    WalkSpec S;
+    if (walk_spec(priors, ndim, &S, "nmma_walk_step")) return 1;
+    if (!live_dev || !key_dev || !prop_dev || !theta_dev || !inside_dev || !logl_prop_dev || !loglstar_dev || !u_dev || !v_dev || !logl_dev ||
+        !counts_dev || n < 0 || n_live < 3) return fail("nmma_walk_step: bad argument (at least three live points)");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_step: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_step_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev,
+                       (long)n_live, key_dev, (long)n, prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev,
+                       counts_dev, n_steps_dev, step, first_step);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_step launch failed: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -28,7 +28,7 @@ class GPUPool:
         self.names = names
         self.prior_transform_many = prior_transform_many     # e.g. nmma_amd.sampler.BatchedPriorTransform
         # with the sampled priors (dict name -> bilby prior, `names` = the column order) a fixed-length ensemble walk runs ENTIRELY
-        # on the GPU -- propose -> likelihood -> accept, three launches per MCMC step (nmma_amd.sampler.device_walk) -- when every
+        # on the GPU -- likelihood -> accept + next proposal, two launches per MCMC step (nmma_amd.sampler.device_walk) -- when every
         # prior has a device formula; otherwise, and for the ACT-tracking walkers, the host walk below
         self.priors = priors
         self.device = int(device)

@@ -291,7 +291,7 @@ class _LockstepWalk:
 
 
 # -----------------------------------------------------------------------------------------------------------------------
-# The walk on the device: propose -> likelihood -> accept as three launches per MCMC step, no host round trip
+# The walk on the device: likelihood -> accept + next proposal as two launches per MCMC step, no host round trip
 # -----------------------------------------------------------------------------------------------------------------------
 _PRIOR_KINDS = {"Uniform": "uniform", "Sine": "sine", "Cosine": "cosine", "PowerLaw": "powerlaw", "LogUniform": "loguniform",
                 "Gaussian": "gaussian", "Normal": "gaussian", "DeltaFunction": "delta"}
@@ -371,15 +371,22 @@ def device_walk(table, live, u0, loglstar, keys, n_steps, loglike_device, device
     p_live, p_u, p_v, p_key, p_prop, p_theta, p_in = ptr(live_d), ptr(u), ptr(v), ptr(key), ptr(prop), ptr(theta), ptr(inside)
     p_star, p_logl, p_cnt, n_live, dev_i = ptr(star), ptr(logl), ptr(counts), live_d.shape[0], int(device)
     p_len = ptr(lengths) if per_chain else None
-    propose, accept = lib.nmma_walk_propose, lib.nmma_walk_accept
-    for s in range(int(first_step), int(first_step) + int(n_steps)):
-        if propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, s, p_prop, p_theta, p_in, dev_i, stream):
-            L.check(1, "nmma_walk_propose")
+    first, n_steps = int(first_step), int(n_steps)
+    if n_steps < 1:
+        return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy()
+    # two launches per step: the likelihood, and the accept of step k fused with the proposal of step k + 1 (nmma_walk_step)
+    L.check(lib.nmma_walk_propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, first, p_prop, p_theta, p_in, dev_i, stream), "nmma_walk_propose")
+    step = lib.nmma_walk_step
+    for k in range(1, n_steps + 1):
         l_prop = loglike_device(theta)
         if l_prop.dtype != torch.float64 or not l_prop.is_contiguous():
             l_prop = l_prop.to(torch.float64).contiguous()
-        if accept(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_len, s - int(first_step) + 1, dev_i, stream):
-            L.check(1, "nmma_walk_accept")
+        if k < n_steps:
+            if step(table, ndim, p_live, n_live, p_key, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_len, k, first, dev_i, stream):
+                L.check(1, "nmma_walk_step")
+        else:
+            L.check(lib.nmma_walk_accept(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_len, k, dev_i, stream),
+                    "nmma_walk_accept")
     return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy()
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""MCMC steps per second of the lock-step ensemble walk on BASELINE config 2: the walk on the device (nmma_walk_propose ->
-nmma_em_loglike -> nmma_walk_accept, three launches per step) against the host walk of nmma_amd/sampler.py around the same
+"""MCMC steps per second of the lock-step ensemble walk on BASELINE config 2: the walk on the device (nmma_em_loglike ->
+nmma_walk_step = accept + next proposal, two launches per step) against the host walk of nmma_amd/sampler.py around the same
 likelihood launch.  Usage: python tools/perf_device_walk.py [chains] [steps]"""
 import os
 import sys
