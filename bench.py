@@ -296,7 +296,7 @@ def host_call_ms(eng, case, syn):
     return res
 
 
-def device_walk_step_ms(eng, case, syn, n=4096, steps=200):
+def device_walk_step_ms(eng, case, syn, n=4096, steps=400):
     """One MCMC step of the lock-step ensemble walk on the device -- proposal + prior transform, the likelihood launch, accept:
     two launches (nmma_amd.sampler.device_walk) -- for `n` chains.  Context for the sampler seam; never `value`."""
     import numpy as np
@@ -309,9 +309,11 @@ def device_walk_step_ms(eng, case, syn, n=4096, steps=200):
 
     names = case["names"]
     th = syn.draw_theta(3, 20000, names)[1]
-    table = smp.device_prior_table({k: Uniform(a, b) for k, a, b in zip(names, th.min(axis=0), th.max(axis=0))}, names)
+    lo, hi = th.min(axis=0), th.max(axis=0)
+    table = smp.device_prior_table({k: Uniform(a, b) for k, a, b in zip(names, lo, hi)}, names)
     live = np.random.default_rng(11).uniform(0.3, 0.7, (n, len(names)))
-    bound = np.full(n, -1e5)
+    # (the bound a nested sampler would hold at this moment: a low quantile of the live points' likelihoods -- tools/perf_device_walk.py)
+    bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(lo + live * (hi - lo))), 0.2))
     keys = np.arange(1000, 1000 + n, dtype=np.uint64)
     buf = torch.empty(n, dtype=torch.float64, device=f"cuda:{eng.device}")
     ll = lambda t: eng.loglike(t, out=buf)

@@ -2161,18 +2161,21 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
                 out[tile0 + vt] = tot;
             } else {
-                // split launch: this workgroup owns ONE band, whose sums sit in the slot of its last item or in the slot of its
-                // observed filter (by task flavour; the other one holds zeros, and 0 + x is exact).  They are parked in the
-                // workspace [2][bands][B] that gp_parts points at; NaN marks a bad sample
-                const int o = itab[W - 1].o;
-                double c = chi_tot[(W - 1) * TS + vt], g = gp_tot[(W - 1) * TS + vt];
-                if (o != W - 1) { c += chi_tot[o * TS + vt]; g += gp_tot[o * TS + vt]; }
-                gp_parts[(long)blockIdx.y * B + tile0 + vt] = isbad ? dnan() : c;
-                gp_parts[((long)nb + blockIdx.y) * B + tile0 + vt] = g;
+                // split launch: this workgroup owns a GROUP of one to three adjacent bands.  A band's sums sit in the slot of its
+                // observed filter (lean_task) or of its last work item (lean_gen_task, FASTM 5); they are parked per observed filter
+                // in the workspace [2][P.O][B] that gp_parts points at; NaN marks a bad sample
+                constexpr bool SLOT_O = FASTM != 5;
+                for (int k = 0; k < W; ++k) {
+                    if (itab[k].ks != itab[k].nsrc - 1) continue;
+                    const int o = itab[k].o;
+                    const int slot = (SLOT_O ? o : k) * TS + vt;
+                    gp_parts[(long)o * B + tile0 + vt] = isbad ? dnan() : chi_tot[slot];
+                    gp_parts[((long)P.O + o) * B + tile0 + vt] = gp_tot[slot];
+                }
             }
         }
         if (SPLITTABLE && nb > 1) {
-            // The band that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused
+            // The group that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused
             // epilogue above, bit for bit -- and re-arms the counter for the next launch.  (Counters: the 64 KiB in front of the
             // workspace, zeroed when it is allocated.  Release / acquire at agent scope: the bands of a tile run on any XCD.)
             unsigned* cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(gp_parts) - SPLIT_COUNTER_BYTES) + blockIdx.x;
@@ -2185,9 +2188,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (vt == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (vt < TS && tile0 + vt < B) {
                     double c = 0.0, g = 0.0;
-                    for (int y = 0; y < nb; ++y) {
+                    const int nO = P.O;
+                    for (int y = 0; y < nO; ++y) {
                         c += gp_parts[(long)y * B + tile0 + vt];
-                        g += gp_parts[((long)nb + y) * B + tile0 + vt];
+                        g += gp_parts[((long)nO + y) * B + tile0 + vt];
                     }
                     double tot = c + g;
                     if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;

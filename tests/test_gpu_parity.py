@@ -554,7 +554,26 @@ def test_band_split_of_small_batches_gives_the_same_bits(name, torch_cuda, monke
     assert want[3] == FLOOR and (want > FLOOR).sum() > 500
     eng.close()
     monkeypatch.delenv("NMMA_EM_SPLIT")
-    eng = engine_from_case(case)                          # auto: split while tiles x bands <= 384
+    # past 256 / bands tiles the workgroups take GROUPS of two or three adjacent bands (forced here at two tiles): same bits
+    n_obs = len(case["observed_filters"])
+    for g in (2, 3):
+        ng = -(-n_obs // g)
+        if ng < 2 or (g == 3 and ng == -(-n_obs // 2)):
+            continue
+        monkeypatch.setenv("NMMA_EM_SPLIT_FILL_WG", str(2 * ng))
+        monkeypatch.setenv("NMMA_EM_SPLIT_MAX_WG", "1")
+        eng = engine_from_case(case)
+        for n in (17, 32):
+            got = eng.loglike(th[:n]).cpu().numpy()
+            eng.check()
+            assert eng.last_launch_geometry()["grid_y"] == ng
+            assert np.array_equal(got, want[:n]), (name, g, n)
+        eng.close()
+    monkeypatch.delenv("NMMA_EM_SPLIT_FILL_WG", raising=False)
+    monkeypatch.delenv("NMMA_EM_SPLIT_MAX_WG", raising=False)
+    eng = engine_from_case(case)                          # auto: the finest partition that keeps every workgroup resident
+    for n in (700, 1100):
+        assert np.array_equal(eng.loglike(th[:n]).cpu().numpy(), want[:n]), (name, n)
     assert np.array_equal(eng.loglike(th[:512]).cpu().numpy(), want[:512])
     split_small = eng.last_launch_geometry()["grid_y"] > 1
     eng.loglike(torch.as_tensor(syn.draw_theta(1, 8192, case["names"])[1], device="cuda:0"))

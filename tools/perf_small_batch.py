@@ -28,8 +28,11 @@ def timed(fn, n=200, warm=20):
 def main():
     case = syn.config2_case()
     batches = [int(a) for a in sys.argv[1:]] or [1, 16, 128, 256, 512, 768, 1024, 1536, 2048, 3072, 4096]
-    for mode in ("0", "1"):
-        os.environ["NMMA_EM_SPLIT"] = mode
+    for mode in ("0", "1", "auto"):
+        if mode == "auto":
+            os.environ.pop("NMMA_EM_SPLIT", None)       # the library's choice: groups of 1 / 2 / 3 bands per workgroup, or none
+        else:
+            os.environ["NMMA_EM_SPLIT"] = mode
         eng = EMEngine.from_case(case)
         for B in batches:
             th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
@@ -43,7 +46,7 @@ def main():
             for _ in range(200):
                 eng.loglike(host)
             hus = (time.perf_counter() - t0) / 200 * 1e6
-            print(f"split={mode} B={B:5d}: {us:7.2f} us/launch (grid {g['grid_x']}x{g['grid_y']}), {B / us:8.3f} Mevals/s; host numpy in/out {hus:7.1f} us/call", flush=True)
+            print(f"split={mode:>4} B={B:5d}: {us:7.2f} us/launch (grid {g['grid_x']}x{g['grid_y']}), {B / us:8.3f} Mevals/s; host numpy in/out {hus:7.1f} us/call", flush=True)
         eng.close()
 
 
