@@ -38,7 +38,8 @@ python3 bench.py --steps 200 --warmup 20 --batch 512 --no-cpu-baseline > $o/benc
 python3 bench.py --steps 200 --warmup 20 --batch 1 --no-cpu-baseline > $o/bench_line_b1.json 2> $o/bench_b1.err
 python3 tools/perf_table.py > $o/perf_table.log 2>&1
 # the lock-step ensemble walk on the device against the host walk (MCMC steps of 4096 chains)
-python3 tools/perf_device_walk.py 4096 400 > $o/device_walk.log 2>&1
+for n in 1024 2048 4096 16384; do python3 tools/perf_device_walk.py $n 400; done > $o/device_walk.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_device_walk -- python3 tools/perf_device_walk.py 4096 400 > $o/stats_device_walk.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_$c.log 2>&1
 done

@@ -22,7 +22,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-for what in ("bench", "dt05", "dt05ext", "c4", "models", "gw", "gw_fused", "at2017gfo"):
+for what in ("bench", "dt05", "dt05ext", "c4", "models", "gw", "gw_fused", "at2017gfo", "device_walk"):
     f = newest(os.path.join(src, f"stats_{what}", "**", "*kernel_stats.csv"))
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_{what}_kernel_stats.csv"))
