@@ -278,6 +278,30 @@ __device__ __forceinline__ double log_pos(const double x) {
     return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + (t2 + t1)) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// exp(x) for x <= 0 (or -inf): x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (remainder 4e-18), ldexp.  For the
+// stacking kernel, where the library's exp and log were the whole cost of a node.
+__device__ __forceinline__ double exp_neg(const double x) {
+    if (!(x > -745.2)) return 0.0;
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, x);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                         // 1 / 13!
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.3888888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)kf);
+}
+
 // ---------------------------------------------------------------------------------------
 // MFMA role of em_logl: ONE continuous stream of weight records over all work items.
 // Wave `wave` of NMW owns NSL = NSLICE/NMW hidden slices of every item; its records of

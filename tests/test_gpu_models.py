@@ -118,3 +118,43 @@ def test_combined_union_grids_and_filter_fallbacks():
     ok[[3, 17]] = False
     got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
     assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+def test_stack_matches_logsumexp_for_any_number_of_models():
+    """nmma_lc_stack against scipy's logsumexp (stack_magnitudes, model.py:1486-1510) with autocomplete_data's gap filling per model
+    (model.py:1440-1448): one to five sets (two take the unrolled four-nodes-per-thread kernel, the others the generic one), ragged
+    sizes, non-finite interior nodes, curves with no finite node, nodes where every model is dark."""
+    import torch
+    from scipy.special import logsumexp
+    from tests.helpers import engine_from_case
+    case = cases.CASES["c2_default"]()
+    eng = engine_from_case(case)
+    filters = case["model_filters"]
+    st = np.asarray(case["sample_times"] if case.get("sample_times") is not None else case["svd"][filters[0]]["tt"], float)
+    M, NS = len(filters), len(st)
+    ln10 = np.log(10.0)
+    rng = np.random.default_rng(31)
+    for n_models in (1, 2, 3, 5):
+        for B in (1, 7, 300):
+            sets = [rng.uniform(-20.0, -5.0, (B, M, NS)) + 8.0 * k for k in range(n_models)]
+            for k, s in enumerate(sets):
+                hole = rng.uniform(size=s.shape) < 0.05
+                s[hole] = rng.choice([np.inf, np.nan, -np.inf], size=int(hole.sum()))
+                s[0, k % M, :] = np.inf                       # a curve without a finite node
+            filled = []
+            for s in sets:
+                f = np.full_like(s, np.inf)
+                for b in range(B):
+                    for m in range(M):
+                        fin = np.isfinite(s[b, m])
+                        if fin.any():
+                            f[b, m] = np.interp(st, st[fin], s[b, m][fin], left=np.inf, right=np.inf)
+                filled.append(f)
+            with np.errstate(invalid="ignore"):
+                want = -2.5 * logsumexp([-0.4 * ln10 * f for f in filled], axis=0) / ln10
+            got = eng.stack([torch.as_tensor(s, device="cuda:0") for s in sets]).cpu().numpy()
+            both_inf = np.isinf(want) & np.isinf(got) & (np.sign(want) == np.sign(got))
+            ok = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), ok) and both_inf[~ok].all(), (n_models, B)
+            assert np.max(np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))) < 1e-13, (n_models, B)
+    eng.close()
