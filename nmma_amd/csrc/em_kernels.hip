@@ -2523,9 +2523,13 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
     for (int m = 0; m < M; ++m) {
         const double* cur = stage_all ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
-        int nfin = 0;
-        for (int j = lane; j < NS; j += 64) { const double v = cur[j]; nfin += (v - v == 0.0) ? 1 : 0; }
-        nfin = (int)wave_sum((double)nfin);
+        int nfin = 0;                                  // (a ballot per 64 nodes: no cross-lane fp64 reduction for a count)
+        for (int j0 = 0; j0 < NS; j0 += 64) {
+            const int j = j0 + lane;
+            double v = HUGE_VAL;
+            if (j < NS) v = cur[j];
+            nfin += __popcll(__ballot(v - v == 0.0));
+        }
         if (nfin < 2) bad = true;
     }
 
