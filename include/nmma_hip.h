@@ -371,6 +371,13 @@ int32_t nmma_walk_accept_rwalk(int32_t ndim, int64_t n, const double* prop_dev, 
                                const double* logl_prop_dev, const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev,
                                int32_t* counts_dev, double* act_dev, int32_t* active_dev, uint64_t step, double nact, int32_t maxmcmc,
                                double tau, double old_act, int32_t device, void* stream);
+/* nmma_walk_accept_rwalk for step `step` (1-based; the random-number step of its proposal) followed by nmma_walk_propose for
+ * step + 1 in ONE launch. */
+int32_t nmma_walk_step_rwalk(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const uint64_t* key_dev,
+                             int64_t n, double* prop_dev, double* theta_dev, int32_t* inside_dev, const double* logl_prop_dev,
+                             const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev, int32_t* counts_dev, double* act_dev,
+                             int32_t* active_dev, uint64_t step, double nact, int32_t maxmcmc, double tau, double old_act, int32_t device,
+                             void* stream);
 /* theta = prior transform of u[n][ndim] (start points, fresh prior draws). */
 int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
                           void* stream);

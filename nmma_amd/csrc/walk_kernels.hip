@@ -198,6 +198,54 @@ __global__ __launch_bounds__(256) void walk_accept_rwalk_kernel(const int D, con
     active[c] = ((double)step < nact * act[c] && cnt[0] + cnt[1] <= maxmcmc) ? 1 : 0;
 }
 
+// nmma_walk_accept_rwalk for step `step` and the proposal of step `step + 1` in one launch, a group of lanes per chain as in
+// walk_step_kernel (a chain that has stopped still gets a proposal; its accept ignores it).
+__global__ __launch_bounds__(256) void walk_step_rwalk_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
+                                                              const uint64_t* __restrict__ key, const long n, double* prop, double* theta,
+                                                              int32_t* inside, const double* __restrict__ l_prop,
+                                                              const double* __restrict__ loglstar, double* u, double* v,
+                                                              double* __restrict__ logl, int32_t* __restrict__ counts, double* __restrict__ act,
+                                                              int32_t* active, const uint64_t step, const double nact, const int32_t maxmcmc,
+                                                              const double tau, const double old_act) {
+    __shared__ nmma_walk_prior sp[NMMA_WALK_MAX_DIM];
+    walk_stage_spec(S, sp);
+    const int D = S.ndim, T = walk_group(D);
+    const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
+    if (c >= n) return;
+    const int lane = threadIdx.x % T;
+    if (active[c]) {                                           // (uniform over the chain's lanes; lane 0 stores the new flag last)
+        const int in = inside[c];
+        const double lp = l_prop[c];
+        const bool acc = in && lp > loglstar[c];
+        if (acc && lane < D) { u[c * D + lane] = prop[c * D + lane]; v[c * D + lane] = theta[c * D + lane]; }
+        if (lane == 0) {
+            int32_t* cnt = counts + 4 * c;                      // {accept, reject, nfail, ncall}
+            if (!in) cnt[2] += 1;
+            else {
+                cnt[3] += 1;
+                if (acc) { logl[c] = lp; cnt[0] += 1; }
+                else cnt[1] += 1;
+            }
+            const double a = (double)cnt[0], r = (double)cnt[1], f = (double)cnt[2];
+            double ac = act[c];
+            if (a + r > nact) {
+                const double ratio = a / (a + r + f);
+                double n_exact;
+                if (ratio == 0.0) n_exact = old_act < 0.0 ? HUGE_VAL : (1.0 + 1.0 / tau) * old_act;
+                else {
+                    n_exact = 2.0 / ratio - 1.0;                  // safety = 1
+                    if (old_act >= 0.0) n_exact = (1.0 - 1.0 / tau) * old_act + n_exact / tau;
+                }
+                const double capped = n_exact < (double)maxmcmc ? n_exact : (double)maxmcmc;
+                ac = capped > 1.0 ? capped : 1.0;
+                act[c] = ac;
+            }
+            active[c] = ((double)step < nact * ac && cnt[0] + cnt[1] <= maxmcmc) ? 1 : 0;
+        }
+    }
+    walk_propose_one(sp, D, T, c, lane, live, n_live, u, v, key, step + 1, prop, theta, inside);
+}
+
 // the prior transform alone (start points, fresh draws): theta = rescale(u)
 __global__ __launch_bounds__(256) void walk_rescale_kernel(const WalkSpec S, const long n, const double* __restrict__ u, double* __restrict__ theta) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,6 +337,27 @@ int32_t nmma_walk_accept_rwalk(int32_t ndim, int64_t n, const double* prop_dev, 
                        step, nact, maxmcmc, tau, old_act);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_accept_rwalk launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int32_t nmma_walk_step_rwalk(const nmma_walk_prior* priors, int32_t ndim, const double* live_dev, int64_t n_live, const uint64_t* key_dev,
+                             int64_t n, double* prop_dev, double* theta_dev, int32_t* inside_dev, const double* logl_prop_dev,
+                             const double* loglstar_dev, double* u_dev, double* v_dev, double* logl_dev, int32_t* counts_dev, double* act_dev,
+                             int32_t* active_dev, uint64_t step, double nact, int32_t maxmcmc, double tau, double old_act, int32_t device,
+                             void* stream) {
+    using namespace nmma;
+    WalkSpec S;
+    if (walk_spec(priors, ndim, &S, "nmma_walk_step_rwalk")) return 1;
+    if (!live_dev || !key_dev || !prop_dev || !theta_dev || !inside_dev || !logl_prop_dev || !loglstar_dev || !u_dev || !v_dev || !logl_dev ||
+        !counts_dev || !act_dev || !active_dev || n < 0 || n_live < 3 || !(tau > 0) || maxmcmc < 1)
+        return fail("nmma_walk_step_rwalk: bad argument (at least three live points)");
+    if (n == 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_step_rwalk: hipSetDevice failed");
+    hipLaunchKernelGGL(walk_step_rwalk_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev, (long)n_live,
+                       key_dev, (long)n, prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, act_dev,
+                       active_dev, step, nact, maxmcmc, tau, old_act);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_walk_step_rwalk launch failed: ") + hipGetErrorString(e));
     return 0;
 }
 

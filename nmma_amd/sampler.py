@@ -417,14 +417,15 @@ def device_rwalk(table, live, u0, loglstar, keys, nact, maxmcmc, tau, old_act, l
     p_star, p_logl, p_cnt, p_act, p_on, n_live, dev_i = ptr(star), ptr(logl), ptr(counts), ptr(act), ptr(active), live_d.shape[0], int(device)
     old = -1.0 if old_act is None else float(old_act)
     s = 0
+    # two launches per step: the likelihood, and the accept of step s fused with the proposal of step s + 1 (nmma_walk_step_rwalk)
+    L.check(lib.nmma_walk_propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, 1, p_prop, p_theta, p_in, dev_i, stream), "nmma_walk_propose")
     while True:
         s += 1
-        L.check(lib.nmma_walk_propose(table, ndim, p_live, n_live, p_u, p_v, p_key, n, s, p_prop, p_theta, p_in, dev_i, stream), "nmma_walk_propose")
         l_prop = loglike_device(theta)
         if l_prop.dtype != torch.float64 or not l_prop.is_contiguous():
             l_prop = l_prop.to(torch.float64).contiguous()
-        L.check(lib.nmma_walk_accept_rwalk(ndim, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt, p_act, p_on, s, float(nact),
-                                           int(maxmcmc), float(tau), old, dev_i, stream), "nmma_walk_accept_rwalk")
+        L.check(lib.nmma_walk_step_rwalk(table, ndim, p_live, n_live, p_key, n, p_prop, p_theta, p_in, ptr(l_prop), p_star, p_u, p_v, p_logl, p_cnt,
+                                         p_act, p_on, s, float(nact), int(maxmcmc), float(tau), old, dev_i, stream), "nmma_walk_step_rwalk")
         if s % int(poll) == 0 and int(active.sum().item()) == 0:
             break
     return u.cpu().numpy(), v.cpu().numpy(), logl.cpu().numpy(), counts.cpu().numpy(), act.cpu().numpy(), s
