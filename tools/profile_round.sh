@@ -36,6 +36,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_at2017gfo -- py
 python3 tools/perf_small_batch.py > $o/small_batch.log 2>&1
 python3 bench.py --steps 200 --warmup 20 --batch 512 --no-cpu-baseline > $o/bench_line_b512.json 2> $o/bench_b512.err
 python3 bench.py --steps 200 --warmup 20 --batch 1 --no-cpu-baseline > $o/bench_line_b1.json 2> $o/bench_b1.err
+# groups of three / two bands per workgroup
+python3 bench.py --steps 200 --warmup 20 --batch 1024 --no-cpu-baseline > $o/bench_line_b1024.json 2> $o/bench_b1024.err
+python3 bench.py --steps 200 --warmup 20 --batch 2048 --no-cpu-baseline > $o/bench_line_b2048.json 2> $o/bench_b2048.err
 python3 tools/perf_table.py > $o/perf_table.log 2>&1
 # the lock-step ensemble walk on the device against the host walk (MCMC steps of 4096 chains)
 for n in 1024 2048 4096 16384; do python3 tools/perf_device_walk.py $n 400; done > $o/device_walk.log 2>&1

@@ -67,7 +67,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(dst, f"{tag}_bench_line.json"))
-for name in ("bench_line_b512.json", "bench_line_b1.json"):
+for name in ("bench_line_b512.json", "bench_line_b1.json", "bench_line_b1024.json", "bench_line_b2048.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
