@@ -60,9 +60,10 @@ __device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) 
 // The prior table is staged from the kernel arguments into LDS so that lanes can index it by their dimension.
 __device__ __forceinline__ int walk_group(const int D) { return D <= 8 ? 8 : D <= 16 ? 16 : 32; }
 
+static_assert(sizeof(nmma_walk_prior) == 32 && NMMA_WALK_MAX_DIM * 8 <= 256, "one dword of the table per thread of the workgroup");
 __device__ __forceinline__ void walk_stage_spec(const WalkSpec& S, nmma_walk_prior* sp) {
-    if (threadIdx.x == 0)
-        for (int d = 0; d < S.ndim; ++d) sp[d] = S.p[d];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.p[0]);          // (the kernel-argument segment, read per thread)
+    if ((int)threadIdx.x < S.ndim * 8) reinterpret_cast<uint32_t*>(sp)[threadIdx.x] = src[threadIdx.x];
     __syncthreads();
 }
 
