@@ -16,6 +16,8 @@ Without a launcher (RANK unset) and N > 1 the script starts ``torch.distributed.
 before anything here touches the GPU -- and relays the child's JSON line.  ``--scaling weak`` (default) keeps 4096
 live points per GPU; ``--scaling strong`` splits ONE 4096-point batch over the ranks (north_star's 8-GPU target).
 
+The K-step region (W untimed steps first, each region bracketed by barrier + synchronize) is timed ``--repeats`` times and
+`value` / `ms_per_step` are the MEDIAN region's (`spread_pct` = the 10-90 percentile spread over the repeats, relative to it).
 With N > 1 BOTH scaling modes are measured in the one invocation: the line's top level is the mode ``--scaling`` names, the
 other one sits under ``other_scaling``.  Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
 MLP on the f32 MFMA pipe, SVD reconstruction, interpolation and likelihood terms in one launch)
@@ -76,6 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=25, help="the K-step region is timed this many times; value = the median region")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="live points per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,6 +111,12 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:        # NMMA_BENCH_FORCE_DIST=1 without a launcher: a process group of this one rank
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
         if share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -186,38 +195,51 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
         # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
         # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
         # by the dispatch latency behind the start event); with a collective between launches, single launches.
-        os.environ["NMMA_PROFILE_GROUP"] = os.environ.get("NMMA_BENCH_EVENT_GROUP", "8" if world == 1 else "1")
-        os.environ["NMMA_PROFILE_STRIDE"] = os.environ.get("NMMA_BENCH_EVENT_STRIDE", "2" if world == 1 else "4")
-        eng.profile_begin(args.steps)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        os.environ["NMMA_PROFILE_GROUP"] = os.environ.get("NMMA_BENCH_EVENT_GROUP", "8" if not use_dist else "1")
+        os.environ["NMMA_PROFILE_STRIDE"] = os.environ.get("NMMA_BENCH_EVENT_STRIDE", "2" if not use_dist else "4")
+        # The K-step region is timed R times (each one bracketed by barrier + synchronize on both sides); `value` comes from
+        # the MEDIAN region: at the driver's flags the region is well under a millisecond and a single one carries the noise
+        # of whatever the box did in that millisecond.
+        times, prof = [], dict(fused_ms_total=0.0, n_launches=0)
+        done = args.warmup
+        for _ in range(args.repeats):
+            if use_dist:
+                dist.barrier()
             torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        prof = eng.profile_end()
+            eng.profile_begin(args.steps)
+            t0 = time.perf_counter()
+            for i in range(done, done + args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+                torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            done += args.steps
+            p = eng.profile_end()
+            prof["fused_ms_total"] += p["fused_ms_total"]
+            prof["n_launches"] += p["n_launches"]
         gc.enable()
         if pipelined:
             torch.cuda.set_stream(prev_stream)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if use_dist:        # every region's time is the MAX over ranks
+            t = torch.tensor(times, dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            times = t.cpu().tolist()
+        elapsed = float(np.median(times))
+        spread = 100.0 * (float(np.percentile(times, 90)) - float(np.percentile(times, 10))) / elapsed if len(times) > 1 else 0.0
+        n_done = done
         # sanity: the numbers we just timed are real likelihood values
-        last = (outs[(args.steps - 1) & 1] if pipelined else out).cpu().numpy()
+        last = (outs[(n_done - 1) & 1] if pipelined else out).cpu().numpy()
         assert np.all(np.isfinite(last)) and np.all(last < 0)
-        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry())
+        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry(),
+                    spread_pct=spread, best=min(times), worst=max(times))
 
     def exchange_label(m):
-        if world == 1:
+        if not use_dist:
             return "none"
         if share_gpu:
             return "gloo all_gather (TEST MODE: ranks share one GPU)"
@@ -238,7 +260,8 @@ def main():
             "value": evals / m["elapsed"], "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 MLP + f64",
-            "data": "synthetic",
+            "data": "synthetic", "repeats": args.repeats, "spread_pct": m["spread_pct"],
+            "ms_per_step_best": 1e3 * m["best"] / args.steps, "ms_per_step_worst": 1e3 * m["worst"] / args.steps,
             "config": {"workload": "BASELINE config 2: Bu2019lm SVD surrogate (NP=4, NH=2048, NC=10, NT=211), "
                                    "AT2017gfo 6-filter synthetic photometry (99 epochs, 1 upper limit), "
                                    f"batch={B} live points per GPU, sigma_sys=1, detection_limit=inf",

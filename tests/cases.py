@@ -339,6 +339,40 @@ def case_unobserved_filter_dead():
     return c
 
 
+def case_bulla_svd():
+    """A surrogate with REAL conditioning: the SVD basis, ``mins`` / ``maxs`` spans (0.7 ... 23.6 mag across the grid) and
+    coefficient ranges the reference's own ``generate_svd_model`` (em/training.py:198-265) builds from the 28 POSSIS curves of
+    ``nmma/tests/data/bulla`` (model ``Bu2019lm_sparse``: two ejecta masses, 9 filters, documented training grid), with an fp32
+    network fitted to its ``cAmat`` (fixture tests/golden/bulla_svd_model.npz, arrays only, written by
+    tools/make_golden_bulla.py) -- every other golden case has a QR-orthonormalised Gaussian basis.  9 filters, the documented
+    CLI grid, the sampled ``em_syserr`` of current NMMA priors, one upper limit and one filter with a finite detection limit.
+    Rows 0-47 lie inside the training box, the rest extrapolate."""
+    with np.load(os.path.join(GOLDEN_DIR, "bulla_svd_model.npz")) as z:
+        filters = [str(f) for f in z["filters"]]
+        mp = [str(n) for n in z["model_parameters"]]
+        svd = {}
+        for f in filters:
+            t = {k: np.ascontiguousarray(z[f"{f}/{k}"]) for k in ("W1", "b1", "W2", "b2", "VA", "mins", "maxs", "tt",
+                                                                   "param_mins", "param_maxs")}
+            t["n_coeff"] = int(t["W2"].shape[1])
+            svd[f] = t
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    counts = dict(zip(filters, (6, 14, 22, 17, 18, 15, 14, 17, 23)))
+    data = syn.make_photometry(8835, svd, mp, filters=filters, counts=counts, cosmo_grid=grid, upper_limit_filter="ztfi")
+    names, theta = syn.draw_theta(8836, 64, ["luminosity_distance", "timeshift", "log10_mej_dyn", "log10_mej_wind", "em_syserr"])
+    rng = np.random.default_rng(8837)
+    pmin, pmax = svd[filters[0]]["param_mins"], svd[filters[0]]["param_maxs"]
+    for k, n in enumerate(mp):
+        theta[:48, names.index(n)] = rng.uniform(pmin[k], pmax[k], 48)
+    lim = {f: np.inf for f in filters}
+    finite = np.isfinite(data[2]["ztfr"])
+    lim["ztfr"] = float(np.max(data[1]["ztfr"][finite]) + 0.4)
+    return dict(model="Bu2019lm_sparse", model_parameters=mp, svd=svd, model_filters=filters,
+                sample_times=np.arange(0.1, 20.5, 0.5), cosmo_grid=grid, data=data, observed_filters=filters,
+                detection_limit=lim, systematics=dict(mode="param", name="em_syserr"),
+                systematics_ref=dict(error_budget=None, systematics_file=None), names=names, theta=theta)
+
+
 def case_small_hidden():
     """Tiny surrogate (NH=64) for fast pure-Python loops."""
     return _base(seed=8234, n_hidden=64, batch=16)
@@ -367,6 +401,7 @@ CASES = {
     "at2017gfo": case_at2017gfo,
     "unobserved_filter_overflow": case_unobserved_filter_overflow,
     "unobserved_filter_dead": case_unobserved_filter_dead,
+    "bulla_svd": case_bulla_svd,
 }
 
 

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags):
+def _bench(*flags, **env_extra):
     env = dict(os.environ, NMMA_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env.update(env_extra)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", *flags],
                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
@@ -53,6 +54,27 @@ def test_bench_small_batches(batch):
     line = _bench("--batch", str(batch))
     assert line["n_gpus"] == 1 and line["config"]["global_batch"] == batch and "other_scaling" not in line
     assert np.isfinite(line["value"]) and line["value"] > 0
+
+
+@pytest.mark.parametrize("blocking", ["0", "1"])
+def test_bench_rccl_exchange_with_one_rank(blocking):
+    """The RCCL path of bench.py on the one GPU of the box: process group `nccl` (= RCCL) of world size 1, the all-gather of logL
+    after every evaluation -- on a second stream, overlapping the next kernel (the form an 8-GPU run takes), and blocking on the
+    compute stream -- plus the barrier / max-over-ranks timing.  No scaling number; the code an N-GPU run executes has run."""
+    line = _bench("--gpus", "1", "--repeats", "3", NMMA_BENCH_SHARE_GPU="0", NMMA_BENCH_FORCE_DIST="1", NMMA_BENCH_BLOCKING=blocking,
+                  HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["repeats"] == 3
+    ex = line["config"]["exchange"]
+    assert ex.startswith("RCCL all_gather of logL per step") and ("pipelined" in ex) == (blocking == "0")
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert line["value"] == pytest.approx(4096 / (line["ms_per_step"] * 1e-3), rel=1e-9)
+    assert line["roofline"]["kernel"] == "em_logl" and 0 < line["roofline"]["frac"] < 1
+
+
+def test_bench_line_reports_the_median_region():
+    line = _bench("--repeats", "7")
+    assert line["repeats"] == 7 and line["spread_pct"] >= 0
+    assert line["ms_per_step_best"] <= line["ms_per_step"] <= line["ms_per_step_worst"]
 
 
 def test_multi_device_evaluator_in_one_process():
