@@ -367,10 +367,16 @@ def case_bulla_svd():
     lim = {f: np.inf for f in filters}
     finite = np.isfinite(data[2]["ztfr"])
     lim["ztfr"] = float(np.max(data[1]["ztfr"][finite]) + 0.4)
+    # Row 34 is the best fit: log L = -7.17 is what is left of ~150 terms of order one.  One ulp(fp32) of the leading SVD
+    # coefficient (|c_0| ~ 13: 9.5e-7) times a span of ~20 mag moves a node by ~1e-5 mag and log L by a few 1e-5 -- any two fp32
+    # forwards of the network (numpy's BLAS, Keras' Eigen, the MFMA chain) differ by that much; relative to 7.17 it reads 5e-6.
+    # The GPU test therefore allows ONE row an absolute 1e-4 instead of the relative 1e-6 (and checks the kernel against the
+    # order-independent fp64-accumulated value: test_realistic_basis_hip_is_as_close_to_exact_arithmetic_as_the_reference_stand_in).
     return dict(model="Bu2019lm_sparse", model_parameters=mp, svd=svd, model_filters=filters,
                 sample_times=np.arange(0.1, 20.5, 0.5), cosmo_grid=grid, data=data, observed_filters=filters,
                 detection_limit=lim, systematics=dict(mode="param", name="em_syserr"),
-                systematics_ref=dict(error_budget=None, systematics_file=None), names=names, theta=theta)
+                systematics_ref=dict(error_budget=None, systematics_file=None), names=names, theta=theta,
+                logl_atol=1e-4, logl_atol_rows=1)
 
 
 def case_small_hidden():

@@ -40,7 +40,12 @@ def test_logl_matches_reference_golden(name, torch_cuda):
     assert np.array_equal(got == FLOOR, floor), f"floor pattern differs: {np.nonzero((got == FLOOR) != floor)}"
     err = rel_err(got[~floor], want[~floor])
     print(f"{name}: max rel err {err.max() if err.size else 0:.3e} over {err.size} finite rows")
-    assert err.size == 0 or err.max() <= LOGL_RTOL
+    # (a case may state an ABSOLUTE noise floor of the fp32 surrogate -- cases.py says why; the relative bound holds for every other row)
+    over = err > LOGL_RTOL
+    if over.any():
+        abs_err = np.abs(got[~floor] - want[~floor])[over]
+        print(f"{name}: {int(over.sum())} row(s) above {LOGL_RTOL:g} relative: |logL| {np.abs(want[~floor][over])}, abs err {abs_err}")
+        assert abs_err.max() <= case.get("logl_atol", 0.0) and over.sum() <= case.get("logl_atol_rows", 0)
     # host-buffer entry point gives the same numbers
     got_h = eng.loglike(np.asarray(case["theta"]))
     assert np.array_equal(got_h, got)
@@ -74,6 +79,39 @@ def test_coefficients_and_lightcurves(name, torch_cuda):
         x = (plist - t["param_mins"]) / (t["param_maxs"] - t["param_mins"])
         ideal = orc.mlp_forward(x, t["W1"], t["b1"], t["W2"], t["b2"], "f64acc")
         np.testing.assert_allclose(c[:, k], ideal, atol=COEFF_ATOL, rtol=0)
+    eng.close()
+
+
+def test_realistic_basis_hip_is_as_close_to_exact_arithmetic_as_the_reference_stand_in(torch_cuda):
+    """`bulla_svd` (the reference's own SVD of the POSSIS grid: spans of up to 23.6 mag, |c_0| ~ 13): what separates the HIP path
+    from the golden numbers is fp32 summation order in the surrogate -- both are roundings of the same exact value.  Against the
+    fp64-ACCUMULATED value of the same fp32 operands (order independent) the kernel's coefficients are at least as close as the
+    numpy fp32 forward that stands in for Keras on the reference side, and log L agrees with
+    that ideal to 5e-6 relative / 5e-5 absolute (worst: the best-fit row, where log L = -7.2 is a near-cancelling sum)."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    case = cases.CASES["bulla_svd"]()
+    eng = engine_from_case(case)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    c = eng.coefficients(th).cpu().numpy()
+    got = eng.loglike(th).cpu().numpy()
+    olik = oracle_from_case(case, use_scipy=False)
+    p = olik.model.parameter_conversion(dict(zip(case["names"], case["theta"].T)))
+    plist = np.stack([np.broadcast_to(p[k], (len(case["theta"]),)) for k in case["model_parameters"]], 1)
+    worst_hip = worst_np = 0.0
+    for k, f in enumerate(case["model_filters"]):
+        t = case["svd"][f]
+        x = (plist - t["param_mins"]) / (t["param_maxs"] - t["param_mins"])
+        ideal = orc.mlp_forward(x, t["W1"], t["b1"], t["W2"], t["b2"], "f64acc")
+        stand_in = orc.mlp_forward(x, t["W1"], t["b1"], t["W2"], t["b2"], "f32")
+        worst_hip = max(worst_hip, float(np.abs(c[:, k] - ideal).max()))
+        worst_np = max(worst_np, float(np.abs(stand_in - ideal).max()))
+    print(f"coefficients vs fp64-accumulated ideal: HIP {worst_hip:.3e}, numpy fp32 stand-in {worst_np:.3e}")
+    assert worst_hip <= worst_np
+    ideal_l = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False, mlp_mode="f64acc"), case["names"], case["theta"])
+    e = np.abs(got - ideal_l)
+    print(f"logL vs ideal: max rel {rel_err(got, ideal_l).max():.3e}, max abs {e.max():.3e}")
+    assert rel_err(got, ideal_l).max() <= 5e-6 and np.all((rel_err(got, ideal_l) <= LOGL_RTOL) | (e <= 5e-5))
     eng.close()
 
 
