@@ -286,6 +286,7 @@ def main():
             ms = device_walk_step_ms(eng, case, syn)
             line["device_walk"] = {"chains": 4096, "ms_per_mcmc_step": ms, "evals_per_s": 4096 / (ms * 1e-3),
                                    "what": "lock-step ensemble walk on the device: likelihood -> accept + next proposal, two launches per step"}
+            line["device_walk_queue"] = device_walk_queue(case, syn, line["device_walk"]["evals_per_s"])
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)
@@ -344,6 +345,72 @@ def device_walk_step_ms(eng, case, syn, n=4096, steps=400):
     t0 = time.perf_counter()
     smp.device_walk(table, live, live, bound, keys, steps, ll, device=eng.device)
     return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def device_walk_queue(case, syn, inner_rate, n=4096, walks=100, repeats=7):
+    """The sampler seam END TO END: wall time of ``GPUPool.map(walker.sample, queue)`` -- the call the nested sampler of
+    nmma/core/mpi_setup.py:282-303 makes per queue -- for a queue of `n` records x `walks` MCMC steps of the default
+    "acceptance-walk", through the reference-shaped plugin objects (SVDLightCurveModel, EMTransientLikelihood, GPUPool,
+    EnsembleWalkSampler.prepare_sampler).  Context for SURVEY section 8 f1; never `value`."""
+    import numpy as np
+    from nmma_amd import sampler as smp
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    from nmma_amd.pool import GPUPool
+
+    class Uniform:          # (bilby's Uniform as far as the seam reads it; the device table recognises the class by name)
+        def __init__(self, lo, hi):
+            self.minimum, self.maximum = float(lo), float(hi)
+
+        def rescale(self, val):
+            return self.minimum + val * (self.maximum - self.minimum)
+
+    names = case["names"]
+    th = syn.draw_theta(3, 20000, names)[1]
+    pri = {k: Uniform(a, b) for k, a, b in zip(names, th.min(axis=0), th.max(axis=0))}
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"], model_parameters=case["model_parameters"],
+                               sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(case["observed_filters"], systematics_file=None, error_budget=1.0, light_curve_times=times)
+    lik = EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, dict(pri), filters=case["observed_filters"],
+                                detection_limit=case["detection_limit"])
+    pt = smp.BatchedPriorTransform(pri, names)
+    pool = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri)
+    walker = smp.EnsembleWalkSampler(ndim=len(names), walks=walks, naccept=60)
+    live = np.random.default_rng(11).uniform(0.3, 0.7, (n, len(names)))
+
+    class _NS:
+        live_u = live
+    bound = float(np.quantile(lik.log_likelihood_batch(np.ascontiguousarray(pt(live)), names), 0.2))
+    seeds = np.arange(1000, 1000 + n)
+
+    def queue():
+        return walker.prepare_sampler(loglstar=bound, points=live, axes=None, seeds=seeds, prior_transform=pt, loglikelihood=None,
+                                      nested_sampler=_NS)
+    pool.map(walker.sample, queue())
+    t_map, t_all, t_list, gpu = [], [], [], []
+    eng = lik.sub_model.engine(names)
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        res = pool.map(walker.sample, queue())
+        t1 = time.perf_counter()
+        recs = list(res)                     # dynesty: self.queue = list(mapper(...)) -- 4096 Python records
+        t2 = time.perf_counter()
+        t_map.append(t1 - t0); t_all.append(t2 - t0); gpu.append(eng.last_walk_gpu_ms * 1e-3)
+    args_list = list(queue())                # per-record arguments (a driver that builds its own records)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pool.map(walker.sample, args_list)
+        t_list.append(time.perf_counter() - t0)
+    assert len(recs) == n and all(np.isfinite(r[2]) for r in recs[:64])
+    med = lambda v: float(np.median(v))
+    rate = n * walks / med(t_map)
+    eng.close()
+    return {"records": n, "walks": walks, "map_ms": 1e3 * med(t_map), "device_ms": 1e3 * med(gpu), "map_plus_materialised_records_ms": 1e3 * med(t_all),
+            "map_ms_per_record_arguments": 1e3 * med(t_list), "evals_per_s": rate, "fraction_of_inner_loop_rate": rate / inner_rate,
+            "what": "wall time of GPUPool.map(walker.sample, queue) for prepare_sampler's array-backed queue: one library call "
+                    "(nmma_em_walk_queue: upload, 100 x {likelihood, accept + next proposal}, fresh draws, download), array-backed records"}
 
 
 def _oracle_rows():

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 4
+#define NMMA_ABI_VERSION 5
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -337,13 +337,18 @@ enum nmma_prior_kind {        /* bilby/core/prior/analytical.py, by the formula 
     NMMA_PRIOR_COSINE = 2,    /* arcsin(u (sin b - sin a) + sin a)                                        */
     NMMA_PRIOR_POWERLAW = 3,  /* (a^(1+alpha) + u (b^(1+alpha) - a^(1+alpha)))^(1/(1+alpha)); alpha = -1: a exp(u ln(b/a)) (LogUniform) */
     NMMA_PRIOR_GAUSSIAN = 4,  /* a + erfinv(2u - 1) sqrt(2) b                   a = mu, b = sigma         */
-    NMMA_PRIOR_DELTA = 5      /* a                                              a = peak                  */
+    NMMA_PRIOR_DELTA = 5,     /* a                                              a = peak                  */
+    NMMA_PRIOR_TRUNC_GAUSSIAN = 6, /* a + sqrt(2) b erfinv(2 u alpha + c)       a = mu, b = sigma, alpha = normalisation =
+                                 (erf((max - mu)/(sqrt(2) sigma)) - erf((min - mu)/(sqrt(2) sigma)))/2, c = erf((min - mu)/(sqrt(2) sigma))
+                                 (bilby TruncatedGaussian / TruncatedNormal.rescale; priors/Sr2023.prior)  */
+    NMMA_PRIOR_LOGNORMAL = 7, /* exp(a + sqrt(2 b^2) erfinv(2u - 1))            a = mu, b = sigma (LogNormal / LogGaussian) */
+    NMMA_PRIOR_HALF_GAUSSIAN = 8 /* erfinv(u) sqrt(2) b                          b = sigma (HalfGaussian / HalfNormal)      */
 };
 enum nmma_boundary { NMMA_BOUNDARY_NONE = 0, NMMA_BOUNDARY_PERIODIC = 1, NMMA_BOUNDARY_REFLECTIVE = 2 };
 typedef struct nmma_walk_prior {
     int32_t kind;      /* enum nmma_prior_kind */
     int32_t boundary;  /* enum nmma_boundary: how a proposal that leaves [0, 1] in this dimension is folded back */
-    double a, b, alpha;
+    double a, b, alpha, c;
 } nmma_walk_prior;
 
 /* prop = u + gamma (live[j] - live[i]) with the boundary conditions applied; inside[c] = the proposal lies in the unit cube;
@@ -381,6 +386,66 @@ int32_t nmma_walk_step_rwalk(const nmma_walk_prior* priors, int32_t ndim, const 
 /* theta = prior transform of u[n][ndim] (start points, fresh prior draws). */
 int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const double* u_dev, int64_t n, double* theta_dev, int32_t device,
                           void* stream);
+
+/* ---- Constraint priors on the device (nmma/core/base.py:51-82: `evaluate_constraints` on the CONVERTED sample, the floor where the
+ * product of the Constraint priors' prob is 0).  The conversion chain of a likelihood (core/conversion.py, em/model.py:272-286,
+ * bilby's mass conversions) is elementwise arithmetic on the sampled columns, so the host lowers "derived quantity, then
+ * minimum < value < maximum" into a small postfix program (nmma_amd/core/constraints.py traces the reference-shaped conversion
+ * functions) that a kernel evaluates per row: no device-to-host copy of theta on a batched call, and the device walk can honour
+ * a constrained prior set.  NaN fails every comparison (bilby's Constraint.prob does the same). */
+enum nmma_con_opcode {
+    NMMA_CON_PUSH_COL = 0,    /* push theta[row][col]                                   */
+    NMMA_CON_PUSH_CONST = 1,  /* push value                                             */
+    NMMA_CON_ADD = 2, NMMA_CON_SUB = 3, NMMA_CON_MUL = 4, NMMA_CON_DIV = 5, NMMA_CON_POW = 6,      /* (a, b) -> a op b         */
+    NMMA_CON_MIN = 7, NMMA_CON_MAX = 8,
+    NMMA_CON_NEG = 9, NMMA_CON_ABS = 10, NMMA_CON_SQRT = 11, NMMA_CON_LOG10 = 12, NMMA_CON_LOG = 13, NMMA_CON_EXP = 14,
+    NMMA_CON_SIN = 15, NMMA_CON_COS = 16, NMMA_CON_ACOS = 17, NMMA_CON_ASIN = 18, NMMA_CON_SIGN = 19,
+    NMMA_CON_CHECK_GT = 20,   /* ok &= top > value   (the value stays on the stack)     */
+    NMMA_CON_CHECK_LT = 21    /* ok &= top < value   (pops)                             */
+};
+#define NMMA_CON_MAX_OPS 256
+#define NMMA_CON_MAX_STACK 16
+typedef struct nmma_con_op {
+    int32_t op;      /* enum nmma_con_opcode */
+    int32_t col;     /* NMMA_CON_PUSH_COL    */
+    double value;    /* NMMA_CON_PUSH_CONST, NMMA_CON_CHECK_* */
+} nmma_con_op;
+typedef struct nmma_con_program nmma_con_program;
+/* ops: HOST array, copied to `device`; the program is checked (stack depth, columns < n_cols) before anything is launched. */
+int32_t nmma_con_create(const nmma_con_op* ops, int32_t n_ops, int32_t n_cols, int32_t device, nmma_con_program** out);
+void nmma_con_destroy(nmma_con_program* p);
+/* logl_dev[b] = NMMA_LOGL_FLOOR where row b of theta_dev[B][ld] fails a check (in place; asynchronous on `stream`). */
+int32_t nmma_con_floor(const nmma_con_program* p, const double* theta_dev, int64_t B, int64_t ld, double* logl_dev, void* stream);
+
+/* ---- One queue of the nested sampler in ONE call: `pool.map(sample, queue)` of core/mpi_setup.py:282-303, :339 for the
+ * fixed-length ensemble walk ("acceptance-walk", :221-232) over an EM likelihood handle.  Host arrays in, host arrays out; inside:
+ * one packed upload, prior transform of the start points, then per MCMC step the likelihood launch and accept + next proposal
+ * (nmma_em_loglike, nmma_walk_step: the very launches of the per-step entry points, so the chains are bit-identical), a fresh
+ * prior draw for every chain that never moved (bilby: "Unable to find a new point using walk"), one packed download.  The
+ * workspace keeps its device and pinned buffers between queues. */
+typedef struct nmma_walk_ws nmma_walk_ws;
+int32_t nmma_walk_ws_create(int32_t device, nmma_walk_ws** out);
+void nmma_walk_ws_destroy(nmma_walk_ws* ws);
+typedef struct nmma_walk_queue {
+    const nmma_walk_prior* priors;   /* [ndim] */
+    int32_t ndim;
+    int32_t walks;                   /* steps per chain when walks_per_chain is NULL */
+    const double* live;              /* [n_live][ndim] unit-cube live points (>= 3)  */
+    int64_t n_live;
+    const double* u0;                /* [n][ndim] start points (unit cube)           */
+    const double* loglstar;          /* [n] likelihood bound of every chain          */
+    const uint64_t* key;             /* [n] chain keys                               */
+    const int32_t* walks_per_chain;  /* [n] or NULL                                  */
+    int64_t n;
+    uint64_t first_step;             /* random-number step of the first proposal (1) */
+    const nmma_con_program* constraints;   /* or NULL: rows failing a check count as evaluated and get NMMA_LOGL_FLOOR   */
+    double* u;                       /* out [n][ndim]                                */
+    double* v;                       /* out [n][ndim] theta of u                     */
+    double* logl;                    /* out [n]                                      */
+    int32_t* counts;                 /* out [n][4] accept, reject, outside the cube, likelihood calls                  */
+    double gpu_ms;                   /* out: upload .. download complete, HIP events */
+} nmma_walk_queue;
+int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream);
 
 /* MultiMessengerLikelihood.sub_log_likelihood for a batch (joint/joint_likelihood.py:62-67): out_dev[b] = sum_k parts[k][b] in
  * messenger order, NMMA_LOGL_FLOOR where the sum is not finite or a messenger already returned the floor.

@@ -20,7 +20,7 @@ SOURCES = ("em_kernels.hip", "gw_kernels.hip", "walk_kernels.hip")
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
 UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -83,12 +83,33 @@ class EmConfig(C.Structure):
 
 class WalkPrior(C.Structure):
     """Mirror of ``struct nmma_walk_prior``."""
-    _fields_ = [("kind", C.c_int32), ("boundary", C.c_int32), ("a", C.c_double), ("b", C.c_double), ("alpha", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("boundary", C.c_int32), ("a", C.c_double), ("b", C.c_double), ("alpha", C.c_double), ("c", C.c_double)]
 
 
 WALK_MAX_DIM = 32
-PRIOR_UNIFORM, PRIOR_SINE, PRIOR_COSINE, PRIOR_POWERLAW, PRIOR_GAUSSIAN, PRIOR_DELTA = range(6)
+(PRIOR_UNIFORM, PRIOR_SINE, PRIOR_COSINE, PRIOR_POWERLAW, PRIOR_GAUSSIAN, PRIOR_DELTA, PRIOR_TRUNC_GAUSSIAN, PRIOR_LOGNORMAL,
+ PRIOR_HALF_GAUSSIAN) = range(9)
 BOUNDARY_NONE, BOUNDARY_PERIODIC, BOUNDARY_REFLECTIVE = range(3)
+
+
+class ConOp(C.Structure):
+    """Mirror of ``struct nmma_con_op``: one operation of a constraint program (postfix)."""
+    _fields_ = [("op", C.c_int32), ("col", C.c_int32), ("value", C.c_double)]
+
+
+(CON_PUSH_COL, CON_PUSH_CONST, CON_ADD, CON_SUB, CON_MUL, CON_DIV, CON_POW, CON_MIN, CON_MAX, CON_NEG, CON_ABS, CON_SQRT, CON_LOG10,
+ CON_LOG, CON_EXP, CON_SIN, CON_COS, CON_ACOS, CON_ASIN, CON_SIGN, CON_CHECK_GT, CON_CHECK_LT) = range(22)
+CON_MAX_OPS, CON_MAX_STACK = 256, 16
+
+
+class WalkQueue(C.Structure):
+    """Mirror of ``struct nmma_walk_queue`` (field order must match the header)."""
+    _fields_ = [
+        ("priors", C.POINTER(WalkPrior)), ("ndim", C.c_int32), ("walks", C.c_int32),
+        ("live", C.c_void_p), ("n_live", C.c_int64), ("u0", C.c_void_p), ("loglstar", C.c_void_p), ("key", C.c_void_p),
+        ("walks_per_chain", C.c_void_p), ("n", C.c_int64), ("first_step", C.c_uint64), ("constraints", C.c_void_p),
+        ("u", C.c_void_p), ("v", C.c_void_p), ("logl", C.c_void_p), ("counts", C.c_void_p), ("gpu_ms", C.c_double),
+    ]
 
 
 class GwConfig(C.Structure):
@@ -146,6 +167,12 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int32, C.c_double, C.c_double,
                                            C.c_int32, C.c_void_p]),
     "nmma_walk_rescale": (C.c_int32, [C.POINTER(WalkPrior), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "nmma_con_create": (C.c_int32, [C.POINTER(ConOp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "nmma_con_destroy": (None, [C.c_void_p]),
+    "nmma_con_floor": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_walk_ws_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "nmma_walk_ws_destroy": (None, [C.c_void_p]),
+    "nmma_em_walk_queue": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue), C.c_void_p]),
     "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
     "nmma_gw_destroy": (None, [C.c_void_p]),
     "nmma_gw_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

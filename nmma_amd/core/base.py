@@ -189,6 +189,53 @@ class NMMALikelihoodMixin:
             return logl
         return floor_rows(logl, self.evaluate_constraints(self.parameter_conversion(dict(columns))))
 
+    # ---- Constraint priors of a batch that lives on the GPU (no device-to-host copy of theta) --------------------------------
+    def conversion_chain(self):
+        """The callables ``parameter_conversion`` applies, in application order (traced by ``device_constraints``)."""
+        return [self.parameter_conversion]
+
+    def device_constraints(self, names, fixed, device=0):
+        """The constraint set lowered to a device program for the columns ``names`` (``nmma_amd.core.constraints``), or ``None``
+        when a constrained quantity has no device expression (the host mask then applies).  Cached per (constraints, layout):
+        ``self.constraints`` may be edited in place, so the key is the set's content."""
+        from .constraints import ConstraintProgram, constraint_signature, trace_constraints
+        key = (constraint_signature(self._constraints), tuple(names), tuple(sorted((k, float(v)) for k, v in (fixed or {}).items())),
+               int(device))
+        cache = self.__dict__.setdefault("_con_programs", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                for prog in cache.values():
+                    if prog is not None:
+                        prog.close()
+                cache.clear()
+            ops = trace_constraints(self._constraints, list(names), fixed, self.conversion_chain())
+            cache[key] = ConstraintProgram(ops, len(names), device) if ops else None
+        return cache[key]
+
+    def apply_constraints_batch(self, logl, theta, names, fixed):
+        """core/base.py:67-68, :77-82 for a batch.  A CUDA ``theta`` is checked where it lies: one small kernel floors the rows
+        that violate a Constraint prior (``nmma_con_floor``), nothing is copied to the host.  Host arrays, and constraint sets
+        the tracer cannot lower, take the numpy mask on the converted columns."""
+        if not self._constraints:
+            return logl
+        import torch
+        if isinstance(theta, torch.Tensor) and theta.is_cuda and isinstance(logl, torch.Tensor) and logl.is_cuda:
+            prog = self.device_constraints(names, fixed, theta.device.index or 0)
+            if prog is not None:
+                th = theta if (theta.dtype == torch.float64 and theta.is_contiguous()) else theta.to(torch.float64).contiguous()
+                out = logl if (logl.dtype == torch.float64 and logl.is_contiguous()) else logl.to(torch.float64).contiguous()
+                return prog.floor(th, out)
+        host = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta, dtype=float)
+        columns = {n: host[:, i] for i, n in enumerate(names)}
+        for key, val in (fixed or {}).items():
+            columns.setdefault(key, np.full(len(host), val))
+        return self.floor_constrained_rows(logl, columns)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_con_programs", None)          # device objects are rebuilt per process
+        return state
+
 
 class NMMALikelihood(NMMALikelihoodMixin, Likelihood):
     """One messenger: wraps ``sub_model`` (anything with ``log_likelihood(parameters)``) and the
@@ -220,6 +267,9 @@ class NMMALikelihood(NMMALikelihoodMixin, Likelihood):
         for convert in self.conv_functions[::-1]:
             parameters = convert(parameters)
         return parameters
+
+    def conversion_chain(self):
+        return list(self.conv_functions[::-1])
 
     def posterior_conversion(self, parameters):
         return self.parameter_conversion(parameters)

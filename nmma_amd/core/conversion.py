@@ -133,8 +133,18 @@ def get_cosmo_grids(distance_min, distance_max, cosmology=None, n=50):
     return cosmology.luminosity_distance(z_grid), z_grid
 
 
+def _symbolic(*values):
+    """Is any of the values a traced column (nmma_amd.core.constraints lowers Constraint priors by running these conversions on
+    symbolic columns)?  A root-find or a table look-up has no device expression: it then returns an opaque symbol."""
+    from .constraints import is_symbolic
+    return any(is_symbolic(v) for v in values)
+
+
 def luminosity_distance_to_redshift(distance, cosmology=None):
     """z(d_L [Mpc]) by root-finding on the native cosmology; scalar or array."""
+    if _symbolic(distance):
+        from .constraints import opaque_like
+        return opaque_like(distance)
     cosmo = native_cosmology(cosmology)
     d = np.asarray(distance, dtype=float)
     if d.ndim == 0:
@@ -154,6 +164,10 @@ def cosmology_to_distance(parameters, cosmology=None):
         over["Om0"] = parameters["Omega_matter"]
     if "luminosity_distance" not in parameters and "redshift" not in parameters:
         raise KeyError("Either redshift or luminosity_distance must be in parameters")
+    if _symbolic(parameters.get("luminosity_distance"), parameters.get("redshift"), *over.values()):
+        from .constraints import opaque_like
+        parameters["redshift" if "luminosity_distance" in parameters else "luminosity_distance"] = opaque_like(None)
+        return parameters
 
     def variant(**kw):
         return base.clone(**{k: float(v) for k, v in kw.items()})
@@ -188,7 +202,7 @@ def convert_mtot_mni(params):
     the priors constrain.  Works on scalars and on columns."""
     for par in ("mni", "mtot", "mrp"):
         if par not in params:
-            params[par] = 10 ** np.asarray(params[f"log10_{par}"], dtype=float)
+            params[par] = np.power(10.0, params[f"log10_{par}"])
     params["mni_c"] = params["mni"] / params["mtot"]
     params["mrp_c"] = params["xmix"] * (params["mtot"] - params["mni"]) - params["mrp"]
     return params
@@ -262,8 +276,9 @@ def source_frame_masses(p, cosmology=None):
         p["redshift"] = luminosity_distance_to_redshift(p["luminosity_distance"], cosmology)
     if "redshift" in p and "mass_1" in p:
         z = p["redshift"]
-        p.setdefault("mass_1_source", np.array(p["mass_1"] / (1 + z)))
-        p.setdefault("mass_2_source", np.array(p["mass_2"] / (1 + z)))
+        wrap = (lambda x: x) if _symbolic(z, p["mass_1"], p["mass_2"]) else np.array
+        p.setdefault("mass_1_source", wrap(p["mass_1"] / (1 + z)))
+        p.setdefault("mass_2_source", wrap(p["mass_2"] / (1 + z)))
     return p
 
 
@@ -338,14 +353,20 @@ class MultimessengerConversion:
 
     @staticmethod
     def _scalar(v):
+        """``val_to_scalar`` (reference :19-27): single-value quantities become Python scalars."""
+        if _symbolic(v) or isinstance(v, (str, bytes)):
+            return v
         a = np.asarray(v)
-        return a.item() if a.size == 1 and a.ndim <= 1 and not isinstance(v, (str, bytes)) and a.dtype != object else v
+        return a.item() if a.size == 1 and a.ndim <= 1 and a.dtype != object else v
 
-    def convert_to_multimessenger_parameters(self, parameters, add_new_keys=False):
+    def convert_to_multimessenger_parameters(self, parameters, add_new_keys=False, batched=False):
+        """``batched=True`` (the constraint check of a BATCH of samples, columns in and columns out): nothing is collapsed to a
+        scalar -- a batch of one row keeps its shape-(1,) columns, which the messengers' converters index."""
         original_keys = list(parameters.keys())
-        converted = {k: self._scalar(v) for k, v in parameters.items()}
+        scalar = (lambda v: v) if batched else self._scalar
+        converted = {k: scalar(v) for k, v in parameters.items()}
         converted = self.core_conversion(converted)
-        converted = {k: self._scalar(v) for k, v in converted.items()}
+        converted = {k: scalar(v) for k, v in converted.items()}
         if add_new_keys:
             return converted, [k for k in converted if k not in original_keys]
         return converted

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <string>
 
 #include "../../include/nmma_hip.h"
@@ -49,6 +50,9 @@ __device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) 
             if (p.alpha == -1.0) return p.a * exp(u * log(p.b / p.a));
             return pow(pow(p.a, 1.0 + p.alpha) + u * (pow(p.b, 1.0 + p.alpha) - pow(p.a, 1.0 + p.alpha)), 1.0 / (1.0 + p.alpha));
         case NMMA_PRIOR_GAUSSIAN: return p.a + erfinv(2.0 * u - 1.0) * 1.4142135623730951 * p.b;      // mu, sigma
+        case NMMA_PRIOR_TRUNC_GAUSSIAN: return erfinv(2.0 * u * p.alpha + p.c) * 1.4142135623730951 * p.b + p.a;   // bilby TruncatedGaussian.rescale
+        case NMMA_PRIOR_LOGNORMAL: return exp(p.a + sqrt(2.0 * p.b * p.b) * erfinv(2.0 * u - 1.0));                // bilby LogNormal.rescale
+        case NMMA_PRIOR_HALF_GAUSSIAN: return erfinv(u) * 1.4142135623730951 * p.b;                                // bilby HalfGaussian.rescale
         default: return p.a;                                                                        // NMMA_PRIOR_DELTA: peak
     }
 }
@@ -60,11 +64,53 @@ __device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) 
 // The prior table is staged from the kernel arguments into LDS so that lanes can index it by their dimension.
 __device__ __forceinline__ int walk_group(const int D) { return D <= 8 ? 8 : D <= 16 ? 16 : 32; }
 
-static_assert(sizeof(nmma_walk_prior) == 32 && NMMA_WALK_MAX_DIM * 8 <= 256, "one dword of the table per thread of the workgroup");
+static_assert(sizeof(nmma_walk_prior) == 40 && NMMA_WALK_MAX_DIM * 10 <= 512, "at most two dwords of the table per thread of the workgroup");
 __device__ __forceinline__ void walk_stage_spec(const WalkSpec& S, nmma_walk_prior* sp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.p[0]);          // (the kernel-argument segment, read per thread)
-    if ((int)threadIdx.x < S.ndim * 8) reinterpret_cast<uint32_t*>(sp)[threadIdx.x] = src[threadIdx.x];
+    for (int j = threadIdx.x; j < S.ndim * 10; j += 256) reinterpret_cast<uint32_t*>(sp)[j] = src[j];
     __syncthreads();
+}
+
+// Constraint priors: the postfix program of include/nmma_hip.h (nmma_con_op) on one row of theta.  Uniform control flow (every
+// lane runs the same program); the stack is a handful of doubles.
+__device__ inline bool con_row_ok(const nmma_con_op* __restrict__ ops, const int n_ops, const double* __restrict__ row) {
+    double st[NMMA_CON_MAX_STACK];
+    int sp = 0;
+    bool ok = true;
+    for (int i = 0; i < n_ops; ++i) {
+        const nmma_con_op o = ops[i];
+        switch (o.op) {
+            case NMMA_CON_PUSH_COL: st[sp++] = row[o.col]; break;
+            case NMMA_CON_PUSH_CONST: st[sp++] = o.value; break;
+            case NMMA_CON_ADD: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
+            case NMMA_CON_SUB: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
+            case NMMA_CON_MUL: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
+            case NMMA_CON_DIV: st[sp - 2] = st[sp - 2] / st[sp - 1]; --sp; break;
+            case NMMA_CON_POW: st[sp - 2] = pow(st[sp - 2], st[sp - 1]); --sp; break;
+            case NMMA_CON_MIN: st[sp - 2] = fmin(st[sp - 2], st[sp - 1]); --sp; break;
+            case NMMA_CON_MAX: st[sp - 2] = fmax(st[sp - 2], st[sp - 1]); --sp; break;
+            case NMMA_CON_NEG: st[sp - 1] = -st[sp - 1]; break;
+            case NMMA_CON_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
+            case NMMA_CON_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+            case NMMA_CON_LOG10: st[sp - 1] = log10(st[sp - 1]); break;
+            case NMMA_CON_LOG: st[sp - 1] = log(st[sp - 1]); break;
+            case NMMA_CON_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+            case NMMA_CON_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+            case NMMA_CON_COS: st[sp - 1] = cos(st[sp - 1]); break;
+            case NMMA_CON_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
+            case NMMA_CON_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
+            case NMMA_CON_SIGN: { const double x = st[sp - 1]; st[sp - 1] = x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); } break;
+            case NMMA_CON_CHECK_GT: ok = ok && (st[sp - 1] > o.value); break;
+            default: ok = ok && (st[sp - 1] < o.value); --sp; break;          // NMMA_CON_CHECK_LT
+        }
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void con_floor_kernel(const nmma_con_op* __restrict__ ops, const int n_ops, const double* __restrict__ theta,
+                                                        const long B, const long ld, double* __restrict__ logl) {
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b < B && !con_row_ok(ops, n_ops, theta + b * ld)) logl[b] = NMMA_LOGL_FLOOR;
 }
 
 // proposal in the unit cube (differential evolution between two other live points), boundary conditions, inside-the-cube flag, prior
@@ -114,10 +160,13 @@ __global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, con
 __device__ __forceinline__ void walk_accept_one(const int D, const long c, const int lane, const double* prop, const double* theta,
                                                 const int32_t* inside, const double* __restrict__ l_prop, const double* __restrict__ loglstar,
                                                 double* u, double* v, double* __restrict__ logl, int32_t* __restrict__ counts,
-                                                const int32_t* __restrict__ n_steps, const uint64_t step) {
+                                                const int32_t* __restrict__ n_steps, const uint64_t step,
+                                                const nmma_con_op* __restrict__ con_ops = nullptr, const int n_con_ops = 0) {
     if (n_steps != nullptr && step > (uint64_t)n_steps[c]) return;       // this chain's walk is over (walk lengths may differ per chain)
     const int in = inside[c];
-    const double lp = l_prop[c];
+    double lp = l_prop[c];
+    // a Constraint prior the proposal violates: the reference's likelihood returns the floor for it (core/base.py:77-82)
+    if (n_con_ops > 0 && in && !con_row_ok(con_ops, n_con_ops, theta + c * D)) lp = NMMA_LOGL_FLOOR;
     const bool acc = in && lp > loglstar[c];
     if (acc && lane < D) { u[c * D + lane] = prop[c * D + lane]; v[c * D + lane] = theta[c * D + lane]; }
     if (lane == 0) {
@@ -136,10 +185,40 @@ __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const lon
                                                           const double* __restrict__ l_prop, const double* __restrict__ loglstar,
                                                           double* __restrict__ u, double* __restrict__ v, double* __restrict__ logl,
                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ n_steps,
-                                                          const uint64_t step) {
+                                                          const uint64_t step, const nmma_con_op* __restrict__ con_ops, const int n_con_ops) {
     const int T = walk_group(D);
     const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
-    if (c < n) walk_accept_one(D, c, threadIdx.x % T, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step);
+    if (c < n) walk_accept_one(D, c, threadIdx.x % T, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
+}
+
+// End of a queue (sampler.py: run_many): a chain that never accepted returns a fresh draw from the prior -- u = the counter hash of
+// (key, step 0, dimension), v = theta = its prior transform; the likelihood launch that follows evaluates it and walk_fresh_logl_kernel
+// files the value.  A group of lanes per chain as in walk_step_kernel.
+__global__ __launch_bounds__(256) void walk_fresh_kernel(const WalkSpec S, const uint64_t* __restrict__ key, const long n, double* u, double* v,
+                                                         double* theta, const int32_t* __restrict__ counts, int32_t* __restrict__ stuck) {
+    __shared__ nmma_walk_prior sp[NMMA_WALK_MAX_DIM];
+    walk_stage_spec(S, sp);
+    const int D = S.ndim, T = walk_group(D);
+    const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
+    if (c >= n) return;
+    const int lane = threadIdx.x % T;
+    const int never = counts[4 * c] == 0;
+    if (lane == 0) stuck[c] = never;
+    if (never && lane < D) {
+        const double x = walk_uniform(key[c], 0ull, (uint64_t)lane);
+        const double t = walk_rescale(sp[lane], x);
+        u[c * D + lane] = x; v[c * D + lane] = t; theta[c * D + lane] = t;
+    }
+}
+__global__ __launch_bounds__(256) void walk_fresh_logl_kernel(const long n, const int D, const int32_t* __restrict__ stuck, const double* __restrict__ l_prop,
+                                                              const double* __restrict__ theta, double* __restrict__ logl, int32_t* __restrict__ counts,
+                                                              const nmma_con_op* __restrict__ con_ops, const int n_con_ops) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n || !stuck[c]) return;
+    double lp = l_prop[c];
+    if (n_con_ops > 0 && !con_row_ok(con_ops, n_con_ops, theta + c * D)) lp = NMMA_LOGL_FLOOR;
+    logl[c] = lp;
+    counts[4 * c + 3] += 1;
 }
 
 // accept of step `step` and proposal of step `step + 1` in one launch (a chain's accept touches only its own row, and its next proposal
@@ -150,14 +229,14 @@ __global__ __launch_bounds__(256) void walk_step_kernel(const WalkSpec S, const 
                                                         int32_t* inside, const double* __restrict__ l_prop,
                                                         const double* __restrict__ loglstar, double* u, double* v, double* __restrict__ logl,
                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ n_steps, const uint64_t step,
-                                                        const uint64_t first_step) {
+                                                        const uint64_t first_step, const nmma_con_op* __restrict__ con_ops, const int n_con_ops) {
     __shared__ nmma_walk_prior sp[NMMA_WALK_MAX_DIM];
     walk_stage_spec(S, sp);
     const int T = walk_group(S.ndim);
     const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
     if (c >= n) return;
     const int lane = threadIdx.x % T;
-    walk_accept_one(S.ndim, c, lane, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step);
+    walk_accept_one(S.ndim, c, lane, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
     walk_propose_one(sp, S.ndim, T, c, lane, live, n_live, u, v, key, first_step + step, prop, theta, inside);
 }
 
@@ -263,7 +342,7 @@ static int walk_spec(const nmma_walk_prior* priors, int32_t ndim, WalkSpec* S, c
     if (!priors || ndim < 1 || ndim > NMMA_WALK_MAX_DIM) return fail(std::string(what) + ": 1 .. NMMA_WALK_MAX_DIM dimensions");
     S->ndim = ndim;
     for (int d = 0; d < ndim; ++d) {
-        if (priors[d].kind < NMMA_PRIOR_UNIFORM || priors[d].kind > NMMA_PRIOR_DELTA) return fail(std::string(what) + ": unknown prior kind");
+        if (priors[d].kind < NMMA_PRIOR_UNIFORM || priors[d].kind > NMMA_PRIOR_HALF_GAUSSIAN) return fail(std::string(what) + ": unknown prior kind");
         S->p[d] = priors[d];
     }
     return 0;
@@ -299,7 +378,8 @@ int32_t nmma_walk_accept(int32_t ndim, int64_t n, const double* prop_dev, const 
     if (n == 0) return 0;
     if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_accept: hipSetDevice failed");
     hipLaunchKernelGGL(walk_accept_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), (int)ndim, (long)n,
-                       prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, n_steps_dev, step);
+                       prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev, counts_dev, n_steps_dev, step,
+                       (const nmma_con_op*)nullptr, 0);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_accept launch failed: ") + hipGetErrorString(e));
     return 0;
@@ -318,7 +398,7 @@ int32_t nmma_walk_step(const nmma_walk_prior* priors, int32_t ndim, const double
     if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_step: hipSetDevice failed");
     hipLaunchKernelGGL(walk_step_kernel, dim3(walk_blocks(n, ndim)), dim3(256), 0, static_cast<hipStream_t>(stream), S, live_dev,
                        (long)n_live, key_dev, (long)n, prop_dev, theta_dev, inside_dev, logl_prop_dev, loglstar_dev, u_dev, v_dev, logl_dev,
-                       counts_dev, n_steps_dev, step, first_step);
+                       counts_dev, n_steps_dev, step, first_step, (const nmma_con_op*)nullptr, 0);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_step launch failed: ") + hipGetErrorString(e));
     return 0;
@@ -375,6 +455,200 @@ int32_t nmma_walk_rescale(const nmma_walk_prior* priors, int32_t ndim, const dou
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("nmma_walk_rescale launch failed: ") + hipGetErrorString(e));
     return 0;
+}
+
+// ---- constraint programs -------------------------------------------------------------------------------------------------------------
+struct nmma_con_program {
+    int32_t device = 0, n_ops = 0, n_cols = 0;
+    nmma_con_op* ops_d = nullptr;
+};
+
+int32_t nmma_con_create(const nmma_con_op* ops, int32_t n_ops, int32_t n_cols, int32_t device, nmma_con_program** out) {
+    using namespace nmma;
+    if (!ops || !out || n_ops < 1 || n_ops > NMMA_CON_MAX_OPS || n_cols < 1) return fail("nmma_con_create: bad argument (1 .. NMMA_CON_MAX_OPS operations)");
+    *out = nullptr;
+    int sp = 0;                       // the program is validated on the host: the kernel then runs it unchecked
+    for (int i = 0; i < n_ops; ++i) {
+        const int op = ops[i].op;
+        if (op == NMMA_CON_PUSH_COL || op == NMMA_CON_PUSH_CONST) {
+            if (op == NMMA_CON_PUSH_COL && (ops[i].col < 0 || ops[i].col >= n_cols)) return fail("nmma_con_create: column out of range");
+            if (++sp > NMMA_CON_MAX_STACK) return fail("nmma_con_create: expression too deep (NMMA_CON_MAX_STACK)");
+        } else if (op >= NMMA_CON_ADD && op <= NMMA_CON_MAX) {
+            if (sp < 2) return fail("nmma_con_create: stack underflow");
+            --sp;
+        } else if ((op >= NMMA_CON_NEG && op <= NMMA_CON_SIGN) || op == NMMA_CON_CHECK_GT) {
+            if (sp < 1) return fail("nmma_con_create: stack underflow");
+        } else if (op == NMMA_CON_CHECK_LT) {
+            if (sp < 1) return fail("nmma_con_create: stack underflow");
+            --sp;
+        } else return fail("nmma_con_create: unknown operation");
+    }
+    if (sp != 0) return fail("nmma_con_create: values left on the stack (every expression ends in CHECK_GT, CHECK_LT)");
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_con_create: hipSetDevice failed (no CPU fallback)");
+    auto* p = new nmma_con_program();
+    p->device = device; p->n_ops = n_ops; p->n_cols = n_cols;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ops_d), sizeof(nmma_con_op) * n_ops);
+    if (e == hipSuccess) e = hipMemcpy(p->ops_d, ops, sizeof(nmma_con_op) * n_ops, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->ops_d) (void)hipFree(p->ops_d);
+        delete p;
+        return fail(std::string("nmma_con_create: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return 0;
+}
+
+void nmma_con_destroy(nmma_con_program* p) {
+    if (!p) return;
+    if (p->ops_d) { (void)hipSetDevice(p->device); (void)hipFree(p->ops_d); }
+    delete p;
+}
+
+int32_t nmma_con_floor(const nmma_con_program* p, const double* theta_dev, int64_t B, int64_t ld, double* logl_dev, void* stream) {
+    using namespace nmma;
+    if (!p || !theta_dev || !logl_dev || B < 0 || ld < p->n_cols) return fail("nmma_con_floor: bad argument (ld must cover the program's columns)");
+    if (B == 0) return 0;
+    if (hipSetDevice(p->device) != hipSuccess) return fail("nmma_con_floor: hipSetDevice failed");
+    hipLaunchKernelGGL(con_floor_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p->ops_d, (int)p->n_ops,
+                       theta_dev, (long)B, (long)ld, logl_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("nmma_con_floor launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- a whole queue of the nested sampler -----------------------------------------------------------------------------------------------
+// Workspace: ONE device allocation and ONE pinned host mirror with the same layout,
+//   [ live | loglstar | key | walks | u ][ v | logl | counts ]  prop | theta | l_prop | inside | stuck
+//   '------------- upload ------------'
+//                               '------- download ---------'
+// so that a queue costs one host-to-device and one device-to-host copy.
+struct nmma_walk_ws {
+    int32_t device = 0;
+    size_t cap = 0;                 // bytes of each of the two buffers
+    unsigned char* dev = nullptr;
+    unsigned char* pin = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int32_t nmma_walk_ws_create(int32_t device, nmma_walk_ws** out) {
+    using namespace nmma;
+    if (!out) return fail("nmma_walk_ws_create: null argument");
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail("nmma_walk_ws_create: hipSetDevice failed (no CPU fallback)");
+    auto* ws = new nmma_walk_ws();
+    ws->device = device;
+    if (hipEventCreate(&ws->ev0) != hipSuccess || hipEventCreate(&ws->ev1) != hipSuccess) { delete ws; return fail("nmma_walk_ws_create: hipEventCreate failed"); }
+    *out = ws;
+    return 0;
+}
+
+void nmma_walk_ws_destroy(nmma_walk_ws* ws) {
+    if (!ws) return;
+    (void)hipSetDevice(ws->device);
+    if (ws->dev) (void)hipFree(ws->dev);
+    if (ws->pin) (void)hipHostFree(ws->pin);
+    if (ws->ev0) (void)hipEventDestroy(ws->ev0);
+    if (ws->ev1) (void)hipEventDestroy(ws->ev1);
+    delete ws;
+}
+
+int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream) {
+    using namespace nmma;
+    if (!h || !ws || !q) return fail("nmma_em_walk_queue: null argument");
+    WalkSpec S;
+    if (walk_spec(q->priors, q->ndim, &S, "nmma_em_walk_queue")) return 1;
+    const long n = (long)q->n, D = q->ndim, NL = (long)q->n_live;
+    if (n < 0 || NL < 3 || !q->live || !q->u0 || !q->loglstar || !q->key || !q->u || !q->v || !q->logl || !q->counts ||
+        (!q->walks_per_chain && q->walks < 1))
+        return fail("nmma_em_walk_queue: bad argument (at least three live points, walks >= 1)");
+    if (q->constraints && (q->constraints->device != ws->device || q->constraints->n_cols > D))
+        return fail("nmma_em_walk_queue: the constraint program belongs to another device or reads columns the walk does not sample");
+    q->gpu_ms = 0.0;
+    if (n == 0) return 0;
+    if (hipSetDevice(ws->device) != hipSuccess) return fail("nmma_em_walk_queue: hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    size_t off = 0;
+    const size_t o_live = off;  off = al(off + sizeof(double) * NL * D);
+    const size_t o_star = off;  off = al(off + sizeof(double) * n);
+    const size_t o_key = off;   off = al(off + sizeof(uint64_t) * n);
+    const size_t o_walks = off; off = al(off + sizeof(int32_t) * n);
+    const size_t o_u = off;     off = al(off + sizeof(double) * n * D);
+    const size_t up_end = off;
+    const size_t o_v = off;     off = al(off + sizeof(double) * n * D);
+    const size_t o_logl = off;  off = al(off + sizeof(double) * n);
+    const size_t o_cnt = off;   off = al(off + sizeof(int32_t) * 4 * n);
+    const size_t down_end = off;
+    const size_t o_prop = off;  off = al(off + sizeof(double) * n * D);
+    const size_t o_theta = off; off = al(off + sizeof(double) * n * D);
+    const size_t o_lp = off;    off = al(off + sizeof(double) * n);
+    const size_t o_in = off;    off = al(off + sizeof(int32_t) * n);
+    const size_t o_stuck = off; off = al(off + sizeof(int32_t) * n);
+    if (off > ws->cap) {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail("nmma_em_walk_queue: stream error before growing the workspace");
+        if (ws->dev) (void)hipFree(ws->dev);
+        if (ws->pin) (void)hipHostFree(ws->pin);
+        ws->dev = ws->pin = nullptr; ws->cap = 0;
+        const size_t want = off + off / 4;
+        if (hipMalloc(reinterpret_cast<void**>(&ws->dev), want) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&ws->pin), want, hipHostMallocDefault) != hipSuccess)
+            return fail("nmma_em_walk_queue: out of memory for the walk workspace");
+        ws->cap = want;
+    }
+    unsigned char *d = ws->dev, *p = ws->pin;
+    memcpy(p + o_live, q->live, sizeof(double) * NL * D);
+    memcpy(p + o_star, q->loglstar, sizeof(double) * n);
+    memcpy(p + o_key, q->key, sizeof(uint64_t) * n);
+    int max_walks = q->walks;
+    if (q->walks_per_chain) {
+        memcpy(p + o_walks, q->walks_per_chain, sizeof(int32_t) * n);
+        max_walks = 0;
+        for (long c = 0; c < n; ++c) max_walks = q->walks_per_chain[c] > max_walks ? q->walks_per_chain[c] : max_walks;
+    }
+    memcpy(p + o_u, q->u0, sizeof(double) * n * D);
+    // NaN = "never moved" (sampler.py: run_many); the counts start at zero
+    { double* lg = reinterpret_cast<double*>(p + o_logl); for (long c = 0; c < n; ++c) lg[c] = __builtin_nan(""); }
+    memset(p + o_cnt, 0, sizeof(int32_t) * 4 * n);
+#define NMQ(call, what) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return fail(std::string("nmma_em_walk_queue: ") + what + ": " + hipGetErrorString(e_)); } while (0)
+    NMQ(hipEventRecord(ws->ev0, s), "event");
+    NMQ(hipMemcpyAsync(d, p, up_end, hipMemcpyHostToDevice, s), "upload");
+    NMQ(hipMemcpyAsync(d + o_logl, p + o_logl, o_prop - o_logl, hipMemcpyHostToDevice, s), "upload of the initial state");
+    double *live_d = reinterpret_cast<double*>(d + o_live), *star_d = reinterpret_cast<double*>(d + o_star), *u_d = reinterpret_cast<double*>(d + o_u),
+           *v_d = reinterpret_cast<double*>(d + o_v), *logl_d = reinterpret_cast<double*>(d + o_logl), *prop_d = reinterpret_cast<double*>(d + o_prop),
+           *theta_d = reinterpret_cast<double*>(d + o_theta), *lp_d = reinterpret_cast<double*>(d + o_lp);
+    const uint64_t* key_d = reinterpret_cast<const uint64_t*>(d + o_key);
+    const int32_t* walks_d = q->walks_per_chain ? reinterpret_cast<const int32_t*>(d + o_walks) : nullptr;
+    int32_t *cnt_d = reinterpret_cast<int32_t*>(d + o_cnt), *in_d = reinterpret_cast<int32_t*>(d + o_in), *stuck_d = reinterpret_cast<int32_t*>(d + o_stuck);
+    const nmma_con_op* con_ops = q->constraints ? q->constraints->ops_d : nullptr;
+    const int n_con = q->constraints ? q->constraints->n_ops : 0;
+    const dim3 grid_g(walk_blocks(n, (int32_t)D)), grid_t((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(walk_rescale_kernel, grid_t, block, 0, s, S, n, u_d, v_d);
+    hipLaunchKernelGGL(walk_propose_kernel, grid_g, block, 0, s, S, live_d, NL, u_d, v_d, key_d, n, q->first_step, prop_d, theta_d, in_d);
+    for (int k = 1; k <= max_walks; ++k) {
+        if (nmma_em_loglike(h, theta_d, n, D, lp_d, stream)) return 1;
+        if (k < max_walks)
+            hipLaunchKernelGGL(walk_step_kernel, grid_g, block, 0, s, S, live_d, NL, key_d, n, prop_d, theta_d, in_d, lp_d, star_d, u_d, v_d, logl_d, cnt_d,
+                               walks_d, (uint64_t)k, q->first_step, con_ops, n_con);
+        else
+            hipLaunchKernelGGL(walk_accept_kernel, grid_g, block, 0, s, (int)D, n, prop_d, theta_d, in_d, lp_d, star_d, u_d, v_d, logl_d, cnt_d, walks_d,
+                               (uint64_t)k, con_ops, n_con);
+    }
+    hipLaunchKernelGGL(walk_fresh_kernel, grid_g, block, 0, s, S, key_d, n, u_d, v_d, theta_d, cnt_d, stuck_d);
+    if (nmma_em_loglike(h, theta_d, n, D, lp_d, stream)) return 1;
+    hipLaunchKernelGGL(walk_fresh_logl_kernel, grid_t, block, 0, s, n, (int)D, stuck_d, lp_d, theta_d, logl_d, cnt_d, con_ops, n_con);
+    NMQ(hipGetLastError(), "launch");
+    NMQ(hipMemcpyAsync(p + o_u, d + o_u, down_end - o_u, hipMemcpyDeviceToHost, s), "download");
+    NMQ(hipEventRecord(ws->ev1, s), "event");
+    NMQ(hipStreamSynchronize(s), "stream");
+    float ms = 0.f;
+    NMQ(hipEventElapsedTime(&ms, ws->ev0, ws->ev1), "event time");
+#undef NMQ
+    q->gpu_ms = ms;
+    memcpy(q->u, p + o_u, sizeof(double) * n * D);
+    memcpy(q->v, p + o_v, sizeof(double) * n * D);
+    memcpy(q->logl, p + o_logl, sizeof(double) * n);
+    memcpy(q->counts, p + o_cnt, sizeof(int32_t) * 4 * n);
+    return nmma_em_check(h) ? 1 : 0;
 }
 
 }  // extern "C"

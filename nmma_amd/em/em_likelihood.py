@@ -163,16 +163,11 @@ class EMTransientLikelihood(NMMALikelihood):
         return out
 
     def _apply_constraints_batch(self, out, theta, names):
-        """core/base.py:67-68, :77-82 for a batch: the conversion functions run on columns (they are numpy-vectorised),
-        every Constraint's ``prob`` is evaluated on its derived column, and rows whose product is 0 get the floor."""
-        import torch
+        """core/base.py:67-68, :77-82 for a batch: on the device for a CUDA ``theta`` (the conversion chain traced into a
+        constraint program, ``core/constraints.py``), numpy on the converted columns for host arrays."""
         cols = list(names) if names is not None else self.sub_model.engine().parameter_names
-        th = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta, dtype=float)
-        params = {n: th[:, i] for i, n in enumerate(cols)}
         _, fixed = self.sub_model.sampling_layout()
-        for key, val in fixed.items():
-            params.setdefault(key, np.full(len(th), val))
-        return self.floor_constrained_rows(out, params)
+        return self.apply_constraints_batch(out, theta, cols, fixed)
 
     def parameter_names(self):
         return self.sub_model.sampling_layout()[0]

@@ -523,7 +523,46 @@ class EMEngine:
         """Synchronise and raise if an earlier asynchronous launch failed (kernel watchdog)."""
         L.check(self._lib.nmma_em_check(self._handle), "nmma_em_check")
 
+    def walk_queue(self, table, live, u0, loglstar, keys, walks, constraints=None, first_step=1, stream=None):
+        """One queue of the nested sampler -- ``len(u0)`` chains of the fixed-length ensemble walk, ``walks`` steps each (an int
+        or one length per chain) -- in ONE library call (``nmma_em_walk_queue``): packed upload, per step the likelihood launch
+        and accept + next proposal, fresh prior draws for chains that never moved, packed download.  Host arrays in and out:
+        ``(u[n, D], v[n, D], logl[n], counts[n, 4] = accept, reject, outside-the-cube, likelihood calls)``; ``self.last_walk_gpu_ms``
+        holds the device time of the call.  ``constraints``: a ``nmma_amd.core.constraints.ConstraintProgram`` or None."""
+        import torch
+        live, u0 = _f64(live), _f64(u0)
+        n, ndim = u0.shape
+        if len(table) != ndim or live.ndim != 2 or live.shape[1] != ndim or ndim != len(self.parameter_names):
+            raise L.NMMAHipError(f"walk_queue: {ndim} sampled dimensions, a prior table of {len(table)}, live points {live.shape}, "
+                                 f"the engine's {len(self.parameter_names)} columns")
+        star = np.ascontiguousarray(np.broadcast_to(np.asarray(loglstar, dtype=np.float64), (n,)))
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        per_chain = np.ndim(walks) > 0
+        wl = np.ascontiguousarray(walks, dtype=np.int32) if per_chain else None
+        if keys.shape != (n,) or (per_chain and wl.shape != (n,)):
+            raise L.NMMAHipError("walk_queue: one key (and walk length) per chain")
+        if getattr(self, "_walk_ws", None) is None:
+            ws = C.c_void_p()
+            L.check(self._lib.nmma_walk_ws_create(self.device, C.byref(ws)), "nmma_walk_ws_create")
+            self._walk_ws = ws
+        u, v = np.empty((n, ndim)), np.empty((n, ndim))
+        logl, counts = np.empty(n), np.empty((n, 4), dtype=np.int32)
+        q = L.WalkQueue()
+        q.priors, q.ndim, q.walks = table, ndim, 0 if per_chain else int(walks)
+        q.live, q.n_live, q.u0, q.loglstar, q.key = live.ctypes.data, live.shape[0], u0.ctypes.data, star.ctypes.data, keys.ctypes.data
+        q.walks_per_chain = wl.ctypes.data if per_chain else None
+        q.n, q.first_step = n, int(first_step)
+        q.constraints = constraints.handle if constraints is not None else None
+        q.u, q.v, q.logl, q.counts = u.ctypes.data, v.ctypes.data, logl.ctypes.data, counts.ctypes.data
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        L.check(self._lib.nmma_em_walk_queue(self._handle, self._walk_ws, C.byref(q), C.c_void_p(s.cuda_stream)), "nmma_em_walk_queue")
+        self.last_walk_gpu_ms = float(q.gpu_ms)
+        return u, v, logl, counts
+
     def close(self):
+        if getattr(self, "_walk_ws", None):
+            self._lib.nmma_walk_ws_destroy(self._walk_ws)
+            self._walk_ws = None
         if getattr(self, "_handle", None):
             self._lib.nmma_em_destroy(self._handle)
             self._handle = None

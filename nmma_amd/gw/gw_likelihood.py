@@ -566,8 +566,5 @@ class GravitationalWaveTransientLikelihood(NMMALikelihood):
         ratio = self.sub_model.log_likelihood_ratio_batch(th, gw_names, out=out, stream=stream)
         logl = torch.where(ratio > LOGL_FLOOR, ratio + self.sub_model.noise_log_likelihood(), ratio)
         if self.constraints:
-            host = theta.detach().cpu().numpy() if isinstance(theta, torch.Tensor) else np.asarray(theta)
-            columns = {n: host[:, i] for i, n in enumerate(names)}
-            columns.update(self.sub_model.fixed_parameters(names))
-            logl = self.floor_constrained_rows(logl, columns)
+            logl = self.apply_constraints_batch(logl, theta, names, self.sub_model.fixed_parameters(names))
         return logl

@@ -103,6 +103,18 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
             parameters = lh.parameter_conversion(parameters)
         return parameters
 
+    def _batched_conversion(self, columns):
+        """``parameter_conversion`` for columns (a batch of samples, or the symbolic columns of the constraint tracer): the
+        ``MultimessengerConversion`` chain without its scalar unwrapping."""
+        if self.multi_conversion is not None:
+            return self.multi_conversion.convert_to_multimessenger_parameters(columns, batched=True)
+        for lh in self.likelihoods:
+            columns = lh.parameter_conversion(columns)
+        return columns
+
+    def conversion_chain(self):
+        return [self._batched_conversion]
+
     def posterior_conversion(self, posterior_samples):
         for lh in self.likelihoods:
             posterior_samples = lh.posterior_conversion(posterior_samples)
@@ -156,8 +168,23 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
                                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                     "nmma_logl_sum_floor")
         if self.constraints:
-            total = self.floor_constrained_rows(total, self._columns(theta, names))
+            total = self._apply_joint_constraints(total, theta, names)
         return total if as_torch else total.cpu().numpy()
+
+    def _apply_joint_constraints(self, total, theta, names):
+        """The joint prior's Constraint entries on the batch: on the device when ``theta`` is a CUDA tensor and every constrained
+        quantity is traceable arithmetic of the sampled columns (mass_1 / mass_2 from chirp mass and mass ratio, ...), else the
+        numpy mask on the converted columns."""
+        import torch
+        from ..core.base import fixed_value, is_constraint
+        if isinstance(theta, torch.Tensor) and theta.is_cuda:
+            cols = list(names) if names is not None else [k for k, p in self.priors.items() if fixed_value(p) is None and not is_constraint(p)]
+            fixed = {k: fixed_value(p) for k, p in self.priors.items() if fixed_value(p) is not None and k not in cols}
+            prog = self.device_constraints(cols, fixed, theta.device.index or 0)
+            if prog is not None:
+                th = theta if (theta.dtype == torch.float64 and theta.is_contiguous()) else theta.to(torch.float64).contiguous()
+                return prog.floor(th, total)
+        return self.floor_constrained_rows(total, self._columns(theta, names))
 
     def _columns(self, theta, names):
         """Sampled columns + fixed priors as a dict of arrays: what ``parameter_conversion`` and the constraints work on."""
@@ -178,7 +205,7 @@ class MultiMessengerLikelihood(NMMALikelihoodMixin, _BilbyLikelihood):
         """As the mixin's, with a clear error when a constrained key is neither a column nor derived by a messenger's
         conversion (the reference would raise the same KeyError per sample, core/base.py:67-68)."""
         from .. import _lib as L
-        converted = self.parameter_conversion(dict(columns))
+        converted = self._batched_conversion(dict(columns))
         missing = [k for k in self.constraints if k not in converted]
         if missing:
             raise L.NMMAHipError(f"Constraint priors on {missing} cannot be evaluated on the batched path: no messenger's "

@@ -75,9 +75,31 @@ class GPUPool:
         """theta[n, D] CUDA tensor -> logL[n] CUDA tensor (the device walk's likelihood step)."""
         return self.likelihood.log_likelihood_batch(theta, self.names)
 
+    def _walk_engine(self):
+        """(engine, constraint program) when the likelihood is ONE EM surrogate likelihood -- its queue then runs as one library
+        call (``EMEngine.walk_queue``); ``(None, None)`` for everything else (joint likelihoods, combined models, constraint sets
+        without a device form): the walk is then driven step by step around ``log_likelihood_batch``."""
+        lik = self.likelihood
+        sub = getattr(lik, "sub_model", None)
+        if sub is None or not hasattr(sub, "engine") or hasattr(getattr(sub, "light_curve_model", None), "stacked_lightcurves_abs"):
+            return None, None
+        from .em.em_likelihood import EMTransientLikelihood
+        if getattr(type(lik), "log_likelihood_batch", None) is not EMTransientLikelihood.log_likelihood_batch:
+            return None, None                     # (another likelihood class, or a subclass with its own batched evaluation)
+        names = list(self.names)
+        eng = sub.engine(names)
+        prog = None
+        if getattr(lik, "constraints", None):
+            _, fixed = sub.sampling_layout()
+            prog = lik.device_constraints(names, {k: v for k, v in fixed.items() if k not in names}, eng.device)
+            if prog is None:
+                return None, None
+        return eng, prog
+
     def map(self, func, iterable, callback=None):
-        items = list(iterable)
-        if not items:
+        from .sampler import SamplerArgumentBatch
+        items = iterable if isinstance(iterable, (list, SamplerArgumentBatch)) else list(iterable)
+        if not len(items):
             return []
         if getattr(func, "__self__", None) is self and getattr(func, "__func__", None) is GPUPool.log_likelihood:
             res = list(self.log_likelihood_many(items))
@@ -86,8 +108,11 @@ class GPUPool:
             # (dynesty 3): the queue of chains advances together, one likelihood launch per MCMC step
             walker = func if hasattr(func, "run_many") else func.__self__
             if self.device_walk and self.priors is not None and self.names is not None and hasattr(walker, "run_many_device"):
+                kw = {}
+                if "engine" in walker.run_many_device.__code__.co_varnames:
+                    kw["engine"], kw["constraints"] = self._walk_engine()
                 res = walker.run_many_device(items, self._log_likelihood_device, self.priors, self.names, device=self.device,
-                                             loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many)
+                                             loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many, **kw)
                 self.n_batches += getattr(walker, "n_batches", 0)
                 self.n_evals += getattr(walker, "n_evals", 0)
             else:

@@ -33,6 +33,8 @@ steps per chain; ``AcceptanceTrackingRWalk`` runs until ``nact`` autocorrelation
 """
 from __future__ import annotations
 
+from collections.abc import Sequence
+
 import numpy as np
 
 _GOLDEN = np.uint64(0x9E3779B97F4A7C15)
@@ -71,6 +73,19 @@ def chain_key(rseed):
     if isinstance(rseed, np.random.SeedSequence):
         return int(rseed.generate_state(1, dtype=np.uint64)[0])
     return int(np.random.default_rng(rseed).integers(0, 2 ** 63 - 1))
+
+
+def chain_keys(rseeds):
+    """``chain_key`` for a whole queue: one vectorised pass when the seeds are integers (dynesty 3 hands out an integer array)."""
+    a = rseeds if isinstance(rseeds, np.ndarray) else None
+    if a is None:
+        try:
+            a = np.asarray(rseeds)
+        except (TypeError, ValueError):
+            a = None
+    if a is not None and a.dtype.kind in "iu" and a.ndim == 1:
+        return a.astype(np.uint64, copy=False) if a.dtype.kind == "u" else a.astype(np.int64).view(np.uint64)
+    return np.array([chain_key(r) for r in rseeds], dtype=np.uint64)
 
 
 class BatchedPriorTransform:
@@ -117,6 +132,84 @@ class SamplerReturn(tuple):
     tuning_info = property(lambda self: self[4])
 
 
+class SamplerArgumentBatch(Sequence):
+    """What ``prepare_sampler`` returns: the queue's argument records as ONE set of arrays (start points ``u[n, D]``, seeds
+    ``[n]``) plus what the records share (bound, callables, walker kwargs).  It is a sequence of :class:`SamplerArgument` -- a
+    driver that indexes or iterates it gets the per-record objects -- but ``GPUPool.map`` and ``run_many_device`` read the arrays
+    directly: building, then unpacking, 4096 Python records costs more than the queue's whole device time."""
+
+    def __init__(self, u, loglstar, rseeds, prior_transform, loglikelihood, kwargs, axes=None, scale=1.0):
+        self.u = np.ascontiguousarray(u, dtype=float)
+        self.loglstar, self.rseeds = loglstar, rseeds
+        self.prior_transform, self.loglikelihood, self.kwargs = prior_transform, loglikelihood, kwargs
+        self.axes, self.scale = axes, scale
+
+    def __len__(self):
+        return len(self.u)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        star = self.loglstar[i] if np.ndim(self.loglstar) else self.loglstar
+        axes = self.axes[i] if isinstance(self.axes, (list, tuple)) or np.ndim(self.axes) > 2 else self.axes
+        return SamplerArgument(u=self.u[i], loglstar=star, rseed=self.rseeds[i], prior_transform=self.prior_transform,
+                               loglikelihood=self.loglikelihood, kwargs=self.kwargs, axes=axes, scale=self.scale)
+
+    def keys(self):
+        return chain_keys(self.rseeds)
+
+    def bounds(self):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(self.loglstar, dtype=float), (len(self),)))
+
+
+class WalkResults(Sequence):
+    """The queue's results as arrays; item ``q`` is the :class:`SamplerReturn` ``(u, v, logl, ncall, blob)`` dynesty expects, built
+    when it is asked for.  ``list(results)`` materialises all records (what dynesty's ``self.queue = list(mapper(...))`` does)."""
+
+    def __init__(self, u, v, logl, ncall, accept, reject, scale, walks=None):
+        self.u, self.v, self.logl, self.ncall, self.accept, self.reject = u, v, logl, ncall, accept, reject
+        self.scale, self.walks = scale, walks
+
+    def __len__(self):
+        return len(self.logl)
+
+    def _blob(self, q):
+        blob = {"accept": int(self.accept[q]), "reject": int(self.reject[q]),
+                "scale": float(self.scale[q]) if np.ndim(self.scale) else self.scale}
+        if self.walks is not None:
+            blob["walks"] = int(self.walks[q]) if np.ndim(self.walks) else int(self.walks)
+        return blob
+
+    def __getitem__(self, q):
+        if isinstance(q, slice):
+            return [self[j] for j in range(*q.indices(len(self)))]
+        if q < 0:
+            q += len(self)
+        if not 0 <= q < len(self):
+            raise IndexError(q)
+        return SamplerReturn(self.u[q], self.v[q], float(self.logl[q]), int(self.ncall[q]), self._blob(q))
+
+    def __iter__(self):
+        # (plain Python numbers from tolist(): building 4096 records costs ~2 ms this way, ~5 ms through numpy scalars)
+        acc, rej, ncall, ll = (np.asarray(a).tolist() for a in (self.accept, self.reject, self.ncall, self.logl))
+        scale = np.broadcast_to(self.scale, (len(self),)).tolist()
+        walks = None if self.walks is None else np.broadcast_to(self.walks, (len(self),)).tolist()
+        u, v = self.u, self.v
+        for q in range(len(self)):
+            blob = {"accept": acc[q], "reject": rej[q], "scale": scale[q]}
+            if walks is not None:
+                blob["walks"] = walks[q]
+            yield SamplerReturn(u[q], v[q], ll[q], ncall[q], blob)
+
+    def tuning_summary(self):
+        """What ``tune`` needs from the whole queue without materialising a record: mean accepted steps and the walk length."""
+        return {"accept": float(np.mean(self.accept)), "walks": None if self.walks is None else float(np.mean(self.walks))}
+
+
 def estimate_nmcmc(accept_ratio, safety=5, tau=None, maxmcmc=5000, old_act=None):
     """bilby ``dynesty_utils.estimate_nmcmc``: chain length from the acceptance ratio -- autocorrelation time ``2 / a - 1`` of a
     Metropolis chain, smoothed over ``tau`` calls with the previous estimate."""
@@ -161,9 +254,7 @@ class _LockstepWalk:
         live = np.asarray(getattr(nested_sampler, "live_u"), dtype=float)
         self.nlive = len(live)
         kwargs = dict(self.sampler_kwargs, live=live, walks=getattr(self, "walks", None), nlive=self.nlive)
-        axes = axes if axes is not None else [None] * len(points)
-        return [SamplerArgument(u=p, loglstar=loglstar, rseed=s, prior_transform=prior_transform, loglikelihood=loglikelihood,
-                                kwargs=kwargs, axes=a, scale=self.scale) for p, a, s in zip(points, axes, seeds)]
+        return SamplerArgumentBatch(points, loglstar, seeds, prior_transform, loglikelihood, kwargs, axes=axes, scale=self.scale)
 
     def tune(self, tuning_info, update=True):
         return None
@@ -293,15 +384,32 @@ class _LockstepWalk:
 # -----------------------------------------------------------------------------------------------------------------------
 # The walk on the device: likelihood -> accept + next proposal as two launches per MCMC step, no host round trip
 # -----------------------------------------------------------------------------------------------------------------------
+#: bilby/core/prior/analytical.py class names with a device formula.  EXACT names only (a trailing "Prior" of a stand-in class is
+#: dropped): a suffix match would hand ``TruncatedNormal`` or ``LogNormal`` the plain Gaussian's transform and
+#: ``SymmetricLogUniform`` the log-uniform's -- different distributions (round-3 advisor finding).
 _PRIOR_KINDS = {"Uniform": "uniform", "Sine": "sine", "Cosine": "cosine", "PowerLaw": "powerlaw", "LogUniform": "loguniform",
-                "Gaussian": "gaussian", "Normal": "gaussian", "DeltaFunction": "delta"}
+                "Gaussian": "gaussian", "Normal": "gaussian", "DeltaFunction": "delta",
+                "TruncatedGaussian": "truncgaussian", "TruncatedNormal": "truncgaussian",
+                "LogNormal": "lognormal", "LogGaussian": "lognormal", "HalfGaussian": "halfgaussian", "HalfNormal": "halfgaussian"}
+
+
+def device_prior_kind(prior):
+    """The device formula of a bilby prior, by its EXACT class name (or None: the host transform is used)."""
+    name = type(prior).__name__
+    if name.startswith("Conditional") or hasattr(prior, "condition_func") or hasattr(prior, "required_variables"):
+        return None             # (bilby's conditional priors depend on other parameters: host transform)
+    kind = _PRIOR_KINDS.get(name)
+    if kind is None and name.endswith("Prior"):
+        kind = _PRIOR_KINDS.get(name[:-5])
+    return kind
 
 
 def device_prior_table(priors, keys, periodic=(), reflective=()):
-    """The analytic bilby priors of ``keys`` as the device's table (``nmma_walk_prior``: kind, boundary, a, b, alpha), recognised
-    by class name (bilby/core/prior/analytical.py: Uniform, Sine, Cosine, PowerLaw, LogUniform, Gaussian / Normal, DeltaFunction;
-    a class whose name ends in one of these counts too).  Returns ``None`` when a prior has no device formula -- the caller then
-    stays on the host path."""
+    """The analytic bilby priors of ``keys`` as the device's table (``nmma_walk_prior``: kind, boundary, a, b, alpha, c), recognised
+    by class name (bilby/core/prior/analytical.py: Uniform, Sine, Cosine, PowerLaw, LogUniform, Gaussian / Normal,
+    TruncatedGaussian / TruncatedNormal, LogNormal / LogGaussian, HalfGaussian / HalfNormal, DeltaFunction).  Returns ``None``
+    when a prior has no device formula -- the caller then stays on the host path."""
+    from math import erf, sqrt
     from . import _lib as L
     keys = list(keys)
     if not 1 <= len(keys) <= L.WALK_MAX_DIM:
@@ -310,15 +418,7 @@ def device_prior_table(priors, keys, periodic=(), reflective=()):
     periodic, reflective = set(int(i) for i in periodic), set(int(i) for i in reflective)
     for d, key in enumerate(keys):
         pr = priors[key]
-        name = type(pr).__name__
-        if name.startswith("Conditional") or hasattr(pr, "condition_func") or hasattr(pr, "required_variables"):
-            return None         # (bilby's conditional priors depend on other parameters: host transform)
-        kind = _PRIOR_KINDS.get(name)
-        if kind is None:        # (a subclass / stand-in named after the bilby class: the longest matching name wins -- LogUniform, not Uniform)
-            kind = next((_PRIOR_KINDS[k] for k in sorted(_PRIOR_KINDS, key=len, reverse=True)
-                         if name.endswith(k) or name.endswith(k + "Prior")), None)
-        if kind is None and hasattr(pr, "peak") and getattr(pr, "minimum", None) is None:
-            kind = "delta"
+        kind = device_prior_kind(pr)
         try:
             if kind == "uniform":
                 table[d].kind, table[d].a, table[d].b = L.PRIOR_UNIFORM, float(pr.minimum), float(pr.maximum)
@@ -331,12 +431,25 @@ def device_prior_table(priors, keys, periodic=(), reflective=()):
             elif kind == "loguniform":
                 table[d].kind, table[d].a, table[d].b, table[d].alpha = L.PRIOR_POWERLAW, float(pr.minimum), float(pr.maximum), -1.0
             elif kind == "gaussian":
+                # (a Gaussian that ALSO carries finite bounds is not bilby's Gaussian: leave it to the host)
+                lo, hi = getattr(pr, "minimum", None), getattr(pr, "maximum", None)
+                if (lo is not None and np.isfinite(lo)) or (hi is not None and np.isfinite(hi)):
+                    return None
                 table[d].kind, table[d].a, table[d].b = L.PRIOR_GAUSSIAN, float(pr.mu), float(pr.sigma)
+            elif kind == "truncgaussian":
+                mu, sigma, lo, hi = float(pr.mu), float(pr.sigma), float(pr.minimum), float(pr.maximum)
+                e_lo, e_hi = erf((lo - mu) / (sqrt(2.0) * sigma)), erf((hi - mu) / (sqrt(2.0) * sigma))
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_TRUNC_GAUSSIAN, mu, sigma
+                table[d].alpha, table[d].c = (e_hi - e_lo) / 2.0, e_lo         # bilby: TruncatedGaussian.normalisation, rescale
+            elif kind == "lognormal":
+                table[d].kind, table[d].a, table[d].b = L.PRIOR_LOGNORMAL, float(pr.mu), float(pr.sigma)
+            elif kind == "halfgaussian":
+                table[d].kind, table[d].b = L.PRIOR_HALF_GAUSSIAN, float(pr.sigma)
             elif kind == "delta":
                 table[d].kind, table[d].a = L.PRIOR_DELTA, float(pr.peak)
             else:
                 return None
-        except (AttributeError, TypeError):
+        except (AttributeError, TypeError, ValueError):
             return None
         table[d].boundary = L.BOUNDARY_PERIODIC if d in periodic else (L.BOUNDARY_REFLECTIVE if d in reflective else L.BOUNDARY_NONE)
     return table
@@ -457,36 +570,52 @@ class EnsembleWalkSampler(_LockstepWalk):
         return {"accept": int(st["accept"][q]), "reject": int(st["walks"][q] - st["accept"][q]), "scale": getattr(args, "scale", 1.0),
                 "walks": int(st["walks"][q])}
 
-    def run_many_device(self, args_list, loglike_device, priors, keys, device=0, loglike_many=None, prior_transform_many=None):
-        """``run_many`` with the whole walk on the GPU: ``int(walks)`` steps of propose -> ``loglike_device(theta)`` -> accept with
-        no host round trip (``device_walk``).  ``priors`` / ``keys``: the sampled priors in column order, needed as a device table
-        (``device_prior_table``); a prior without a device formula or chains with their own ensembles send
-        the queue to the host walk ``run_many(args_list, loglike_many, prior_transform_many)``.  The random numbers and the
-        proposal are the host walk's; only the libm of ``log`` / the prior transform differs in the last bits."""
+    def run_many_device(self, args_list, loglike_device, priors, keys, device=0, loglike_many=None, prior_transform_many=None,
+                        engine=None, constraints=None):
+        """``run_many`` with the whole walk on the GPU: ``int(walks)`` steps of propose -> likelihood -> accept with no host
+        round trip.  With ``engine`` (the ``EMEngine`` behind the likelihood; ``GPUPool`` passes it) the queue is ONE library call
+        (``EMEngine.walk_queue`` -> ``nmma_em_walk_queue``: packed upload, the step loop, fresh draws, packed download);
+        otherwise ``device_walk`` drives the same kernels from Python around ``loglike_device(theta)``.  ``priors`` / ``keys``:
+        the sampled priors in column order, needed as a device table (``device_prior_table``); a prior without a device formula
+        or chains with their own ensembles send the queue to the host walk ``run_many(args_list, loglike_many,
+        prior_transform_many)``.  ``constraints``: the likelihood's lowered Constraint priors (``ConstraintProgram``) for the
+        ``engine`` path -- a likelihood called through ``loglike_device`` applies its own.  The random numbers and the proposal
+        are the host walk's; only the libm of ``log`` / the prior transform differs in the last bits.  Returns a
+        :class:`WalkResults` (a sequence of the records dynesty expects, array-backed)."""
         n = len(args_list)
         if n == 0:
             return []
+        batch = args_list if isinstance(args_list, SamplerArgumentBatch) else None
         first = args_list[0]
         live = _live_points(first)
-        shared = all(_live_points(a) is live for a in args_list[1:])
-        walks = [int(a.kwargs.get("walks") or self.walks) for a in args_list]
+        if batch is not None:
+            shared, walks = True, [int(batch.kwargs.get("walks") or self.walks)]
+        else:
+            shared = all(_live_points(a) is live for a in args_list[1:])
+            walks = [int(a.kwargs.get("walks") or self.walks) for a in args_list]
         table = device_prior_table(priors, keys, self.periodic, self.reflective)
         if table is None or not shared or np.asarray(live).shape[0] < 3:
             if loglike_many is None:
                 raise ValueError("this queue needs the host walk: pass loglike_many (and prior_transform_many)")
             return self.run_many(args_list, loglike_many, prior_transform_many)
-        rseeds = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
-        u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
-        loglstar = np.array([a.loglstar for a in args_list], dtype=float)
+        if batch is not None:
+            rseeds, u0, loglstar, scales = batch.keys(), batch.u, batch.bounds(), batch.scale
+        else:
+            rseeds = chain_keys([a.rseed for a in args_list])
+            u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
+            loglstar = np.array([a.loglstar for a in args_list], dtype=float)
+            scales = np.array([getattr(a, "scale", 1.0) for a in args_list], dtype=float)
         same = len(set(walks)) == 1
-        u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, walks[0] if same else np.array(walks), loglike_device, device=device)
-        self.n_batches, self.n_evals = max(walks), int(counts[:, 3].sum())
-        self._device_fresh_draws(np.nonzero(counts[:, 0] == 0)[0], table, rseeds, u, v, logl, counts, loglike_device, device)
-        # (plain Python numbers from three tolist() calls: building 4096 records costs ~2 ms this way, ~5 ms through numpy scalars)
-        acc, ncall, ll = counts[:, 0].tolist(), counts[:, 3].tolist(), logl.tolist()
-        scales = [getattr(a, "scale", 1.0) for a in args_list]
-        return [SamplerReturn(u[q], v[q], ll[q], ncall[q], {"accept": acc[q], "reject": walks[q] - acc[q], "scale": scales[q], "walks": walks[q]})
-                for q in range(n)]
+        steps = walks[0] if same else np.array(walks, dtype=np.int32)
+        if engine is not None:
+            u, v, logl, counts = engine.walk_queue(table, live, u0, loglstar, rseeds, steps, constraints=constraints)
+            self.n_batches, self.n_evals = max(walks) + int(np.any(counts[:, 0] == 0)), int(counts[:, 3].sum())
+        else:
+            u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, steps, loglike_device, device=device)
+            self.n_batches, self.n_evals = max(walks), int(counts[:, 3].sum())
+            self._device_fresh_draws(np.nonzero(counts[:, 0] == 0)[0], table, rseeds, u, v, logl, counts, loglike_device, device)
+        wl = walks[0] if same else np.array(walks)
+        return WalkResults(u, v, logl, counts[:, 3], counts[:, 0], wl - counts[:, 0], scales, walks=wl)
 
     def tune(self, tuning_info, update=True):
         """Steer the walk length towards ``naccept`` accepted steps; ``delay`` averages over about a tenth of the live points.
@@ -547,18 +676,20 @@ class AcceptanceTrackingRWalk(_LockstepWalk):
             if loglike_many is None:
                 raise ValueError("this queue needs the host walk: pass loglike_many (and prior_transform_many)")
             return self.run_many(args_list, loglike_many, prior_transform_many)
-        rseeds = np.array([chain_key(a.rseed) for a in args_list], dtype=np.uint64)
-        u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
-        loglstar = np.array([a.loglstar for a in args_list], dtype=float)
+        if isinstance(args_list, SamplerArgumentBatch):
+            rseeds, u0, loglstar = args_list.keys(), args_list.u, args_list.bounds()
+        else:
+            rseeds = chain_keys([a.rseed for a in args_list])
+            u0 = np.stack([np.asarray(a.u, dtype=float) for a in args_list])
+            loglstar = np.array([a.loglstar for a in args_list], dtype=float)
         u, v, logl, counts, act, steps = device_rwalk(table, live, u0, loglstar, rseeds, self.nact, self.maxmcmc, taus.pop(), type(self).old_act,
                                                       loglike_device, device=device)
         self.n_batches, self.n_evals = steps, int(counts[:, 3].sum())
         st = dict(act=act, accept=counts[:, 0])
         self._device_fresh_draws(np.nonzero(self._stuck(st))[0], table, rseeds, u, v, logl, counts, loglike_device, device)
         self._finish(st)
-        acc, rej, ncall, ll = counts[:, 0].tolist(), (counts[:, 1] + counts[:, 2]).tolist(), counts[:, 3].tolist(), logl.tolist()
-        return [SamplerReturn(u[q], v[q], ll[q], ncall[q], {"accept": acc[q], "reject": rej[q], "scale": getattr(args_list[q], "scale", 1.0)})
-                for q in range(n)]
+        scales = args_list.scale if isinstance(args_list, SamplerArgumentBatch) else np.array([getattr(a, "scale", 1.0) for a in args_list])
+        return WalkResults(u, v, logl, counts[:, 3], counts[:, 0], counts[:, 1] + counts[:, 2], scales)
 
     def _finish(self, st):
         fin = st["act"][np.isfinite(st["act"])]

@@ -1,0 +1,135 @@
+"""A nested-sampling run through the sampler seam, end to end: a minimal static nested sampler (the loop dynesty runs around the
+objects NMMA hands it -- nmma/core/mpi_setup.py:202-245 builds the walker, :282-303 wires ``pool.map`` as the mapper, :339 maps the
+initial points) drives ``GPUPool.map(walker.sample, queue)`` with the device walk and has to recover a KNOWN evidence.
+
+The sampler below is test infrastructure, deliberately plain: worst live point out, its prior-volume shell into the evidence sum,
+a replacement from the queue (refilled with ``queue_size`` chains started at random live points under the current bound; a queued
+point whose likelihood no longer beats the bound is discarded, as dynesty does), ``tune`` fed with every returned record."""
+import numpy as np
+import pytest
+
+from nmma_amd import sampler as smp
+from nmma_amd import synthetic as syn
+from nmma_amd.pool import GPUPool
+from tests.helpers import UniformPrior, plugin_from_case
+
+pytestmark = pytest.mark.gpu
+
+
+def nested_sampling(pool, walker, prior_transform, loglike_host, ndim, nlive, queue_size, seed, dlogz=0.05, max_iter=200000):
+    rng = np.random.default_rng(seed)
+    live_u = rng.uniform(size=(nlive, ndim))
+    live_v = np.asarray(prior_transform(live_u))
+    live_l = np.asarray(loglike_host(live_v), dtype=float)
+    logz, h_sum, ncall, it, queue, n_queues = -np.inf, 0.0, nlive, 0, [], 0
+    dead_l, dead_logwt, dead_v = [], [], []
+
+    class _View:            # what prepare_sampler reads from the nested sampler
+        live_u = None
+    while it < max_iter:
+        worst = int(np.argmin(live_l))
+        lstar = live_l[worst]
+        logvol0, logvol1 = -it / nlive, -(it + 1) / nlive
+        logwt = lstar + logvol0 + np.log1p(-np.exp(logvol1 - logvol0))
+        dead_l.append(lstar); dead_logwt.append(logwt); dead_v.append(live_v[worst].copy())
+        logz = np.logaddexp(logz, logwt)
+        # remaining evidence: the largest live likelihood times the volume left
+        if np.logaddexp(logz, live_l.max() + logvol1) - logz < dlogz:
+            break
+        while True:
+            if not queue:
+                better = np.nonzero(live_l > lstar)[0]
+                start = better[rng.integers(0, len(better), queue_size)]
+                _View.live_u = live_u.copy()
+                batch = walker.prepare_sampler(loglstar=lstar, points=live_u[start].copy(), axes=None, seeds=rng.integers(1, 2 ** 62, queue_size),
+                                               prior_transform=prior_transform, loglikelihood=None, nested_sampler=_View)
+                queue = list(pool.map(walker.sample, batch))
+                n_queues += 1
+                for rec in queue:
+                    walker.tune(rec[4])
+            u, v, logl, nc, _ = queue.pop(0)
+            ncall += nc
+            if logl > lstar:
+                break
+        live_u[worst], live_v[worst], live_l[worst] = u, v, logl
+        it += 1
+    # the live points share what is left of the prior volume
+    logvol = -(it + 1) / nlive
+    for l, v in zip(live_l, live_v):
+        lw = l + logvol - np.log(nlive)
+        dead_l.append(l); dead_logwt.append(lw); dead_v.append(v.copy())
+        logz = np.logaddexp(logz, lw)
+    dead_l, dead_logwt, dead_v = np.array(dead_l), np.array(dead_logwt), np.array(dead_v)
+    w = np.exp(dead_logwt - logz)
+    info = float(np.sum(w * dead_l) - logz)                    # H = int p ln(L / Z)
+    return dict(logz=float(logz), logz_err=float(np.sqrt(max(info, 0.0) / nlive)), info=info, niter=it, ncall=int(ncall), weights=w, samples=dead_v,
+                n_queues=n_queues, walks=float(walker.walks))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def test_gaussian_evidence_is_recovered_through_the_device_walk(torch_cuda):
+    """Unit-normalised Gaussian likelihood, sigma = 0.5 in D = 4, uniform priors on [-5, 5]^4 (periodic in one dimension, reflective
+    in another: the walk's boundary rules run too): ln Z = -4 ln 10 exactly, up to the mass outside the box (1e-22).  The run has to
+    land within 3 sigma of it (sigma = sqrt(H / nlive), the standard nested-sampling error), recover the posterior's mean and
+    width, and do so through ``GPUPool.map`` with the walk on the device."""
+    torch = torch_cuda
+    ndim, nlive, qsize, sigma = 4, 800, 256, 0.5
+    names = [f"x{i}" for i in range(ndim)]
+    pri = {k: UniformPrior(-5.0, 5.0) for k in names}
+    mu = np.array([0.7, -1.1, 0.2, 1.9])
+    mu_d = torch.as_tensor(mu, device="cuda:0")
+    norm = -ndim * np.log(sigma * np.sqrt(2 * np.pi))
+
+    class Gauss:
+        def log_likelihood_batch(self, theta, names=None):
+            if isinstance(theta, torch.Tensor):
+                return norm - 0.5 * torch.sum(((theta - mu_d) / sigma) ** 2, dim=1)
+            return norm - 0.5 * np.sum(((np.asarray(theta) - mu) / sigma) ** 2, axis=1)
+    lik = Gauss()
+    pt = smp.BatchedPriorTransform(pri, names)
+    pool = GPUPool(lik, queue_size=qsize, names=names, prior_transform_many=pt, priors=pri)
+    walker = smp.EnsembleWalkSampler(ndim=ndim, periodic=[0], reflective=[1], naccept=20, walks=25, maxmcmc=2000)
+    res = nested_sampling(pool, walker, pt, lambda v: lik.log_likelihood_batch(v), ndim, nlive, qsize, seed=7)
+    want = -ndim * np.log(10.0)
+    print(f"ln Z = {res['logz']:.3f} +/- {res['logz_err']:.3f} (analytic {want:.3f}), H = {res['info']:.2f}, {res['niter']} iterations, "
+          f"{res['ncall']} likelihood calls in {res['n_queues']} queues, walks -> {res['walks']:.0f}, device launches {pool.n_batches}")
+    assert pool.n_batches > 0 and res["n_queues"] > 10
+    assert abs(res["logz"] - want) < 3.0 * res["logz_err"] and res["logz_err"] < 0.15
+    # H of a Gaussian well inside the box: D ln(width / (sigma sqrt(2 pi e)))
+    assert res["info"] == pytest.approx(ndim * np.log(10.0 / (sigma * np.sqrt(2 * np.pi * np.e))), abs=0.5)
+    w, s = res["weights"], res["samples"]
+    mean = np.sum(w[:, None] * s, axis=0)
+    std = np.sqrt(np.sum(w[:, None] * (s - mean) ** 2, axis=0))
+    assert np.max(np.abs(mean - mu)) < 0.08 and np.max(np.abs(std - sigma)) < 0.08
+
+
+def test_em_likelihood_run_is_the_same_run_through_the_library_queue(torch_cuda):
+    """BASELINE config 2's likelihood under nested sampling twice with the same seeds: queues through the ONE-call library path
+    (``nmma_em_walk_queue``) and queues driven step by step from Python.  The chains are bit-identical, so the two runs are the
+    same run: same iterations, same evidence, same posterior weights."""
+    case = syn.config2_case()
+    _, _, lik = plugin_from_case(case)
+    names = case["names"]
+    th = syn.draw_theta(3, 20000, names)[1]
+    pri = {k: UniformPrior(float(a), float(b)) for k, a, b in zip(names, th.min(axis=0), th.max(axis=0))}
+    pt = smp.BatchedPriorTransform(pri, names)
+    host_ll = lambda v: lik.log_likelihood_batch(np.ascontiguousarray(v), names)
+    out = []
+    for use_library in (True, False):
+        pool = GPUPool(lik, queue_size=512, names=names, prior_transform_many=pt, priors=pri)
+        if not use_library:
+            pool._walk_engine = lambda: (None, None)
+        walker = smp.EnsembleWalkSampler(ndim=len(names), naccept=10, walks=20, maxmcmc=500)
+        out.append(nested_sampling(pool, walker, pt, host_ll, len(names), 400, 512, seed=11, dlogz=0.5, max_iter=30000))
+    a, b = out
+    print(f"config-2 likelihood: ln Z = {a['logz']:.3f} +/- {a['logz_err']:.3f}, H = {a['info']:.1f}, {a['niter']} iterations, {a['ncall']} calls, "
+          f"{a['n_queues']} queues")
+    assert a["niter"] == b["niter"] and a["ncall"] == b["ncall"] and a["logz"] == b["logz"]
+    assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["samples"], b["samples"])
+    assert np.isfinite(a["logz"]) and a["info"] > 5.0 and a["niter"] > 400 * 5
