@@ -363,7 +363,11 @@ def time_marginalization_weights(prior, start_time, duration, n_freq):
     """What bilby's ``_setup_time_marginalization`` tabulates from the ``geocent_time`` prior (bilby/gw/likelihood/base.py): the
     coalescence times the FFT of the integrand resolves, ``delta_tc = duration / (n_freq - 1)`` (= 2 / sampling_frequency) apart,
     and ``prior.prob`` on them times the step, as ln(prob x step).  Index j is the shift j * delta_tc of a waveform evaluated
-    with ``geocent_time = start_time`` (bilby's delta-function replacement of the time prior)."""
+    with ``geocent_time = start_time`` (bilby's delta-function replacement of the time prior), so FFT bin j is weighted with the
+    prior AT the coalescence time it stands for, ``start_time + j delta_tc``.  Stated deviation (unpinned -- bilby is not in the
+    image): bilby's own table is, to the best of two recollections, ``start_time + linspace(0, T, n + 1)[1:]``, i.e. bin j paired
+    with the prior one node LATER; for a prior that is flat over its support the two differ only in which edge node carries
+    weight."""
     n = int(n_freq) - 1
     delta = float(duration) / n
     times = float(start_time) + delta * np.arange(n)
@@ -392,6 +396,13 @@ class GravitationalWaveTransient:
                 self._time_logw = time_marginalization_weights(prior, ifo.strain_data.start_time,
                                                                ifo.strain_data.duration, len(ifo.frequency_array))
                 self._time_bounds = (float(prior.minimum), float(prior.maximum)) if self.jitter_time else None
+                if self.jitter_time:
+                    # the kernel weights a jittered node with the tabulated weight of its nearest in-support node: exact only
+                    # when the prior is flat over its support (bilby evaluates prior.prob(times + jitter) per sample)
+                    inside = self._time_logw[np.isfinite(self._time_logw)]
+                    if inside.size and np.ptp(inside) > 1e-9:
+                        raise L.NMMAHipError("jitter_time with a non-uniform geocent_time prior is not supported on the device path "
+                                             "(the time prior would have to be evaluated per sample): pass jitter_time=False")
                 if self.jitter_time and "time_jitter" not in priors:
                     # bilby/gw/likelihood/base.py: priors['time_jitter'] = Uniform(-delta_tc / 2, delta_tc / 2)
                     half = 0.5 * float(ifo.strain_data.duration) / (len(ifo.frequency_array) - 1)

@@ -100,6 +100,7 @@ class MultiDeviceEvaluator:
         for lo, hi, part, s in pieces:
             cur.wait_stream(s)
             out[lo:hi].copy_(part, non_blocking=True)
+            part.record_stream(cur)        # allocated under `s`, read by the copy on `cur`: keep the block until that copy is done
         return out
 
     def close(self):

@@ -234,7 +234,11 @@ def test_reference_constructor_with_time_marginalisation(torch_cuda):
                                               jitter_time=False)
     _, theta = syn.draw_gw_theta(43, 6, centre=case["injection"], names=names)
     got = gw.log_likelihood_batch(torch.as_tensor(theta, device="cuda:0"), names).cpu().numpy()
-    logw = time_marginalization_weights(priors["geocent_time"], case["start_time"], case["duration"], len(case["frequency_array"]))
+    # (the oracle's weights are built here, independently of the product's helper: ln(prior(t_j) dt) on t_j = start + j dt)
+    dt_ = case["duration"] / 16384
+    with np.errstate(divide="ignore"):
+        logw = np.log(priors["geocent_time"].prob(case["start_time"] + dt_ * np.arange(16384)) * dt_)
+    assert np.array_equal(logw, time_marginalization_weights(priors["geocent_time"], case["start_time"], case["duration"], len(case["frequency_array"])))
     assert logw.shape == (16384,) and np.isfinite(logw).sum() in (204, 205, 206)
     want = oracle_loglike_ratio(case, names, theta, dict(geocent_time=case["start_time"]), phase_marginalization=True,
                                 time_marginalization=logw) + gw.noise_log_likelihood()
