@@ -205,6 +205,14 @@ int32_t nmma_em_model_lightcurves(nmma_em_handle* h, const double* theta_dev, in
 int32_t nmma_em_loglike_lc(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                            const double* lc_dev, double* out_dev, void* stream);
 
+/* nmma_em_loglike_lc for a COMBINED model (CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes,
+ * nmma/em/model.py:1411-1510) without materialising the stacked curves: lc_dev_sets = HOST array of n_sets (1..8) device pointers
+ * to source-frame sets [B][M][NS] on the handle's grid and filters (nmma_lc_regrid's output); the flux sum of nmma_lc_stack is
+ * formed node by node while a sample's curves are staged on chip.  bad_rows_dev (or NULL): [B] bytes, non-zero = a sub-model
+ * delivered no light curve for this row (model.py:1423-1426) -> floor. */
+int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* const* lc_dev_sets,
+                                int32_t n_sets, const uint8_t* bad_rows_dev, double* out_dev, void* stream);
+
 /* Flux addition of n_models light-curve sets lc_k[B][M][NS] given on the handle's sample_times
  * (CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes, model.py:1440-1448,
  * :1486-1510): interior non-finite nodes of every model are interpolated between its finite

@@ -148,6 +148,8 @@ PROTOTYPES = {
     "nmma_em_model_lightcurves": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_em_loglike_lc": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "nmma_em_loglike_lc_sets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_lc_regrid": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _pd, _pi, _pi, C.c_int64, C.c_void_p,
                                    C.c_void_p]),

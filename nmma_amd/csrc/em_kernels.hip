@@ -2473,40 +2473,130 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// The curve sets of one stacking call, passed by value (no device-side pointer table).
+struct LcSets { const double* p[8]; };       // the curve sets of one stacking call, passed by value (no device-side pointer table)
+
+// One node: vv[k] = model k's value at node g (already loaded).
+template <int KM>
+__device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv) {
+    const int NS = P.NS;
+    const double ln10 = 2.302585092994046;
+    double amax = -HUGE_VAL, terms[KM];
+    bool any_nan = false;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        terms[k] = -HUGE_VAL;
+        if (k >= n_models) continue;
+        double v = vv[k];                 // (the curves of a set are contiguous: node g of the set)
+        if (!(v - v == 0.0)) {            // non-finite node: interpolate between finite neighbours
+            // (only here is the node's place in its curve needed: the 64-bit division stays off the common path)
+            const long cidx = g / NS;
+            const int j = (int)(g - cidx * NS);
+            const double* cur = sets.p[k] + (size_t)cidx * NS;
+            int jl = j - 1, jr = j + 1;
+            while (jl >= 0 && !(cur[jl] - cur[jl] == 0.0)) --jl;
+            while (jr < NS && !(cur[jr] - cur[jr] == 0.0)) ++jr;
+            v = (jl >= 0 && jr < NS) ? lerp_np(P.st[j], P.st[jl], P.st[jr], cur[jl], cur[jr]) : HUGE_VAL;
+        }
+        const double a = -2.0 / 5.0 * ln10 * v;
+        terms[k] = a;
+        if (a != a) any_nan = true;
+        if (a > amax) amax = a;
+    }
+    double res;
+    if (any_nan) res = HUGE_VAL - HUGE_VAL;
+    else if (!(amax - amax == 0.0)) res = amax;          // every model -inf (no flux) or +inf
+    else {
+        double sacc = 0.0;
+        // (exp(0) is exactly 1: the largest term needs no exponential -- half of them for two models.  Own exp for arguments <= 0
+        //  and log for [1, 8] -- exp_neg / log_pos, ~1 ulp: the library's two calls were a third of a node's instructions)
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < n_models) sacc += (terms[k] == amax) ? 1.0 : exp_neg(terms[k] - amax);
+        res = log_pos(sacc) + amax;
+    }
+    return -5.0 / 2.0 * res / ln10;
+}
+
+
+// G lanes per parameter vector: 64 (one wave per sample) or 16 -- FOUR samples per wave.  The kernel is bound by instruction
+// issue, not by HBM or occupancy: with a wave per sample the per-sample scalar chain (sample_scalars: one active
+// lane) and the last, partly filled pass over the photometry are paid per sample; with 16-lane groups four samples share them.
+// NM: how the sample's curves come about -- 1: set 0 as it is; 2 / 0: the flux sum of two / of n_sets (<= 8) sets, node by node
+// (stack_magnitudes, model.py:1486-1510, with its per-model gap filling: lc_stack_node) WHILE the curves are staged into LDS, so
+// that a combined model's stacked set is never written to memory and read back (72.5 MB -> 48.6 MB per call at config 3's shape,
+// one launch instead of two).  bad_rows (or NULL): rows whose sub-model delivered no light curve (floor).
+template <int G>
+__device__ __forceinline__ double group_total(double v) {
+    if constexpr (G == 64) return wave_sum(v);
+    else return group_sum(v, 16);        // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
+}
+
+template <int G, int NM>
 __global__ __launch_bounds__(256) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
-    const double* __restrict__ lc, const int lds_per_wave, const int stage_all, const int always_floor, double* __restrict__ out,
-    double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
+    const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int stage_all,
+    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
+    static_assert(G == 64 || G == 16, "a wave per sample, or four samples per wave");
+    constexpr int SPW = 64 / G;                        // samples per wave
     const EmDev& P = *Pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1), grp = lane / G;     // lane within the sample's group; the group within the wave
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long b_raw = (long)blockIdx.x * 4 + wave;
-    const long b = b_raw < B ? b_raw : B - 1;          // (a wave beyond the batch recomputes the last row and stores nothing)
+    const long b_raw = ((long)blockIdx.x * 4 + wave) * SPW + grp;
+    const long b = b_raw < B ? b_raw : B - 1;          // (a group beyond the batch recomputes the last row and stores nothing)
     const int NS = P.NS, M = P.M;
+    const double* __restrict__ lc = sets.p[0];
     // block LDS: stl[NS] | dist_grid[n_cosmo] | z_grid[n_cosmo] (the cosmology grid only when it fits STAGE_COSMO nodes),
-    // then per wave: app[NS] | estacc[nf_max] | praw[8] | scal[8] | curves[M][NS] (stage_all)
+    // then per sample: app[NS] | estacc[nf_max] | praw[8] | scal[8] | curves[M][NS] (stage_all)
     const bool cosmo_lds = P.redshift_mode == NMMA_Z_GRID && P.n_cosmo <= STAGE_COSMO;
     double* stl = reinterpret_cast<double*>(smem);
     double* dgl = stl + NS;
     double* zgl = dgl + (cosmo_lds ? P.n_cosmo : 0);
     const int shared_bytes = ((NS + (cosmo_lds ? 2 * P.n_cosmo : 0)) * 8 + 15) & ~15;
-    double* app = reinterpret_cast<double*>(smem + shared_bytes + (size_t)wave * lds_per_wave);
+    double* app = reinterpret_cast<double*>(smem + shared_bytes + (size_t)(wave * SPW + grp) * lds_per_sample);
     double* estacc = app + NS;
     double* praw = estacc + P.lc_nf_max;
     double* scal = praw + 8;
     double* curves = scal + 8;
     (void)estacc;
     const double* row = theta + b * ld;
+    auto group_count = [&](const bool pred) -> int {   // lanes of THIS sample's group with pred (a ballot: no cross-lane fp64 reduction)
+        unsigned long long m = __ballot(pred);
+        if constexpr (G < 64) m = (m >> (grp * G)) & ((1ull << G) - 1ull);
+        return __popcll(m);
+    };
     if (stage_all) {                                   // every load of the sample's curves in flight before anything waits
-        const double* src = lc + (size_t)b * M * NS;
-        for (int j = lane; j < M * NS; j += 64) curves[j] = src[j];
+        const long g_base = b * M * NS;
+        if constexpr (NM == 1) {
+            const double* src = lc + g_base;
+            for (int j = gl; j < M * NS; j += G) curves[j] = src[j];
+        } else {
+            constexpr int KM = NM > 0 ? NM : 8;
+            const int n_models = NM > 0 ? NM : n_sets;
+            constexpr int NPT = 4;                     // nodes per lane and trip: all their loads issued before the first is used
+            for (int j0 = gl; j0 < M * NS; j0 += NPT * G) {
+                double v[NPT][KM];
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const int j = j0 + i * G;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) v[i][k] = (k < n_models && j < M * NS) ? sets.p[k][g_base + j] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const int j = j0 + i * G;
+                    if (j < M * NS) curves[j] = lc_stack_node<KM>(P, sets, n_models, g_base + j, v[i]);
+                }
+            }
+        }
     }
     for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
     if (cosmo_lds)
         for (int j = threadIdx.x; j < P.n_cosmo; j += 256) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
     __syncthreads();
-    if (lane == 0) {
+    if (gl == 0) {
         double chk;
         if (cosmo_lds) sample_scalars(P, row, praw, scal, chk, dgl, zgl);
         else sample_scalars(P, row, praw, scal, chk);
@@ -2514,6 +2604,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
             if (P.sys_kind[o] != NMMA_SYS_NODES)
                 for (int q = P.sys_off[o]; q < P.sys_off[o + 1]; ++q) chk += apply_slot(P.sys_slots[q], row);
         scal[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+        if (bad_rows != nullptr && bad_rows[b] != 0) scal[S_BAD] = 1.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2523,12 +2614,12 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
     for (int m = 0; m < M; ++m) {
         const double* cur = stage_all ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
-        int nfin = 0;                                  // (a ballot per 64 nodes: no cross-lane fp64 reduction for a count)
-        for (int j0 = 0; j0 < NS; j0 += 64) {
-            const int j = j0 + lane;
+        int nfin = 0;                                  // (a ballot per G nodes: no cross-lane fp64 reduction for a count)
+        for (int j0 = 0; j0 < NS; j0 += G) {
+            const int j = j0 + gl;
             double v = HUGE_VAL;
             if (j < NS) v = cur[j];
-            nfin += __popcll(__ballot(v - v == 0.0));
+            nfin += group_count(v - v == 0.0);
         }
         if (nfin < 2) bad = true;
     }
@@ -2607,27 +2698,27 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         // all photometry points of all bands in one pass over the lanes (a band with a dozen points would otherwise leave
         // most of the wave idle for a whole pass): d_item[di] = first work item of the datum's band
         double chi = 0.0, gp = 0.0;
-        for (int di = lane; di < P.n_data; di += 64) datum_term(di, P.d_item[di], chi, gp);
-        chi_tot = wave_sum(chi);
-        gp_tot = wave_sum(gp);
+        for (int di = gl; di < P.n_data; di += G) datum_term(di, P.d_item[di], chi, gp);
+        chi_tot = group_total<G>(chi);
+        gp_tot = group_total<G>(gp);
     } else {
         // per-filter parts requested: one pass per band
         for (int k = 0; k < P.n_items; ++k) {
             const ItemDesc& it = P.item_desc[k];
             if (it.ks != 0) continue;
             double chi = 0.0, gp = 0.0;
-            for (int dd = lane; dd < it.nf; dd += 64) datum_term(it.d0 + dd, k, chi, gp);
-            chi = wave_sum(chi);
-            gp = wave_sum(gp);
+            for (int dd = gl; dd < it.nf; dd += G) datum_term(it.d0 + dd, k, chi, gp);
+            chi = group_total<G>(chi);
+            gp = group_total<G>(gp);
             chi_tot += chi;
             gp_tot += gp;
-            if (lane == 0 && b_raw < B) {
+            if (gl == 0 && b_raw < B) {
                 chi_parts[(long)it.o * B + b] = chi;
                 gp_parts[(long)it.o * B + b] = gp;
             }
         }
     }
-    if (lane == 0 && b_raw < B) {
+    if (gl == 0 && b_raw < B) {
         double tot = chi_tot + gp_tot;
         if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;      // (a NaN term of any band makes the total NaN)
         out[b] = tot;

@@ -113,8 +113,9 @@ class MultiFilterTransient:
             import torch
             th = torch.as_tensor(np.asarray(theta)) if not isinstance(theta, torch.Tensor) else theta
             th = th.to(f"cuda:{eng.device}", dtype=torch.float64)
-            lc = model.stacked_lightcurves_abs(th, eng.parameter_names, external_lc, stack_engine=eng)
-            out = eng.loglike_lc(th, lc)
+            # (the flux sum of the sub-models is formed on chip while the likelihood kernel stages a sample's curves)
+            sets, failed = model.stacked_sets(th, eng.parameter_names, external_lc, stack_engine=eng)
+            out = eng.loglike_lc_sets(th, sets, failed)
             return out if isinstance(theta, torch.Tensor) else out.cpu().numpy()
         return eng.loglike(theta)
 

@@ -468,9 +468,10 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
             parameters = m.parameter_conversion(parameters)
         return parameters
 
-    def stacked_lightcurves_abs(self, theta, names, external_lc=None, stack_engine=None):
-        """[B, M, NS] flux-summed source-frame curves on the union grid / filters.  ``external_lc`` maps the name of each
-        :class:`ExternalLightCurveModel` to its tensor ``[B, M_k, NS_k]`` (on that model's own filters and times), or to a
+    def stacked_sets(self, theta, names, external_lc=None, stack_engine=None):
+        """The sub-models' source-frame sets ``[B, M, NS]`` on the union grid / filters (the operands of ``stack_magnitudes``) and
+        the rows for which a sub-model delivered no light curve (bool CUDA tensor [B], or None).  ``external_lc`` maps the name of
+        each :class:`ExternalLightCurveModel` to its tensor ``[B, M_k, NS_k]`` (on that model's own filters and times), or to a
         pair ``(tensor, ok[B])``: rows with ``ok == False`` are the sub-model's "no light curve for these parameters"
         (an empty dict in the reference, model.py:1423-1426) and floor the sample."""
         import torch
@@ -492,6 +493,13 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
             if plan is not None:
                 lc = eng.regrid(lc, np.asarray(m.model_times, float), plan)
             sets.append(lc)
+        return sets, failed
+
+    def stacked_lightcurves_abs(self, theta, names, external_lc=None, stack_engine=None):
+        """[B, M, NS] flux-summed source-frame curves on the union grid / filters (NaN rows where a sub-model failed): the
+        materialised form, for plots and stage-level tests -- the likelihood stacks on chip (``EMEngine.loglike_lc_sets``)."""
+        eng = stack_engine or self._model_engine(names)
+        sets, failed = self.stacked_sets(theta, names, external_lc, eng)
         out = eng.stack(sets)
         if failed is not None and bool(failed.any()):
             out[failed.to(out.device)] = float("nan")

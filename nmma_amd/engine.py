@@ -451,6 +451,28 @@ class EMEngine:
                 "nmma_em_loglike_lc")
         return out
 
+    def loglike_lc_sets(self, theta, lcs, bad_rows=None):
+        """logL of a COMBINED model from its sub-models' source-frame sets ``lcs`` (list of [B, M, NS] CUDA tensors on this
+        engine's grid and filters): the flux sum (``stack``) is formed on chip while each sample's curves are staged, the stacked
+        set is never written.  ``bad_rows``: bool/uint8 CUDA tensor [B] of rows without a light curve (floor), or None."""
+        import torch
+        t = self._dev_theta(theta)
+        shape = (t.shape[0], len(self.model_filters), self.n_sample_times)
+        lcs = [x.to(device=t.device, dtype=torch.float64).contiguous() for x in lcs]
+        if not lcs or any(tuple(x.shape) != shape for x in lcs):
+            raise L.NMMAHipError(f"every curve set must be [B, M, NS] = {shape}")
+        bad = None
+        if bad_rows is not None:
+            bad = bad_rows.to(device=t.device, dtype=torch.uint8).contiguous()
+            if tuple(bad.shape) != (t.shape[0],):
+                raise L.NMMAHipError("bad_rows must be [B]")
+        out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        ptrs = (C.c_void_p * len(lcs))(*[C.c_void_p(x.data_ptr()) for x in lcs])
+        L.check(self._lib.nmma_em_loglike_lc_sets(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0), ptrs, len(lcs),
+                                                  C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
+                                                  self._stream()), "nmma_em_loglike_lc_sets")
+        return out
+
     def stack(self, lcs):
         """Flux-add light-curve sets [B, M, NS] (CombinedLightCurveModelContainer.stack_magnitudes)."""
         import torch

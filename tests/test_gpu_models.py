@@ -4,6 +4,7 @@ through the reference-shaped plugin classes, against golden vectors from the ref
 import numpy as np
 import pytest
 
+from nmma_amd import synthetic as syn
 from tests import cases, cases_combined, cases_me2017
 from tests.helpers import SimplePrior, rel_err
 
@@ -118,6 +119,52 @@ def test_combined_union_grids_and_filter_fallbacks():
     ok[[3, 17]] = False
     got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
     assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+def test_stack_fused_into_the_likelihood_gives_the_materialised_result():
+    """``nmma_em_loglike_lc_sets`` (flux sum formed while a sample's curves are staged on chip; four samples per wave) against
+    ``nmma_lc_stack`` + ``nmma_em_loglike_lc``: the same bits for one, two, three sets -- non-finite nodes, dark models, ragged
+    batch sizes, a row flagged as "no light curve" -- and the wave-per-sample form (NMMA_LC_NO_GROUPS=1) to rounding."""
+    import os
+    import torch
+    case = cases_combined.case_combined()
+    from nmma_amd.engine import EMEngine
+    tail = EMEngine(None, case["filters"], [], case["names"], sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
+                    data=case["data"], observed_filters=case["filters"], model_kind="external")
+    M, NS = len(case["filters"]), len(case["sample_times"])
+    rng = np.random.default_rng(61)
+    for B in (1, 5, 16, 17, 333):
+        theta = np.concatenate([syn.draw_theta(62 + B, B, cases_combined.NAMES[:6])[1], rng.uniform(-17.5, -14.0, (B, 1)),
+                                rng.uniform(0.8, 1.6, (B, 1))], axis=1)
+        th = torch.as_tensor(theta, device="cuda:0")
+        for n_sets in (1, 2, 3):
+            sets = []
+            for k in range(n_sets):
+                a = rng.uniform(-17.0, -12.0, (B, M, NS)) + 2.0 * k
+                hole = rng.uniform(size=a.shape) < 0.03
+                a[hole] = rng.choice([np.inf, np.nan], size=int(hole.sum()))
+                if B > 3:
+                    a[2, k % M, :] = np.inf                   # a dark curve of one model
+                sets.append(torch.as_tensor(a, device="cuda:0"))
+            want = tail.loglike_lc(th, tail.stack(sets) if n_sets > 1 else sets[0])
+            got = tail.loglike_lc_sets(th, sets)
+            assert torch.equal(got, want), (B, n_sets)
+            assert tail.last_launch_geometry()["tile_samples"] == 16
+            bad = torch.zeros(B, dtype=torch.bool, device="cuda:0")
+            bad[B // 2] = True
+            flagged = tail.loglike_lc_sets(th, sets, bad)
+            assert flagged[B // 2].item() == FLOOR and torch.equal(flagged[~bad], want[~bad])
+            os.environ["NMMA_LC_NO_GROUPS"] = "1"
+            try:
+                per_wave = tail.loglike_lc_sets(th, sets)
+                assert tail.last_launch_geometry()["tile_samples"] == 4
+            finally:
+                del os.environ["NMMA_LC_NO_GROUPS"]
+            w, g = want.cpu().numpy(), per_wave.cpu().numpy()
+            assert np.array_equal(w == FLOOR, g == FLOOR)
+            fin = w != FLOOR
+            assert fin.sum() == 0 or rel_err(g[fin], w[fin]).max() < 1e-13
+    tail.close()
 
 
 def test_stack_matches_logsumexp_for_any_number_of_models():

@@ -57,12 +57,27 @@ t = torch.as_tensor(theta, device="cuda:0")
 ext = torch.full((B, len(c3["filters"]), len(c3["sample_times"])), -15.0, dtype=torch.float64, device="cuda:0")
 
 
-def combined():
+def combined():                    # what CombinedLightCurveModelContainer's likelihood runs: the stack formed on chip
+    lc = kn.model_lightcurves(t)
+    return tail.loglike_lc_sets(t, [lc, ext])
+
+
+def combined_materialised():       # round 3's form: lc_stack_kernel writes the stacked set, the likelihood reads it back
     lc = kn.model_lightcurves(t)
     return tail.loglike_lc(t, tail.stack([lc, ext]))
 
 
-print(f"config 3 shape B={B}: SVD curves + stack + likelihood {timeit(combined):8.1f} us per call")
+lc_fixed = kn.model_lightcurves(t)
+stacked = tail.stack([lc_fixed, ext])
+print(f"config 3 shape B={B}: SVD curves + fused stack / likelihood {timeit(combined):8.1f} us per call "
+      f"(materialised stack: {timeit(combined_materialised):8.1f} us)")
+print(f"   tail alone: fused stack + likelihood {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
+      f"lc_stack {timeit(lambda: tail.stack([lc_fixed, ext])):8.1f} us + likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
+os.environ["NMMA_LC_NO_GROUPS"] = "1"          # the wave-per-sample form of the same kernels
+print(f"   wave per sample (NMMA_LC_NO_GROUPS=1): fused {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
+      f"likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
+del os.environ["NMMA_LC_NO_GROUPS"]
+assert torch.equal(tail.loglike_lc_sets(t, [lc_fixed, ext]), tail.loglike_lc(t, stacked))
 kn.close(); tail.close()
 
 # ---- auxiliary outputs of the SVD model
