@@ -2532,7 +2532,7 @@ __device__ __forceinline__ double group_total(double v) {
     else return group_sum(v, 16);        // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
 }
 
-template <int G, int NM>
+template <int G, int NM, bool SD>
 __global__ __launch_bounds__(256) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
     const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int stage_all,
@@ -2554,7 +2554,23 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     double* stl = reinterpret_cast<double*>(smem);
     double* dgl = stl + NS;
     double* zgl = dgl + (cosmo_lds ? P.n_cosmo : 0);
-    const int shared_bytes = ((NS + (cosmo_lds ? 2 * P.n_cosmo : 0)) * 8 + 15) & ~15;
+    // ... | photometry {t, m, sigma, sigma_tot, ln sigma_tot}[n_data] | first work item of each datum | item descriptors (stage_dat):
+    // a datum's term then runs on LDS latency -- from global memory every datum was a chain of L2 round trips, and the kernel was
+    // bound by that latency at the few waves per CU its LDS slabs allow
+    const int grid_bytes = ((NS + (cosmo_lds ? 2 * P.n_cosmo : 0)) * 8 + 15) & ~15;
+    const int ND = P.n_data;
+    double* pho = reinterpret_cast<double*>(smem + grid_bytes);
+    int* ditl = reinterpret_cast<int*>(pho + 5 * ND);
+    int* itl = ditl + ((ND + 3) & ~3);
+    const int shared_bytes = SD ? ((grid_bytes + 5 * ND * 8 + ((ND + 3) & ~3) * 4 + P.n_items * ITEM_WORDS * 4 + 15) & ~15) : grid_bytes;
+    // (SD is a compile-time switch: the staged pointers are LDS pointers to the compiler, not a run-time choice of address space)
+    const double* dt_p = SD ? pho : P.dt;
+    const double* dm_p = SD ? pho + ND : P.dm;
+    const double* dsig_p = SD ? pho + 2 * ND : P.dsig;
+    const double* dsigtot_p = SD ? pho + 3 * ND : P.dsigtot;
+    const double* dlogsig_p = SD ? pho + 4 * ND : P.dlogsig;
+    const int* d_item_p = SD ? ditl : P.d_item;
+    const ItemDesc* item_p = SD ? reinterpret_cast<const ItemDesc*>(itl) : P.item_desc;
     double* app = reinterpret_cast<double*>(smem + shared_bytes + (size_t)(wave * SPW + grp) * lds_per_sample);
     double* estacc = app + NS;
     double* praw = estacc + P.lc_nf_max;
@@ -2593,6 +2609,14 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         }
     }
     for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
+    if constexpr (SD) {
+        for (int j = threadIdx.x; j < ND; j += 256) {
+            pho[j] = P.dt[j]; pho[ND + j] = P.dm[j]; pho[2 * ND + j] = P.dsig[j]; pho[3 * ND + j] = P.dsigtot[j]; pho[4 * ND + j] = P.dlogsig[j];
+            ditl[j] = P.d_item[j];
+        }
+        const int* src = reinterpret_cast<const int*>(P.item_desc);
+        for (int j = threadIdx.x; j < P.n_items * ITEM_WORDS; j += 256) itl[j] = src[j];
+    }
     if (cosmo_lds)
         for (int j = threadIdx.x; j < P.n_cosmo; j += 256) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
     __syncthreads();
@@ -2627,10 +2651,10 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     // One datum: interpolate every source curve of the datum's band at its epoch, average, likelihood term.
     // k0 = first work item of the band (its sources are consecutive items); the bracket depends on the epoch only.
     auto datum_term = [&](const int di, const int k0, double& chi, double& gp) {
-        const ItemDesc& it0 = P.item_desc[k0];
+        const ItemDesc& it0 = item_p[k0];
         const int o = it0.o, nsrc = it0.nsrc, kind = it0.kind;
         const double lim = it0.lim, e_const = it0.e_const;
-        const double t = P.dt[di];
+        const double t = dt_p[di];
         int lo = -1;                                   // t_obs[lo] <= t (<= t_obs[NS - 1]); -1: outside the grid
         if (t == t && NS >= 1 && t >= stl[0] * zp1 + tsh && t <= stl[NS - 1] * zp1 + tsh) {
             int hi = NS - 1;
@@ -2643,7 +2667,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         }
         double acc_e = 0.0;
         for (int ks = 0; ks < nsrc; ++ks) {
-            const ItemDesc& it = P.item_desc[k0 + ks];
+            const ItemDesc& it = item_p[k0 + ks];
             const double ext = extinction_mag(P.ext_law, it.ebvc, zp1, ebv);
             // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
             const double* cur = stage_all ? curves + it.m * NS : lc + ((size_t)b * M + it.m) * NS;
@@ -2666,10 +2690,10 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
             acc_e = ks == 0 ? est : acc_e + est;     // averaged band: (a + b [+ c]) / n  (utils.py:566-584)
         }
         const double est = nsrc > 1 ? acc_e / (double)nsrc : acc_e;
-        const double sd = P.dsig[di];
+        const double sd = dsig_p[di];
         double e = e_const, sig, lsig;
         if (kind == NMMA_SYS_CONST) {
-            sig = P.dsigtot[di]; lsig = P.dlogsig[di];
+            sig = dsigtot_p[di]; lsig = dlogsig_p[di];
         } else {
             const nmma_slot* sv = P.sys_slots + P.sys_off[o];
             if (kind == NMMA_SYS_PARAM) {
@@ -2688,7 +2712,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
             sig = sqrt(sd * sd + e * e);
             lsig = log(sig);
         }
-        const double mobs = P.dm[di];
+        const double mobs = dm_p[di];
         if (sig - sig == 0.0) chi += detection_term(mobs, est, sig, lsig, lim);
         else gp += upper_limit_term(mobs, est, e);
     };
@@ -2698,13 +2722,13 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         // all photometry points of all bands in one pass over the lanes (a band with a dozen points would otherwise leave
         // most of the wave idle for a whole pass): d_item[di] = first work item of the datum's band
         double chi = 0.0, gp = 0.0;
-        for (int di = gl; di < P.n_data; di += G) datum_term(di, P.d_item[di], chi, gp);
+        for (int di = gl; di < P.n_data; di += G) datum_term(di, d_item_p[di], chi, gp);
         chi_tot = group_total<G>(chi);
         gp_tot = group_total<G>(gp);
     } else {
         // per-filter parts requested: one pass per band
         for (int k = 0; k < P.n_items; ++k) {
-            const ItemDesc& it = P.item_desc[k];
+            const ItemDesc& it = item_p[k];
             if (it.ks != 0) continue;
             double chi = 0.0, gp = 0.0;
             for (int dd = gl; dd < it.nf; dd += G) datum_term(it.d0 + dd, k, chi, gp);
