@@ -2515,7 +2515,9 @@ __device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& se
             if (k < n_models) sacc += (terms[k] == amax) ? 1.0 : exp_neg(terms[k] - amax);
         res = log_pos(sacc) + amax;
     }
-    return -5.0 / 2.0 * res / ln10;
+    // (x (1 / ln 10) instead of / ln 10: one rounding more than the reference's expression -- 1 ulp of a magnitude -- for a
+    //  division's ~35 instructions less per node)
+    return (-5.0 / 2.0 * res) * 0.43429448190325176;
 }
 
 
@@ -2529,15 +2531,18 @@ __device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& se
 template <int G>
 __device__ __forceinline__ double group_total(double v) {
     if constexpr (G == 64) return wave_sum(v);
-    else return group_sum(v, 16);        // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
+    else if constexpr (G == 32) {        // (the sum lands in the group's last row: lanes 16-31 / 48-63; hand it to the whole group)
+        v = group_sum(v, 32);
+        return __shfl(v, (int)((threadIdx.x & 32) | 31), 64);
+    } else return group_sum(v, 16);      // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
 }
 
-template <int G, int NM, bool SD>
+template <int G, int NM, bool SD, bool SA>
 __global__ __launch_bounds__(256) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
-    const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int stage_all,
+    const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
-    static_assert(G == 64 || G == 16, "a wave per sample, or four samples per wave");
+    static_assert(G == 64 || G == 32 || G == 16, "a wave per sample, or two / four samples per wave");
     constexpr int SPW = 64 / G;                        // samples per wave
     const EmDev& P = *Pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2583,7 +2588,10 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         if constexpr (G < 64) m = (m >> (grp * G)) & ((1ull << G) - 1ull);
         return __popcll(m);
     };
-    if (stage_all) {                                   // every load of the sample's curves in flight before anything waits
+    // (SA -- the sample's curves staged in LDS -- is a compile-time switch like SD: `cur` below is then an LDS pointer to the compiler
+    //  and a node costs a ds_read; as a run-time choice between LDS and global memory it was a flat load, several times the latency,
+    //  on the serial bracket / finite-node walks of every datum)
+    if constexpr (SA) {                                // every load of the sample's curves in flight before anything waits
         const long g_base = b * M * NS;
         if constexpr (NM == 1) {
             const double* src = lc + g_base;
@@ -2634,10 +2642,12 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     __builtin_amdgcn_wave_barrier();
     const double zp1 = scal[S_ZP1], tsh = scal[S_TS], dmod = scal[S_DMOD], rc = scal[S_RC], ebv = scal[S_EBV];
     bool bad = always_floor != 0 || scal[S_BAD] != 0.0;
+    const bool st_uniform = P.st_uniform != 0;
+    const double st0 = P.st0, st_inv_dt = P.st_inv_dt, izp1 = scal[S_IZP1];
 
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
     for (int m = 0; m < M; ++m) {
-        const double* cur = stage_all ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
+        const double* cur = SA ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
         int nfin = 0;                                  // (a ballot per G nodes: no cross-lane fp64 reduction for a count)
         for (int j0 = 0; j0 < NS; j0 += G) {
             const int j = j0 + gl;
@@ -2657,20 +2667,29 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         const double t = dt_p[di];
         int lo = -1;                                   // t_obs[lo] <= t (<= t_obs[NS - 1]); -1: outside the grid
         if (t == t && NS >= 1 && t >= stl[0] * zp1 + tsh && t <= stl[NS - 1] * zp1 + tsh) {
-            int hi = NS - 1;
-            lo = 0;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+            if (st_uniform) {
+                // equally spaced sample_times: the index guess, then the exact test np.interp's bracket obeys (t_obs[lo] <= t, and
+                // t_obs[lo + 1] > t unless lo is the last node) -- the guess is off by at most one node from rounding
+                lo = (int)(((t - tsh) * izp1 - st0) * st_inv_dt);      // (a guess: the reciprocal's rounding is corrected below)
+                lo = lo < 0 ? 0 : (lo > NS - 1 ? NS - 1 : lo);
+                while (lo > 0 && stl[lo] * zp1 + tsh > t) --lo;
+                while (lo < NS - 1 && stl[lo + 1] * zp1 + tsh <= t) ++lo;
+            } else {
+                int hi = NS - 1;
+                lo = 0;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+                }
+                if (stl[hi] * zp1 + tsh <= t) lo = hi;      // t on the last node
             }
-            if (stl[hi] * zp1 + tsh <= t) lo = hi;      // t on the last node
         }
         double acc_e = 0.0;
         for (int ks = 0; ks < nsrc; ++ks) {
             const ItemDesc& it = item_p[k0 + ks];
             const double ext = extinction_mag(P.ext_law, it.ebvc, zp1, ebv);
             // detector-frame curve of this source (model.py:390-397); non-finite stays non-finite
-            const double* cur = stage_all ? curves + it.m * NS : lc + ((size_t)b * M + it.m) * NS;
+            const double* cur = SA ? curves + it.m * NS : lc + ((size_t)b * M + it.m) * NS;
             auto app = [&](const int j) { double v = cur[j]; if (ext != 0.0) v = v + ext; return (v + dmod) + rc; };
             // np.interp over the FINITE nodes only, left = right = +inf (utils.py:634-645)
             double est = dinf();
