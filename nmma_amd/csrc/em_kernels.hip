@@ -217,9 +217,17 @@ typedef __attribute__((address_space(3))) int* lds_ip;
 // the record loop nest makes the compiler guard every ring access with s_waitcnt vmcnt(0).
 typedef __attribute__((address_space(1))) int* g_ip;
 typedef __attribute__((address_space(1))) long long* g_llp;
+// Measurement builds (tools/levers_r04.sh): -DNMMA_SYNC_SLEEP=<n> sets the s_sleep argument of a polling wave (64 n cycles),
+// -DNMMA_SYNC_WAKEUP makes every signal wake the workgroup's sleeping waves (s_wakeup), so that long sleeps cost no latency.
+#ifndef NMMA_SYNC_SLEEP
+#define NMMA_SYNC_SLEEP 6
+#endif
 __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lds_ip)cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef NMMA_SYNC_WAKEUP
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+#endif
 }
 // A wait that does not complete within ~2^20 polls (tens of milliseconds; a healthy launch needs
 // microseconds) records where it was stuck in the handle's watchdog words and gives up, so that a
@@ -234,7 +242,7 @@ __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watch
     // v_mov + ds_read + v_cmp): sleep ~400 cycles between polls so that waiting costs next to nothing.
     int spins = 0;
     while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-        __builtin_amdgcn_s_sleep(6);
+        __builtin_amdgcn_s_sleep(NMMA_SYNC_SLEEP);
         if (++spins > (1 << 18)) {
             if ((threadIdx.x & 63) == 0) g_wd_trip = 1;
             if (watchdog_generic != nullptr && (threadIdx.x & 63) == 0) {
@@ -330,10 +338,10 @@ constexpr int DAT_MAX = 2560;
 #endif
 constexpr int LEAN_NF_MAX = NMMA_LEAN_NF_MAX;
 
-template <int R, int KP, int PF, int NMW, int NVW, bool FAST>
+template <int R, int KP, int PF, int NMW, int NVW, bool FAST, class LateX>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
                                           float* __restrict__ part, const int NBUF, int* sync,
-                                          long long* __restrict__ dbg_generic) {
+                                          long long* __restrict__ dbg_generic, LateX&& late_xraw) {
     g_llp dbg = (g_llp)(uintptr_t)dbg_generic;
     constexpr int RECF = rec_floats(KP);
     constexpr int RECB = RECF * 4;
@@ -394,6 +402,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         for (int kp = 0; kp < KP; ++kp) ra1[u][kp] = ld1(off_a1 + kp * 256, base + u * RECB);
         rbias[u] = ld4(off_b, base + u * RECB);
     }
+    late_xraw();          // (measurement build -DNMMA_DBG_PRELOAD_FIRST: theta is read only now, behind the ring's first loads)
     float xB[R][KP], xN[R][KP];
     load_x(0, xB);
     f32x4 d[R];
@@ -687,24 +696,33 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // ============================ MFMA role ============================
         // layer-1 operands straight from theta (no dependency on the other role's prologue)
         double xraw[R][KP];
+        auto fill_xraw = [&]() {
 #pragma unroll
-        for (int rb = 0; rb < R; ++rb) {
-            long b = tile0 + rb * 16 + (lane & 15);
-            if (b >= B) b = B - 1;
-            const double* row = theta + b * ld;
+            for (int rb = 0; rb < R; ++rb) {
+                long b = tile0 + rb * 16 + (lane & 15);
+                if (b >= B) b = B - 1;
+                const double* row = theta + b * ld;
 #pragma unroll
-            for (int kp = 0; kp < KP; ++kp) {
-                const int p = 4 * kp + (lane >> 4);
-                xraw[rb][kp] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
+                for (int kp = 0; kp < KP; ++kp) {
+                    const int p = 4 * kp + (lane >> 4);
+                    xraw[rb][kp] = (p < NP) ? apply_slot(P.model_param[p], row) : 0.0;
+                }
             }
-        }
+        };
+#ifndef NMMA_DBG_PRELOAD_FIRST
+        fill_xraw();
+#endif
         switch (P.prio_mfma) {
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
             case 3: __builtin_amdgcn_s_setprio(3); break;
             default: break;
         }
-        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg);
+#ifdef NMMA_DBG_PRELOAD_FIRST
+        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, fill_xraw);
+#else
+        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, [] {});
+#endif
         if (!FAST || !P.helpers) return;
         // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
     }
@@ -769,6 +787,14 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const lds_cdp dgl_l = (lds_cdp)dgl, zgl_l = (lds_cdp)zgl;
                 double* sc = scal + lane * 8;
                 double chk = 0.0;
+#ifdef NMMA_DBG_NOCHAINS
+                // measurement build: what a pre-pass kernel for the per-sample scalars could save AT MOST -- the chains are gone,
+                // plausible constants stand in (the tasks run the same instruction stream on wrong numbers)
+                if (vwave == 0) { sc[S_ZP1] = 1.0093; sc[S_IZP1] = 1.0 / 1.0093; sc[S_RC] = -0.01; }
+                else if (vwave == 1) { sc[S_DMOD] = 33.0; sc[S_TS] = -0.3; sc[S_EBV] = 0.0; if constexpr (LEANX) fill_ext(lane, 0.0); }
+                else if (vwave == 3) bad[lane] = 0;
+                (void)row; (void)dgl_l; (void)zgl_l;
+#else
                 if (vwave == 0) {
                     const double d_l = apply_slot(P.lumdist, row);
                     double z = 0.0;
@@ -808,6 +834,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     bad[lane] = 0;
 
                 }
+#endif
                 badp[vwave * TS + lane] = (chk - chk == 0.0) ? 0 : 1;
             }
         } else if (vt < TS) {
@@ -843,7 +870,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // (slots: one per work item; some task flavours file a band's sums under its observed-filter index instead, which in a
         //  band's own workgroup of the split launch can lie beyond its item count -- the layout always holds P.O slots)
         for (int j = cvt; j < (W > P.O ? W : P.O) * TS; j += cnv) { chi_tot[j] = 0.0; gp_tot[j] = 0.0; }
+#ifdef NMMA_DBG_NODIV     // measurement build: the table of reciprocal spacings without its division (a create-time table would hold them)
+        for (int j = cvt; j < NS; j += cnv) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? P.st_inv_dt : 0.0; }
+#else
         for (int j = cvt; j < NS; j += cnv) { stl[j] = P.st[j]; stl[NS + j] = (j + 1 < NS) ? 1.0 / (P.st[j + 1] - P.st[j]) : 0.0; }
+#endif
         if (!P.st_uniform && P.bguess != nullptr) {
             int* bgl = reinterpret_cast<int*>(stl + 2 * NS);
             gci32p bgs = as_global(P.bguess);

@@ -124,7 +124,7 @@ def test_combined_union_grids_and_filter_fallbacks():
 def test_stack_fused_into_the_likelihood_gives_the_materialised_result():
     """``nmma_em_loglike_lc_sets`` (flux sum formed while a sample's curves are staged on chip; four samples per wave) against
     ``nmma_lc_stack`` + ``nmma_em_loglike_lc``: the same bits for one, two, three sets -- non-finite nodes, dark models, ragged
-    batch sizes, a row flagged as "no light curve" -- and the other group sizes (NMMA_LC_GROUP=32 / 64) to rounding."""
+    batch sizes, a row flagged as "no light curve" -- and the other group sizes (NMMA_LC_GROUP=16 / 64) to rounding."""
     import os
     import torch
     case = cases_combined.case_combined()
@@ -149,13 +149,13 @@ def test_stack_fused_into_the_likelihood_gives_the_materialised_result():
             want = tail.loglike_lc(th, tail.stack(sets) if n_sets > 1 else sets[0])
             got = tail.loglike_lc_sets(th, sets)
             assert torch.equal(got, want), (B, n_sets)
-            assert tail.last_launch_geometry()["tile_samples"] == 16         # four samples per wave
+            assert tail.last_launch_geometry()["tile_samples"] == 8          # two samples per wave
             bad = torch.zeros(B, dtype=torch.bool, device="cuda:0")
             bad[B // 2] = True
             flagged = tail.loglike_lc_sets(th, sets, bad)
             assert flagged[B // 2].item() == FLOOR and torch.equal(flagged[~bad], want[~bad])
             w = want.cpu().numpy()
-            for grp, tile in (("32", 8), ("64", 4)):           # the other group sizes: the same values up to the summation order
+            for grp, tile in (("16", 16), ("64", 4)):           # the other group sizes: the same values up to the summation order
                 os.environ["NMMA_LC_GROUP"] = grp
                 try:
                     other = tail.loglike_lc_sets(th, sets).cpu().numpy()

@@ -73,7 +73,7 @@ print(f"config 3 shape B={B}: SVD curves + fused stack / likelihood {timeit(comb
       f"(materialised stack: {timeit(combined_materialised):8.1f} us)")
 print(f"   tail alone: fused stack + likelihood {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
       f"lc_stack {timeit(lambda: tail.stack([lc_fixed, ext])):8.1f} us + likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
-for grp in ("32", "64"):                       # the other group sizes of the same kernels (default: 16 lanes per sample)
+for grp in ("16", "32", "64"):                 # every group size of the same kernels, like for like (default: 32 lanes per sample)
     os.environ["NMMA_LC_GROUP"] = grp
     print(f"   NMMA_LC_GROUP={grp}: fused {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
           f"likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
