@@ -12,6 +12,7 @@ o=gpurun_out/$tag
 rm -rf $o; mkdir -p $o
 export TMPDIR=/tmp
 python3 bench.py --steps 200 --warmup 20 > $o/bench_line.json 2> $o/bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_line_driver_flags.json 2> $o/bench_driver.err     # what the driver runs
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05 -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05.log 2>&1
 export NMMA_EM_NO_LEAN_LIM=1       # the same case on the extended task (em_logl<.., 2>), which had the finite limits before
@@ -19,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05ext -- pyth
 unset NMMA_EM_NO_LEAN_LIM
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c4 -- python3 tools/perf_case.py c4_shape 8192 > $o/stats_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_models -- python3 tools/perf_models.py > $o/stats_models.log 2>&1
+if [ -z "$SKIP_GW" ]; then       # (round 4: the GW leg is frozen -- SKIP_GW=1 leaves its profiles of round 3 in place)
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw -- python3 tools/perf_gw.py 2048 > $o/stats_gw.log 2>&1
 # the GW leg from parameters at config 5's shape (16 384 samples x 259 585 bins x 3 detectors), with and without phase marginalisation
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_gw_fused -- python3 tools/perf_gw_fused.py --batch 16384 --reps 5 > $o/stats_gw_fused.log 2>&1
@@ -29,6 +31,8 @@ python3 tools/perf_gw_fused.py --batch 16384 --reps 3 --dm --pm > $o/gw_fused_dm
 python3 tools/perf_gw_fused.py --batch 16384 --reps 3 --tm > $o/gw_fused_tm.log 2>&1
 python3 tools/perf_gw_fused.py --batch 16384 --reps 1 --tm --dm --pm > $o/gw_fused_tm_dm_pm.log 2>&1
 bash tools/pmc_gw.sh $tag > $o/pmc_gw.log 2>&1
+fi
+bash tools/pmc_models.sh > $o/pmc_models.log 2>&1
 bash tools/pmc_c4.sh $tag > $o/pmc_c4.log 2>&1
 # the real AT2017gfo photometry (9 filters, CLI grid, sampled em_syserr)
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_at2017gfo -- python3 tools/perf_case.py at2017gfo 4096 > $o/stats_at2017gfo.log 2>&1
