@@ -16,7 +16,8 @@ Without a launcher (RANK unset) and N > 1 the script starts ``torch.distributed.
 before anything here touches the GPU -- and relays the child's JSON line.  ``--scaling weak`` (default) keeps 4096
 live points per GPU; ``--scaling strong`` splits ONE 4096-point batch over the ranks (north_star's 8-GPU target).
 
-The K-step region (W untimed steps first, each region bracketed by barrier + synchronize) is timed ``--repeats`` times and
+Before the W warmup steps ``--clock-warmup-steps`` (1536) untimed steps let the GPU's clocks settle (a fresh process runs its first
+~900 launches at ramping clocks).  The K-step region (W untimed steps first, each region bracketed by barrier + synchronize) is timed ``--repeats`` times and
 `value` / `ms_per_step` are the MEDIAN region's (`spread_pct` = the 10-90 percentile spread over the repeats, relative to it).
 With N > 1 BOTH scaling modes are measured in the one invocation: the line's top level is the mode ``--scaling`` names, the
 other one sits under ``other_scaling``.  Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=25, help="the K-step region is timed this many times; value = the median region")
+    ap.add_argument("--clock-warmup-steps", type=int, default=1536,
+                    help="untimed steps BEFORE the W warmup steps: the GPU's clocks need ~30 ms of continuous load (~900 launches) to settle")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="live points per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,8 +195,19 @@ def main():
         # whenever enough container objects have been allocated: none inside the timed region
         gc.collect()
         gc.disable()
-        for i in range(args.warmup):
-            step(i)
+        # Clock warm-up (untimed, before the W warmup steps of the contract): a freshly started process runs its first ~900 launches
+        # -- ~28 ms of continuous load -- at ramping clocks (the kernel takes 31.3 us at launch 0 and 27.6 us from launch ~900 on,
+        # rocprofv3 trace in profiles/r04_bench_kernel_stats.csv); a sampler lives in the steady state, the driver's 20-step region
+        # would not.
+        done = 0                # steps issued so far (the pipelined form alternates its two buffers on this count)
+        for _ in range(args.clock_warmup_steps):        # (a fixed count: every rank issues the same collectives)
+            step(done)
+            done += 1
+        torch.cuda.synchronize()
+        n_clock = done
+        for _ in range(args.warmup):
+            step(done)
+            done += 1
         torch.cuda.synchronize()
         # HIP events on the launch stream inside the timed region: with one GPU every second group of 8
         # back-to-back launches is bracketed by one event pair (a pair around a single ~35 us launch over-reads
@@ -204,7 +218,6 @@ def main():
         # the MEDIAN region: at the driver's flags the region is well under a millisecond and a single one carries the noise
         # of whatever the box did in that millisecond.
         times, prof = [], dict(fused_ms_total=0.0, n_launches=0)
-        done = args.warmup
         for _ in range(args.repeats):
             if use_dist:
                 dist.barrier()
@@ -235,7 +248,7 @@ def main():
         # sanity: the numbers we just timed are real likelihood values
         last = (outs[(n_done - 1) & 1] if pipelined else out).cpu().numpy()
         assert np.all(np.isfinite(last)) and np.all(last < 0)
-        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry(),
+        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry(), n_clock=n_clock,
                     spread_pct=spread, best=min(times), worst=max(times))
 
     def exchange_label(m):
@@ -260,7 +273,7 @@ def main():
             "value": evals / m["elapsed"], "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 MLP + f64",
-            "data": "synthetic", "repeats": args.repeats, "spread_pct": m["spread_pct"],
+            "data": "synthetic", "repeats": args.repeats, "spread_pct": m["spread_pct"], "clock_warmup_launches": m["n_clock"],
             "ms_per_step_best": 1e3 * m["best"] / args.steps, "ms_per_step_worst": 1e3 * m["worst"] / args.steps,
             "config": {"workload": "BASELINE config 2: Bu2019lm SVD surrogate (NP=4, NH=2048, NC=10, NT=211), "
                                    "AT2017gfo 6-filter synthetic photometry (99 epochs, 1 upper limit), "

@@ -2772,7 +2772,52 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         // all photometry points of all bands in one pass over the lanes (a band with a dozen points would otherwise leave
         // most of the wave idle for a whole pass): d_item[di] = first work item of the datum's band
         double chi = 0.0, gp = 0.0;
-        for (int di = gl; di < P.n_data; di += G) datum_term(di, d_item_p[di], chi, gp);
+        // FAST LANE (compile-time staged data only).  The common datum -- a detection inside the model window whose band has one
+        // source, a constant systematic, no finite limit, no extinction, and whose two bracket nodes are finite -- needs none of
+        // the general term's machinery (source loop, finite-node walks, systematics kinds, truncation mass, upper limits: ~3 000
+        // instructions of code of which a lane executes a few hundred).  It is evaluated here with the SAME operations in the same
+        // order (lerp_np's quotient, the residual's quotient, scipy's expression of the Gaussian term), so a lane's sum is bit for
+        // bit the general term's; lanes that do not qualify -- an upper limit, a non-finite node, an epoch outside the window --
+        // take the general term, and the branch is skipped when no lane of the wave needs it.
+        constexpr bool FASTLANE = SD && SA;
+        const bool fast_cfg = FASTLANE && !P.has_ebv && NS >= 2;
+        const double t_first = stl[0] * zp1 + tsh, t_last = stl[NS - 1] * zp1 + tsh;
+        for (int d0 = 0; d0 < ND; d0 += G) {
+            const int di = d0 + gl;
+            bool general = di < ND;
+            if (fast_cfg && general) {
+                const ItemDesc& it0 = item_p[d_item_p[di]];
+                const double t = dt_p[di], sig = dsigtot_p[di];
+                if (it0.nsrc == 1 && it0.kind == NMMA_SYS_CONST && it0.lim == dinf() && t >= t_first && t < t_last && sig > 0.0 && sig < dinf()) {
+                    int lo;
+                    if (st_uniform) {
+                        lo = (int)(((t - tsh) * izp1 - st0) * st_inv_dt);
+                        lo = lo < 0 ? 0 : (lo > NS - 2 ? NS - 2 : lo);
+                        while (lo > 0 && stl[lo] * zp1 + tsh > t) --lo;
+                        while (lo < NS - 2 && stl[lo + 1] * zp1 + tsh <= t) ++lo;
+                    } else {
+                        int hi = NS - 1;
+                        lo = 0;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+                        }
+                    }
+                    const double* cur = curves + it0.m * NS;
+                    const double y0 = cur[lo], y1 = cur[lo + 1];
+                    if ((y0 - y0 == 0.0) && (y1 - y1 == 0.0)) {
+                        const double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
+                        const double est = (x0 == t) ? (y0 + dmod) + rc : lerp_np(t, x0, x1, (y0 + dmod) + rc, (y1 + dmod) + rc);
+                        const double x = (dm_p[di] - est) / sig;
+                        if (est < dinf() && x == x) {
+                            chi += ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - dlogsig_p[di];
+                            general = false;
+                        }
+                    }
+                }
+            }
+            if (general) datum_term(di, d_item_p[di], chi, gp);
+        }
         chi_tot = group_total<G>(chi);
         gp_tot = group_total<G>(gp);
     } else {
