@@ -434,6 +434,29 @@ int32_t nmma_con_floor(const nmma_con_program* p, const double* theta_dev, int64
 typedef struct nmma_walk_ws nmma_walk_ws;
 int32_t nmma_walk_ws_create(int32_t device, nmma_walk_ws** out);
 void nmma_walk_ws_destroy(nmma_walk_ws* ws);
+/* The MCMC step as ONE launch: the likelihood kernel's workgroup owns the chains whose log L it has just summed, so the accept of
+ * step `step` and the proposal of step `step + 1` (nmma_walk_step) can run in its epilogue and leave the tile's theta rows ready for
+ * the next launch.  `wf_dev`: a DEVICE copy of this struct (pointers to the chains' state, as for nmma_walk_step; theta is the
+ * launch's own theta_dev, which the kernel then WRITES).  last != 0: accept only (the walk's final step).  Returns 2 -- nothing
+ * launched -- when the handle's task flavour has no fused instantiation, or more than 8 dimensions / 4096 chains (the caller then takes
+ * nmma_em_loglike + nmma_walk_step); Constraint programs are NOT evaluated by the fused step (n_con_ops must be 0: their interpreter does
+ * not fit the likelihood kernel's register budget);
+ * the chains are bit-identical either way. */
+typedef struct nmma_walk_fuse {
+    nmma_walk_prior priors[NMMA_WALK_MAX_DIM];
+    int32_t ndim, n_con_ops;
+    const double* live; int64_t n_live;
+    const uint64_t* key;
+    double* prop; int32_t* inside;
+    const double* loglstar;
+    double* u; double* v; double* logl; int32_t* counts;
+    const int32_t* n_steps;           /* or NULL */
+    const nmma_con_op* con_ops;       /* device array (nmma_con_program) or NULL */
+    uint64_t first_step;
+} nmma_walk_fuse;
+int32_t nmma_em_loglike_walk(nmma_em_handle* h, double* theta_dev, int64_t B, int64_t ld, double* out_dev, const nmma_walk_fuse* wf_dev,
+                             uint64_t step, int32_t last, void* stream);
+
 typedef struct nmma_walk_queue {
     const nmma_walk_prior* priors;   /* [ndim] */
     int32_t ndim;

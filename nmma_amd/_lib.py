@@ -172,6 +172,7 @@ PROTOTYPES = {
     "nmma_con_create": (C.c_int32, [C.POINTER(ConOp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "nmma_con_destroy": (None, [C.c_void_p]),
     "nmma_con_floor": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nmma_em_loglike_walk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
     "nmma_walk_ws_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
     "nmma_walk_ws_destroy": (None, [C.c_void_p]),
     "nmma_em_walk_queue": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue), C.c_void_p]),

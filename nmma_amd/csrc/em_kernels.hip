@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "em_device.h"
+#include "walk_device.h"
 #include "em_math.h"
 #include "nmma_common.h"
 
@@ -648,11 +649,15 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
 // separate instantiations so that the extensions cost the basic configuration nothing.
 // Fast modes: every work item qualifies for the fast path (EmDev::all_fast) -- the generic item phase and its
 // LDS table staging are not compiled in, which keeps the register budget small enough for 16-wave workgroups.
-template <int R, int KP, int NMW, int NVW, int FASTM>
+// WALKF: the MCMC step fused in (nmma_em_loglike_walk) -- the first likelihood wave, which sums the tile's log L, also runs the accept
+// of the walk's step `wstep` and the proposal of the next one for the tile's chains (walk_device.h: the device functions of
+// walk_step_kernel, same arithmetic) and writes the tile's theta rows for the next launch.  Its own instantiations: the walk code
+// must not touch the register allocation of the tuned flavours.
+template <int R, int KP, int NMW, int NVW, int FASTM, bool WALKF = false>
 __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
-    long long* __restrict__ dbg) {
+    long long* __restrict__ dbg, const nmma_walk_fuse* __restrict__ wf = nullptr, const unsigned long long wstep = 0, const int wlast = 0) {
     constexpr int TS = 16 * R;
     constexpr int PF = (R == 1) ? 8 : 4;
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
@@ -2204,7 +2209,29 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
+    // (WALKF: the fused MCMC step keeps a group of 8 lanes per chain -- up to 8 sampled dimensions -- and 16-sample tiles)
+    constexpr int WNR = WALKF ? TS / 8 : 1;
+    WalkPre wpre[WNR];
+    nmma_walk_prior* wspl = reinterpret_cast<nmma_walk_prior*>(reinterpret_cast<double*>(smem + L.stage) + TS);
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
+        if constexpr (WALKF) {
+            // ---- the MCMC step, first phase: everything that does not depend on log L is put in flight NOW, while this wave
+            // would only wait for the tile's last tasks (the prologue's staging area is free: the prior table goes there)
+            {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(&wf->priors[0]);
+                for (int j = vt; j < wf->ndim * 10; j += 64) reinterpret_cast<uint32_t*>(wspl)[j] = src[j];
+            }
+#ifndef NMMA_DBG_WALK_NOPRE
+#pragma unroll
+            for (int r = 0; r < WNR; ++r) {
+                const long c = tile0 + r * 8 + (vt >> 3);
+                walk_step_pre(wf->ndim, c < B ? c : B - 1, vt & 7, wf->live, (long)wf->n_live, wf->key, wf->first_step + (uint64_t)wstep, wf->u, wf->v,
+                              wf->prop, theta, wf->inside, wf->loglstar, wf->counts, wf->n_steps, (uint64_t)wstep, wpre[r]);
+            }
+#else
+            for (int r = 0; r < WNR; ++r) { wpre[r] = WalkPre{}; wpre[r].active = 1; wpre[r].in0 = 1; }
+#endif
+        }
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
         if (vt < TS && tile0 + vt < B) {
@@ -2215,6 +2242,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 double tot = c + g;
                 if (isbad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
                 out[tile0 + vt] = tot;
+                if constexpr (WALKF) reinterpret_cast<double*>(smem + L.stage)[vt] = tot;      // (the prologue's staging area is free by now)
             } else {
                 // split launch: this workgroup owns a GROUP of one to three adjacent bands.  A band's sums sit in the slot of its
                 // observed filter (lean_task) or of its last work item (lean_gen_task, FASTM 5); they are parked per observed filter
@@ -2228,6 +2256,22 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     gp_parts[((long)P.O + o) * B + tile0 + vt] = gp_tot[slot];
                 }
             }
+        }
+        if constexpr (WALKF) {
+            // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch
+            double* totl = reinterpret_cast<double*>(smem + L.stage);
+#ifndef NMMA_DBG_WALK_NOPOST
+#pragma unroll
+            for (int r = 0; r < WNR; ++r) {
+                const int cl = r * 8 + (vt >> 3);
+                const long c = tile0 + cl;
+                if (c < B)
+                    walk_step_post<false>(wspl, wf->ndim, 8, c, vt & 7, totl[cl], wpre[r], wf->u, wf->v, wf->logl, wf->counts, wf->prop, const_cast<double*>(theta),
+                                   wf->inside, wf->con_ops, wf->n_con_ops, !wlast);
+            }
+#else
+            if (vt == 0) wf->counts[0] = wpre[0].cnt0 + (int)wpre[WNR - 1].gamma;      // (keep the first phase alive)
+#endif
         }
         if (SPLITTABLE && nb > 1) {
             // The group that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused

@@ -16,133 +16,14 @@
 
 #include "../../include/nmma_hip.h"
 #include "nmma_common.h"
+#include "walk_device.h"
 
 namespace nmma {
-
-struct WalkSpec {
-    nmma_walk_prior p[NMMA_WALK_MAX_DIM];
-    int32_t ndim;
-};
-
-__device__ __forceinline__ uint64_t walk_mix64(uint64_t x) {
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-// draw k of step `step` of the chain with key `key`: sampler.py:counter_uniforms, bit for bit
-__device__ __forceinline__ double walk_uniform(const uint64_t key, const uint64_t step, const uint64_t k) {
-    const uint64_t G = 0x9E3779B97F4A7C15ull;
-    uint64_t x = walk_mix64(walk_mix64(key * G + G) ^ (step * 0xD1342543DE82EF95ull + k * 0xA0761D6478BD642Full + G));
-    x = walk_mix64(x);
-    return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-}
-__device__ __forceinline__ double floored_mod(const double x, const double m) {       // np.mod for m > 0
-    const double r = fmod(x, m);
-    return r < 0.0 ? r + m : r;
-}
-// bilby/core/prior/analytical.py: rescale(val) of the analytic priors
-__device__ inline double walk_rescale(const nmma_walk_prior& p, const double u) {
-    switch (p.kind) {
-        case NMMA_PRIOR_UNIFORM: return p.a + u * (p.b - p.a);
-        case NMMA_PRIOR_SINE: { const double norm = 1.0 / (cos(p.a) - cos(p.b)); return acos(cos(p.a) - u / norm); }
-        case NMMA_PRIOR_COSINE: { const double norm = 1.0 / (sin(p.b) - sin(p.a)); return asin(u / norm + sin(p.a)); }
-        case NMMA_PRIOR_POWERLAW:
-            if (p.alpha == -1.0) return p.a * exp(u * log(p.b / p.a));
-            return pow(pow(p.a, 1.0 + p.alpha) + u * (pow(p.b, 1.0 + p.alpha) - pow(p.a, 1.0 + p.alpha)), 1.0 / (1.0 + p.alpha));
-        case NMMA_PRIOR_GAUSSIAN: return p.a + erfinv(2.0 * u - 1.0) * 1.4142135623730951 * p.b;      // mu, sigma
-        case NMMA_PRIOR_TRUNC_GAUSSIAN: return erfinv(2.0 * u * p.alpha + p.c) * 1.4142135623730951 * p.b + p.a;   // bilby TruncatedGaussian.rescale
-        case NMMA_PRIOR_LOGNORMAL: return exp(p.a + sqrt(2.0 * p.b * p.b) * erfinv(2.0 * u - 1.0));                // bilby LogNormal.rescale
-        case NMMA_PRIOR_HALF_GAUSSIAN: return erfinv(u) * 1.4142135623730951 * p.b;                                // bilby HalfGaussian.rescale
-        default: return p.a;                                                                        // NMMA_PRIOR_DELTA: peak
-    }
-}
-
-// A GROUP of T = 8 / 16 / 32 lanes per chain (the smallest that holds the dimensions: lane d owns dimension d), 256 / T chains per
-// workgroup.  One thread per chain made this kernel a 10 us chain of dependent loads and a serial loop over the dimensions around a
-// 29 us likelihood launch; with a lane per dimension the loads of a row are one coalesced access and the prior transforms run side by
-// side (rocprofv3: 10.1 -> see DESIGN.md section 6).  Every lane draws the chain's seven uniforms itself (integer hashing, no traffic).
-// The prior table is staged from the kernel arguments into LDS so that lanes can index it by their dimension.
-__device__ __forceinline__ int walk_group(const int D) { return D <= 8 ? 8 : D <= 16 ? 16 : 32; }
-
-static_assert(sizeof(nmma_walk_prior) == 40 && NMMA_WALK_MAX_DIM * 10 <= 512, "at most two dwords of the table per thread of the workgroup");
-__device__ __forceinline__ void walk_stage_spec(const WalkSpec& S, nmma_walk_prior* sp) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.p[0]);          // (the kernel-argument segment, read per thread)
-    for (int j = threadIdx.x; j < S.ndim * 10; j += 256) reinterpret_cast<uint32_t*>(sp)[j] = src[j];
-    __syncthreads();
-}
-
-// Constraint priors: the postfix program of include/nmma_hip.h (nmma_con_op) on one row of theta.  Uniform control flow (every
-// lane runs the same program); the stack is a handful of doubles.
-__device__ inline bool con_row_ok(const nmma_con_op* __restrict__ ops, const int n_ops, const double* __restrict__ row) {
-    double st[NMMA_CON_MAX_STACK];
-    int sp = 0;
-    bool ok = true;
-    for (int i = 0; i < n_ops; ++i) {
-        const nmma_con_op o = ops[i];
-        switch (o.op) {
-            case NMMA_CON_PUSH_COL: st[sp++] = row[o.col]; break;
-            case NMMA_CON_PUSH_CONST: st[sp++] = o.value; break;
-            case NMMA_CON_ADD: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
-            case NMMA_CON_SUB: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
-            case NMMA_CON_MUL: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
-            case NMMA_CON_DIV: st[sp - 2] = st[sp - 2] / st[sp - 1]; --sp; break;
-            case NMMA_CON_POW: st[sp - 2] = pow(st[sp - 2], st[sp - 1]); --sp; break;
-            case NMMA_CON_MIN: st[sp - 2] = fmin(st[sp - 2], st[sp - 1]); --sp; break;
-            case NMMA_CON_MAX: st[sp - 2] = fmax(st[sp - 2], st[sp - 1]); --sp; break;
-            case NMMA_CON_NEG: st[sp - 1] = -st[sp - 1]; break;
-            case NMMA_CON_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
-            case NMMA_CON_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
-            case NMMA_CON_LOG10: st[sp - 1] = log10(st[sp - 1]); break;
-            case NMMA_CON_LOG: st[sp - 1] = log(st[sp - 1]); break;
-            case NMMA_CON_EXP: st[sp - 1] = exp(st[sp - 1]); break;
-            case NMMA_CON_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-            case NMMA_CON_COS: st[sp - 1] = cos(st[sp - 1]); break;
-            case NMMA_CON_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
-            case NMMA_CON_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
-            case NMMA_CON_SIGN: { const double x = st[sp - 1]; st[sp - 1] = x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); } break;
-            case NMMA_CON_CHECK_GT: ok = ok && (st[sp - 1] > o.value); break;
-            default: ok = ok && (st[sp - 1] < o.value); --sp; break;          // NMMA_CON_CHECK_LT
-        }
-    }
-    return ok;
-}
 
 __global__ __launch_bounds__(256) void con_floor_kernel(const nmma_con_op* __restrict__ ops, const int n_ops, const double* __restrict__ theta,
                                                         const long B, const long ld, double* __restrict__ logl) {
     const long b = (long)blockIdx.x * 256 + threadIdx.x;
     if (b < B && !con_row_ok(ops, n_ops, theta + b * ld)) logl[b] = NMMA_LOGL_FLOOR;
-}
-
-// proposal in the unit cube (differential evolution between two other live points), boundary conditions, inside-the-cube flag, prior
-// transform.  A proposal outside the cube keeps the chain's current point in `theta` (the lock-step likelihood launch evaluates every
-// chain; the accept kernel ignores that row).
-__device__ __forceinline__ void walk_propose_one(const nmma_walk_prior* sp, const int D, const int T, const long c, const int lane,
-                                                 const double* __restrict__ live, const long n_live, const double* u, const double* v,
-                                                 const uint64_t* __restrict__ key, const uint64_t step, double* prop, double* theta,
-                                                 int32_t* inside) {
-    const uint64_t kc = key[c];
-    double r[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) r[k] = walk_uniform(kc, step, (uint64_t)k);
-    long i = (long)(r[0] * (double)n_live);
-    i = i > n_live - 1 ? n_live - 1 : i;
-    long jj = (long)(r[1] * (double)(n_live - 1));
-    jj = jj > n_live - 2 ? n_live - 2 : jj;
-    const long j = (i + 1 + jj) % n_live;                                         // a different live point
-    const double gamma = r[2] < 0.5 ? 1.0 : 2.38 / sqrt(2.0 * (double)D) * (-0.25 * log(r[3] * r[4] * r[5] * r[6]));   // Gamma(4, 1/4)
-    int in = 1;
-    double x = 0.0;
-    if (lane < D) {
-        x = u[c * D + lane] + gamma * (live[j * D + lane] - live[i * D + lane]);
-        const int32_t bc = sp[lane].boundary;
-        if (bc == NMMA_BOUNDARY_PERIODIC) x = floored_mod(x, 1.0);
-        else if (bc == NMMA_BOUNDARY_REFLECTIVE) { const double q = floored_mod(x, 2.0); x = q > 1.0 ? 2.0 - q : q; }
-        prop[c * D + lane] = x;
-        in = (x >= 0.0) && (x <= 1.0);
-    }
-    for (int m = T >> 1; m > 0; m >>= 1) in &= __shfl_xor(in, m, 64);           // (groups are aligned powers of two: the exchange stays inside)
-    if (lane == 0) inside[c] = in;
-    if (lane < D) theta[c * D + lane] = in ? walk_rescale(sp[lane], x) : v[c * D + lane];
 }
 
 __global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, const double* __restrict__ live, const long n_live,
@@ -156,30 +37,6 @@ __global__ __launch_bounds__(256) void walk_propose_kernel(const WalkSpec S, con
     if (c < n) walk_propose_one(sp, S.ndim, T, c, threadIdx.x % T, live, n_live, u, v, key, step, prop, theta, inside);
 }
 
-// accept when the proposal was inside the cube and its likelihood beats the chain's bound (dynesty: logl > loglstar)
-__device__ __forceinline__ void walk_accept_one(const int D, const long c, const int lane, const double* prop, const double* theta,
-                                                const int32_t* inside, const double* __restrict__ l_prop, const double* __restrict__ loglstar,
-                                                double* u, double* v, double* __restrict__ logl, int32_t* __restrict__ counts,
-                                                const int32_t* __restrict__ n_steps, const uint64_t step,
-                                                const nmma_con_op* __restrict__ con_ops = nullptr, const int n_con_ops = 0) {
-    if (n_steps != nullptr && step > (uint64_t)n_steps[c]) return;       // this chain's walk is over (walk lengths may differ per chain)
-    const int in = inside[c];
-    double lp = l_prop[c];
-    // a Constraint prior the proposal violates: the reference's likelihood returns the floor for it (core/base.py:77-82)
-    if (n_con_ops > 0 && in && !con_row_ok(con_ops, n_con_ops, theta + c * D)) lp = NMMA_LOGL_FLOOR;
-    const bool acc = in && lp > loglstar[c];
-    if (acc && lane < D) { u[c * D + lane] = prop[c * D + lane]; v[c * D + lane] = theta[c * D + lane]; }
-    if (lane == 0) {
-        int32_t* cnt = counts + 4 * c;                      // {accept, reject, nfail, ncall}
-        if (!in) cnt[2] += 1;
-        else {
-            cnt[3] += 1;
-            if (acc) { logl[c] = lp; cnt[0] += 1; }
-            else cnt[1] += 1;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const long n, const double* __restrict__ prop,
                                                           const double* __restrict__ theta, const int32_t* __restrict__ inside,
                                                           const double* __restrict__ l_prop, const double* __restrict__ loglstar,
@@ -188,7 +45,7 @@ __global__ __launch_bounds__(256) void walk_accept_kernel(const int D, const lon
                                                           const uint64_t step, const nmma_con_op* __restrict__ con_ops, const int n_con_ops) {
     const int T = walk_group(D);
     const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
-    if (c < n) walk_accept_one(D, c, threadIdx.x % T, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
+    if (c < n) walk_accept_one(D, c, threadIdx.x % T, prop, theta, inside, l_prop[c], loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
 }
 
 // End of a queue (sampler.py: run_many): a chain that never accepted returns a fresh draw from the prior -- u = the counter hash of
@@ -236,7 +93,7 @@ __global__ __launch_bounds__(256) void walk_step_kernel(const WalkSpec S, const 
     const long c = (long)blockIdx.x * (256 / T) + threadIdx.x / T;
     if (c >= n) return;
     const int lane = threadIdx.x % T;
-    walk_accept_one(S.ndim, c, lane, prop, theta, inside, l_prop, loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
+    walk_accept_one(S.ndim, c, lane, prop, theta, inside, l_prop[c], loglstar, u, v, logl, counts, n_steps, step, con_ops, n_con_ops);
     walk_propose_one(sp, S.ndim, T, c, lane, live, n_live, u, v, key, first_step + step, prop, theta, inside);
 }
 
@@ -569,6 +426,7 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     size_t off = 0;
+    const size_t o_wf = off;    off = al(off + sizeof(nmma_walk_fuse));        // the fused step's view of the chains (device copy)
     const size_t o_live = off;  off = al(off + sizeof(double) * NL * D);
     const size_t o_star = off;  off = al(off + sizeof(double) * n);
     const size_t o_key = off;   off = al(off + sizeof(uint64_t) * n);
@@ -609,6 +467,22 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     // NaN = "never moved" (sampler.py: run_many); the counts start at zero
     { double* lg = reinterpret_cast<double*>(p + o_logl); for (long c = 0; c < n; ++c) lg[c] = __builtin_nan(""); }
     memset(p + o_cnt, 0, sizeof(int32_t) * 4 * n);
+    {
+        nmma_walk_fuse* wf = reinterpret_cast<nmma_walk_fuse*>(p + o_wf);
+        memset(wf, 0, sizeof(*wf));
+        for (int dd = 0; dd < D; ++dd) wf->priors[dd] = S.p[dd];
+        wf->ndim = (int32_t)D;
+        wf->n_con_ops = q->constraints ? q->constraints->n_ops : 0;
+        wf->live = reinterpret_cast<const double*>(d + o_live); wf->n_live = NL;
+        wf->key = reinterpret_cast<const uint64_t*>(d + o_key);
+        wf->prop = reinterpret_cast<double*>(d + o_prop); wf->inside = reinterpret_cast<int32_t*>(d + o_in);
+        wf->loglstar = reinterpret_cast<const double*>(d + o_star);
+        wf->u = reinterpret_cast<double*>(d + o_u); wf->v = reinterpret_cast<double*>(d + o_v);
+        wf->logl = reinterpret_cast<double*>(d + o_logl); wf->counts = reinterpret_cast<int32_t*>(d + o_cnt);
+        wf->n_steps = q->walks_per_chain ? reinterpret_cast<const int32_t*>(d + o_walks) : nullptr;
+        wf->con_ops = q->constraints ? q->constraints->ops_d : nullptr;
+        wf->first_step = q->first_step;
+    }
 #define NMQ(call, what) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return fail(std::string("nmma_em_walk_queue: ") + what + ": " + hipGetErrorString(e_)); } while (0)
     NMQ(hipEventRecord(ws->ev0, s), "event");
     NMQ(hipMemcpyAsync(d, p, up_end, hipMemcpyHostToDevice, s), "upload");
@@ -624,7 +498,18 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     const dim3 grid_g(walk_blocks(n, (int32_t)D)), grid_t((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(walk_rescale_kernel, grid_t, block, 0, s, S, n, u_d, v_d);
     hipLaunchKernelGGL(walk_propose_kernel, grid_g, block, 0, s, S, live_d, NL, u_d, v_d, key_d, n, q->first_step, prop_d, theta_d, in_d);
+    // One launch per MCMC step where the handle's task flavour carries the fused step (accept + next proposal in the likelihood
+    // kernel's epilogue, nmma_em_loglike_walk); else the likelihood launch followed by walk_step_kernel.  Same device functions,
+    // same bits.
+    bool fused = q->constraints == nullptr;      // (the constraint interpreter's register needs do not fit the likelihood kernel's budget)
+    const nmma_walk_fuse* wf_d = reinterpret_cast<const nmma_walk_fuse*>(d + o_wf);
     for (int k = 1; k <= max_walks; ++k) {
+        if (fused) {
+            const int rc = nmma_em_loglike_walk(h, theta_d, n, D, lp_d, wf_d, (uint64_t)k, k == max_walks ? 1 : 0, stream);
+            if (rc == 1) return 1;
+            if (rc == 0) continue;
+            fused = false;
+        }
         if (nmma_em_loglike(h, theta_d, n, D, lp_d, stream)) return 1;
         if (k < max_walks)
             hipLaunchKernelGGL(walk_step_kernel, grid_g, block, 0, s, S, live_d, NL, key_d, n, prop_d, theta_d, in_d, lp_d, star_d, u_d, v_d, logl_d, cnt_d,

@@ -68,6 +68,49 @@ def test_queue_call_is_bit_identical_to_the_step_loop(torch_cuda, config2):
         assert np.all(ql[moved] > bound[moved]) and _same(eng.loglike(np.ascontiguousarray(qv)), ql)
 
 
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6"])
+def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
+    """The queue's one-launch MCMC step (accept + next proposal in the likelihood kernel's epilogue: ``nmma_em_loglike_walk``,
+    ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (``NMMA_WALK_NO_FUSE=1``) and against the
+    Python-driven step loop: the same bits -- for the constant-systematics flavour (config 2), the sampled ``em_syserr`` flavour
+    (7 sampled dimensions) and a six-input surrogate (KP = 2) -- with periodic / reflective dimensions and ragged queue sizes."""
+    import os
+    from tests import cases
+    from tests.helpers import engine_from_case
+    torch = torch_cuda
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    eng = engine_from_case(case)
+    names = case["names"]
+    assert len(names) <= 8
+    th = case["theta"]
+    lo, hi = th.min(axis=0) - 1e-3, th.max(axis=0) + 1e-3
+    pri = {k: UniformPrior(float(a), float(b)) for k, a, b in zip(names, lo, hi)}
+    pt = smp.BatchedPriorTransform(pri, names)
+    w = smp.EnsembleWalkSampler(ndim=len(names), periodic=[1], reflective=[2], walks=7)
+    table = smp.device_prior_table(pri, names, w.periodic, w.reflective)
+    rng = np.random.default_rng(71)
+    for n in (1, 37, 1000):
+        n_live = 300
+        live = rng.uniform(0.2, 0.8, (n_live, len(names)))
+        u0 = live[rng.integers(0, n_live, n)].copy()
+        bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.3))
+        keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
+        steps = 7 if n != 37 else (2 + np.arange(n) % 6).astype(np.int32)
+        fused = eng.walk_queue(table, live, u0, bound, keys, steps)
+        os.environ["NMMA_WALK_NO_FUSE"] = "1"
+        try:
+            two = eng.walk_queue(table, live, u0, bound, keys, steps)
+        finally:
+            del os.environ["NMMA_WALK_NO_FUSE"]
+        for a, b in zip(fused, two):
+            assert _same(a, b), (name, n)
+        buf = torch.empty(n, dtype=torch.float64, device="cuda:0")
+        u, v, logl, counts = smp.device_walk(table, live, u0, bound, keys, steps, lambda t: eng.loglike(t, out=buf))
+        w._device_fresh_draws(np.nonzero(counts[:, 0] == 0)[0], table, keys, u, v, logl, counts, lambda t: eng.loglike(t), 0)
+        assert _same(fused[0], u) and _same(fused[2], logl) and np.array_equal(fused[3], counts)
+    eng.close()
+
+
 def test_pool_map_on_the_argument_batch_returns_array_backed_records(torch_cuda, config2):
     """``prepare_sampler`` hands the queue over as ONE set of arrays and ``GPUPool.map(walker.sample, queue)`` answers with an
     array-backed sequence: the records (u, v, logl, ncall, blob) are those of the per-record list path, bit for bit."""
