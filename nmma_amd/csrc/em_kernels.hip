@@ -603,7 +603,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + (3 * n_items + 4 + 4 * n_items) * 4);      // (+ produced / consumed counters per (item, 16 samples): dense task)
+    L.sync = off; off = align16(off + (3 * n_items + 4 + 4 * n_items + 1) * 4);      // (+ produced / consumed counters per (item, 16 samples): dense task)
     L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
@@ -689,13 +689,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
-    for (int j = tid; j < 7 * P.n_items + 4; j += logl_threads(NMW, NVW)) sync[j] = 0;
+    for (int j = tid; j < 7 * P.n_items + 5; j += logl_threads(NMW, NVW)) sync[j] = 0;      // (the last one: fused MCMC step, first phase done)
     if (tid == 0) g_wd_trip = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
     const int W = P.n_items;
     gci32p items = as_global(P.items);
+    // (WALKF: the fused MCMC step keeps a group of 8 lanes per chain -- up to 8 sampled dimensions -- and 16-sample tiles)
+    constexpr int WNR = WALKF ? TS / 8 : 1;
+    // (staging area after the prologue: tot[TS] | parked walk state 5 x WNR x 64 + 2 TS doubles + 6 TS ints | prior table)
+    nmma_walk_prior* wspl = reinterpret_cast<nmma_walk_prior*>(reinterpret_cast<double*>(smem + L.stage) + TS + 5 * WNR * 64 + 2 * TS + 3 * TS);
 
     if (wave < NMW) {
         // ============================ MFMA role ============================
@@ -2125,6 +2129,58 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 
     if constexpr (FAST) {
         sync_wait(sync + W + 1, NVW, P.watchdog, 400);   // prologue data of every likelihood wave in LDS
+        if constexpr (WALKF) {
+            // ---- the fused MCMC step, first phase (the LAST likelihood wave, before it claims tasks): everything that does not
+            // depend on log L -- the chains' uniforms, the two live points of each move, the chains' state -- is loaded NOW and
+            // parked in the prologue's staging area (free from here on), so that the epilogue finds it in LDS instead of waiting for
+            // a chain of dependent L2 round trips after the tile's last task.  At priority 0: it has all of the launch to finish
+            // and must not take issue slots from the MFMA stream.
+            if (!helper && vwave == NVW - 1) {
+                __builtin_amdgcn_s_setprio(0);
+                double* wl = reinterpret_cast<double*>(smem + L.stage);
+                double* pl = wl + TS;                         // [5][WNR * 64]: live_j - live_i | u | v | proposal | theta, per (round, lane)
+                double* pcd = pl + 5 * WNR * 64;              // [2][TS]: gamma | bound, per chain
+                int* pci = reinterpret_cast<int*>(pcd + 2 * TS);      // [6][TS]: inside | active | counts[4]
+                {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(&wf->priors[0]);
+                    for (int j = lane; j < wf->ndim * 10; j += 64) reinterpret_cast<uint32_t*>(wspl)[j] = src[j];
+                }
+#ifndef NMMA_DBG_WALK_NOPRE
+                WalkPre wq[WNR];
+                WalkPreKey wkey[WNR];
+                double wr[WNR][7];
+#pragma unroll
+                for (int r = 0; r < WNR; ++r) {      // every round's state loads first ...
+                    const long c = tile0 + r * 8 + (lane >> 3);
+                    walk_step_pre_a(wf->ndim, c < B ? c : B - 1, lane & 7, wf->key, wf->u, wf->v, wf->prop, theta, wf->inside, wf->loglstar, wf->counts,
+                                    wf->n_steps, (uint64_t)wstep, wq[r], wkey[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < WNR; ++r)        // ... then the hashes and the live points they address ...
+                    walk_step_pre_b(wf->ndim, lane & 7, wf->live, (long)wf->n_live, wf->first_step + (uint64_t)wstep, wkey[r], wq[r], wr[r]);
+#pragma unroll
+                for (int r = 0; r < WNR; ++r) {      // ... then the move's scale; park everything
+                    walk_step_pre_c(wf->ndim, wr[r], wq[r]);
+                    const int e = r * 64 + lane;
+                    pl[e] = wq[r].lj - wq[r].li; pl[WNR * 64 + e] = wq[r].uu; pl[2 * WNR * 64 + e] = wq[r].vv; pl[3 * WNR * 64 + e] = wq[r].pp;
+                    pl[4 * WNR * 64 + e] = wq[r].th;
+                    if ((lane & 7) == 0) {
+                        const int cl = r * 8 + (lane >> 3);
+                        pcd[cl] = wq[r].gamma; pcd[TS + cl] = wq[r].lstar;
+                        pci[cl] = wq[r].in0; pci[TS + cl] = wq[r].active; pci[2 * TS + cl] = wq[r].cnt0; pci[3 * TS + cl] = wq[r].cnt1;
+                        pci[4 * TS + cl] = wq[r].cnt2; pci[5 * TS + cl] = wq[r].cnt3;
+                    }
+                }
+#endif
+                sync_signal(sync + 7 * W + 4, lane);
+                switch (P.prio_valu) {
+                    case 0: break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+        }
         // Tasks (item-major) are claimed from one LDS counter: likelihood waves from the start, MFMA-role
         // waves once their record stream is finished.  Any wave may compute any task (results go to
         // per-(item, sample) slots), so the claim order does not affect the values.
@@ -2209,29 +2265,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
-    // (WALKF: the fused MCMC step keeps a group of 8 lanes per chain -- up to 8 sampled dimensions -- and 16-sample tiles)
-    constexpr int WNR = WALKF ? TS / 8 : 1;
     WalkPre wpre[WNR];
-    nmma_walk_prior* wspl = reinterpret_cast<nmma_walk_prior*>(reinterpret_cast<double*>(smem + L.stage) + TS);
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
-        if constexpr (WALKF) {
-            // ---- the MCMC step, first phase: everything that does not depend on log L is put in flight NOW, while this wave
-            // would only wait for the tile's last tasks (the prologue's staging area is free: the prior table goes there)
-            {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(&wf->priors[0]);
-                for (int j = vt; j < wf->ndim * 10; j += 64) reinterpret_cast<uint32_t*>(wspl)[j] = src[j];
-            }
-#ifndef NMMA_DBG_WALK_NOPRE
-#pragma unroll
-            for (int r = 0; r < WNR; ++r) {
-                const long c = tile0 + r * 8 + (vt >> 3);
-                walk_step_pre(wf->ndim, c < B ? c : B - 1, vt & 7, wf->live, (long)wf->n_live, wf->key, wf->first_step + (uint64_t)wstep, wf->u, wf->v,
-                              wf->prop, theta, wf->inside, wf->loglstar, wf->counts, wf->n_steps, (uint64_t)wstep, wpre[r]);
-            }
-#else
-            for (int r = 0; r < WNR; ++r) { wpre[r] = WalkPre{}; wpre[r].active = 1; wpre[r].in0 = 1; }
-#endif
-        }
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
         if (vt < TS && tile0 + vt < B) {
@@ -2260,6 +2295,21 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         if constexpr (WALKF) {
             // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch
             double* totl = reinterpret_cast<double*>(smem + L.stage);
+            sync_wait(sync + 7 * W + 4, 1, P.watchdog, 900);          // (the first phase finished long ago)
+            {
+                const double* pl = totl + TS;
+                const double* pcd = pl + 5 * WNR * 64;
+                const int* pci = reinterpret_cast<const int*>(pcd + 2 * TS);
+#pragma unroll
+                for (int r = 0; r < WNR; ++r) {
+                    const int e = r * 64 + vt, cl = r * 8 + (vt >> 3);
+                    WalkPre& w = wpre[r];
+                    w.li = 0.0; w.lj = pl[e]; w.uu = pl[WNR * 64 + e]; w.vv = pl[2 * WNR * 64 + e]; w.pp = pl[3 * WNR * 64 + e]; w.th = pl[4 * WNR * 64 + e];
+                    w.gamma = pcd[cl]; w.lstar = pcd[TS + cl];
+                    w.in0 = pci[cl]; w.active = pci[TS + cl]; w.cnt0 = pci[2 * TS + cl]; w.cnt1 = pci[3 * TS + cl]; w.cnt2 = pci[4 * TS + cl];
+                    w.cnt3 = pci[5 * TS + cl];
+                }
+            }
 #ifndef NMMA_DBG_WALK_NOPOST
 #pragma unroll
             for (int r = 0; r < WNR; ++r) {

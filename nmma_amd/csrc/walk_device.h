@@ -167,12 +167,14 @@ struct WalkPre {
     int32_t in0, active, cnt0, cnt1, cnt2, cnt3;
 };
 
-__device__ __forceinline__ void walk_step_pre(const int D, const long c, const int lane, const double* __restrict__ live, const long n_live,
-                                              const uint64_t* __restrict__ key, const uint64_t rng_step, const double* u, const double* v,
-                                              const double* prop, const double* theta, const int32_t* inside,
-                                              const double* __restrict__ loglstar, const int32_t* __restrict__ counts,
-                                              const int32_t* __restrict__ n_steps, const uint64_t step, WalkPre& w) {
-    const uint64_t kc = key[c];
+// (three sub-steps, so that a caller with several rounds of chains can issue ALL rounds' loads of a sub-step back to back: the key
+//  and state loads, then the hashes and the live-point gathers they address, then the arithmetic on the uniforms)
+struct WalkPreKey { uint64_t kc; };
+__device__ __forceinline__ void walk_step_pre_a(const int D, const long c, const int lane, const uint64_t* __restrict__ key, const double* u,
+                                                const double* v, const double* prop, const double* theta, const int32_t* inside,
+                                                const double* __restrict__ loglstar, const int32_t* __restrict__ counts,
+                                                const int32_t* __restrict__ n_steps, const uint64_t step, WalkPre& w, WalkPreKey& k) {
+    k.kc = key[c];
     w.in0 = inside[c];
     w.lstar = loglstar[c];
     w.active = !(n_steps != nullptr && step > (uint64_t)n_steps[c]);
@@ -180,14 +182,16 @@ __device__ __forceinline__ void walk_step_pre(const int D, const long c, const i
     if (lane == 0) { const int32_t* cnt = counts + 4 * c; w.cnt0 = cnt[0]; w.cnt1 = cnt[1]; w.cnt2 = cnt[2]; w.cnt3 = cnt[3]; }
     w.uu = w.vv = w.pp = w.th = 0.0;
     if (lane < D) { w.uu = u[c * D + lane]; w.vv = v[c * D + lane]; w.pp = prop[c * D + lane]; w.th = theta[c * D + lane]; }
-    // The chain's seven uniforms, ONE per lane of its group (lane k draws number k) and handed round by lane shuffles: the fused
-    // epilogue runs on a wave whose every vector instruction takes an issue slot from the MFMA stream of its SIMD, and seven
-    // 64-bit hashes per lane were most of this phase's instructions.  Same numbers as walk_uniform(key, step, k) anywhere else.
-    const double mine = walk_uniform(kc, rng_step, (uint64_t)(lane & 7));
+}
+// The chain's seven uniforms, ONE per lane of its group (lane k draws number k) and handed round by lane shuffles: the fused
+// epilogue runs on a wave whose every vector instruction takes an issue slot from the MFMA stream of its SIMD, and seven 64-bit
+// hashes per lane were most of this phase's instructions.  Same numbers as walk_uniform(key, step, k) anywhere else.
+__device__ __forceinline__ void walk_step_pre_b(const int D, const int lane, const double* __restrict__ live, const long n_live,
+                                                const uint64_t rng_step, const WalkPreKey& k, WalkPre& w, double (&r)[7]) {
+    const double mine = walk_uniform(k.kc, rng_step, (uint64_t)(lane & 7));
     const int g0 = (int)(threadIdx.x & 63) & ~7;              // (groups of at least 8 lanes: T >= 8)
-    double r[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) r[k] = __shfl(mine, g0 + k, 64);
+    for (int q = 0; q < 7; ++q) r[q] = __shfl(mine, g0 + q, 64);
     long i = (long)(r[0] * (double)n_live);
     i = i > n_live - 1 ? n_live - 1 : i;
     long jj = (long)(r[1] * (double)(n_live - 1));
@@ -195,7 +199,20 @@ __device__ __forceinline__ void walk_step_pre(const int D, const long c, const i
     const long j = (i + 1 + jj) % n_live;                                         // a different live point
     w.li = w.lj = 0.0;
     if (lane < D) { w.lj = live[j * D + lane]; w.li = live[i * D + lane]; }
+}
+__device__ __forceinline__ void walk_step_pre_c(const int D, const double (&r)[7], WalkPre& w) {
     w.gamma = r[2] < 0.5 ? 1.0 : 2.38 / sqrt(2.0 * (double)D) * (-0.25 * log(r[3] * r[4] * r[5] * r[6]));   // Gamma(4, 1/4)
+}
+__device__ __forceinline__ void walk_step_pre(const int D, const long c, const int lane, const double* __restrict__ live, const long n_live,
+                                              const uint64_t* __restrict__ key, const uint64_t rng_step, const double* u, const double* v,
+                                              const double* prop, const double* theta, const int32_t* inside,
+                                              const double* __restrict__ loglstar, const int32_t* __restrict__ counts,
+                                              const int32_t* __restrict__ n_steps, const uint64_t step, WalkPre& w) {
+    WalkPreKey k;
+    double r[7];
+    walk_step_pre_a(D, c, lane, key, u, v, prop, theta, inside, loglstar, counts, n_steps, step, w, k);
+    walk_step_pre_b(D, lane, live, n_live, rng_step, k, w, r);
+    walk_step_pre_c(D, r, w);
 }
 
 template <bool CON = true>
