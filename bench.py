@@ -423,7 +423,8 @@ def device_walk_queue(case, syn, inner_rate, n=4096, walks=100, repeats=7):
     return {"records": n, "walks": walks, "map_ms": 1e3 * med(t_map), "device_ms": 1e3 * med(gpu), "map_plus_materialised_records_ms": 1e3 * med(t_all),
             "map_ms_per_record_arguments": 1e3 * med(t_list), "evals_per_s": rate, "fraction_of_inner_loop_rate": rate / inner_rate,
             "what": "wall time of GPUPool.map(walker.sample, queue) for prepare_sampler's array-backed queue: one library call "
-                    "(nmma_em_walk_queue: upload, 100 x {likelihood, accept + next proposal}, fresh draws, download), array-backed records"}
+                    "(nmma_em_walk_queue: upload, 100 x ONE launch {likelihood + accept + next proposal}, fresh draws, download), array-backed "
+                    "records; fraction_of_inner_loop_rate is relative to the two-launch step loop of `device_walk`"}
 
 
 def _oracle_rows():
