@@ -55,3 +55,6 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --ker
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $o/pmc_sq3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq3.log 2>&1
 find $o -name "*kernel_stats.csv" | head
 cat $o/bench_line.json
+# the sampler queue (4096 records x 100 steps): kernel times of the fused MCMC step and of the queue's other launches
+bash tools/gpu_fuse_prof.sh > $o/stats_queue.log 2>&1
+cp $(find gpurun_out/prof_fuse/a -name "*kernel_stats.csv" | head -1) $o/queue_kernel_stats.csv 2>/dev/null

@@ -64,6 +64,9 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     }
     json.dump(traffic, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
+f = os.path.join(src, "queue_kernel_stats.csv")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, f"{tag}_queue_kernel_stats.csv"))
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(dst, f"{tag}_bench_line.json"))
@@ -72,7 +75,7 @@ for name in ("bench_line_b512.json", "bench_line_b1.json", "bench_line_b1024.jso
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
 for name in ("stats_models.log", "stats_dt05.log", "stats_dt05ext.log", "stats_c4.log", "stats_gw.log", "stats_gw_fused.log", "gw_fused_pm.log",
-             "gw_fused_2048.log", "gw_fused_dm_pm.log", "gw_fused_tm.log", "gw_fused_tm_dm_pm.log", "pmc_gw.log", "pmc_c4.log", "pmc_models.log", "stats_at2017gfo.log", "small_batch.log", "perf_table.log", "device_walk.log"):
+             "gw_fused_2048.log", "gw_fused_dm_pm.log", "gw_fused_tm.log", "gw_fused_tm_dm_pm.log", "pmc_gw.log", "pmc_c4.log", "pmc_models.log", "stats_queue.log", "stats_at2017gfo.log", "small_batch.log", "perf_table.log", "device_walk.log"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         # (keep the result lines, not rocprofv3's chatter)
