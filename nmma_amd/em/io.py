@@ -4,7 +4,8 @@
   framework reads -- ``{filter}/W1,b1,W2,b2,VA,mins,maxs,tt,param_mins,param_maxs,n_coeff``.
 * ``convert_reference_model``: reads the reference's own layout
   (``{model}.joblib`` + ``{model}[_tf]/{filter}.keras|.h5``, nmma/em/model.py:593-696)
-  when joblib and keras/h5py are importable, and writes the flat file.
+  and writes the flat file: ``.joblib`` through joblib, legacy ``.h5`` networks through h5py or,
+  without it, the built-in reader ``em/hdf5_lite.py``; ``.keras`` archives need keras.
 * ``load_em_observations``: the ``time filter mag mag_error`` text photometry format
   (nmma/em/io.py:116-144; ISO-T times or MJD floats).
 """
@@ -52,32 +53,43 @@ def load_svd_model(path):
     return svd, params
 
 
+def _h5_datasets(path):
+    """``{"group/.../name": array}`` of a legacy Keras ``.h5`` file: through h5py when it is importable, else through the built-in
+    reader of the HDF5 subset such files use (``em/hdf5_lite.py``; the build image has no h5py)."""
+    try:
+        import h5py
+    except ImportError:
+        from . import hdf5_lite
+        return hdf5_lite.read_datasets(path)
+    out = {}
+    with h5py.File(path, "r") as f:
+        def visit(name, obj):
+            if isinstance(obj, h5py.Dataset):
+                out[name] = np.array(obj)
+        f.visititems(visit)
+    return out
+
+
 def _dense_weights_from_h5(path):
     """(W1, b1, W2, b2) of a Dense -> (Dropout) -> Dense Keras model saved as legacy HDF5
-    (``model_weights/<layer>/<layer>/{kernel,bias}:0``; layers in the order of the ``layer_names`` attribute,
-    nmma/em/training.py:353-364)."""
-    import h5py
-    with h5py.File(path, "r") as f:
-        grp = f["model_weights"] if "model_weights" in f else f
-        names = [n.decode() if isinstance(n, bytes) else str(n) for n in grp.attrs.get("layer_names", list(grp.keys()))]
-        dense = []
-        for ln in names:
-            if ln not in grp:
-                continue
-            found = {}
-
-            def visit(name, obj, found=found):
-                if isinstance(obj, h5py.Dataset):
-                    leaf = name.rsplit("/", 1)[-1].split(":")[0]
-                    if leaf in ("kernel", "bias"):
-                        found[leaf] = np.array(obj)
-            grp[ln].visititems(visit)
-            if "kernel" in found and "bias" in found:
-                dense.append((found["kernel"], found["bias"]))
+    (``model_weights/<layer>/<layer>/{kernel,bias}:0``, nmma/em/training.py:353-364; what ``keras.saving.load_model`` reads at
+    nmma/em/model.py:635-648).  The two Dense layers are told apart by their shapes -- the first one's output width is the second
+    one's input width -- not by the order of the group names (``dense_9`` sorts after ``dense_10``)."""
+    layers = {}
+    for name, arr in _h5_datasets(path).items():
+        parts = name.split("/")
+        if parts[0] != "model_weights" or len(parts) < 3:
+            continue
+        leaf = parts[-1].split(":")[0]
+        if leaf in ("kernel", "bias"):
+            layers.setdefault(parts[1], {})[leaf] = np.asarray(arr)
+    dense = [(v["kernel"], v["bias"]) for v in layers.values() if "kernel" in v and "bias" in v]
     if len(dense) != 2:
         raise ValueError(f"{path}: expected two Dense layers, found {len(dense)}")
+    if dense[0][0].shape[1] != dense[1][0].shape[0]:
+        dense.reverse()
     (w1, b1), (w2, b2) = dense
-    if w1.shape[1] != w2.shape[0] or b1.shape != (w1.shape[1],) or b2.shape != (w2.shape[1],):
+    if w1.ndim != 2 or w2.ndim != 2 or w1.shape[1] != w2.shape[0] or b1.shape != (w1.shape[1],) or b2.shape != (w2.shape[1],):
         raise ValueError(f"{path}: layer shapes do not chain: {w1.shape}, {b1.shape}, {w2.shape}, {b2.shape}")
     return w1, b1, w2, b2
 

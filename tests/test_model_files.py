@@ -1,0 +1,87 @@
+"""Model files in the reference's own layout (nmma/em/model.py:593-696): ``{model}.joblib`` written by
+``joblib.dump`` (training.py:save_model) next to ``{model}_tf/{filter}.h5`` written by Keras 2.x -- read here WITHOUT h5py or keras:
+``em/hdf5_lite.py`` parses the HDF5 subset such files use.  The fixture ``tests/golden/bu2019nsbh_tf_h5/ztfr.h5`` is one of the three
+trained networks the reference ships as test data (nmma/tests/data/Bu2019nsbh_tf, a data file, byte for byte); its weights were read
+once with h5py when ``tests/golden/bu2019nsbh_tf_weights.npz`` was made (tools/convert_h5_weights.py), which is what the built-in
+reader is compared with.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from nmma_amd.em import hdf5_lite, io as em_io
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+H5 = os.path.join(HERE, "golden", "bu2019nsbh_tf_h5", "ztfr.h5")
+
+
+def _weights():
+    with np.load(os.path.join(HERE, "golden", "bu2019nsbh_tf_weights.npz")) as z:
+        return {k: z[f"ztfr/{k}"] for k in ("W1", "b1", "W2", "b2")}
+
+
+def test_builtin_hdf5_reader_gets_the_trained_weights_bit_for_bit():
+    d = hdf5_lite.read_datasets(H5)
+    names = sorted(k for k in d if k.startswith("model_weights/"))
+    assert names == ["model_weights/dense_50/dense_50/bias:0", "model_weights/dense_50/dense_50/kernel:0",
+                     "model_weights/dense_51/dense_51/bias:0", "model_weights/dense_51/dense_51/kernel:0"]
+    assert len(d) == 13 and d["optimizer_weights/Adam/iter:0"].dtype == np.int64 and d["optimizer_weights/Adam/iter:0"].shape == ()
+    w = _weights()
+    w1, b1, w2, b2 = em_io._dense_weights_from_h5(H5)
+    for got, key in ((w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")):
+        assert got.dtype == np.float32 and np.array_equal(got, w[key]), key
+    assert w1.shape == (3, 2048) and w2.shape == (2048, 10)
+
+
+def test_reader_refuses_what_it_does_not_parse(tmp_path):
+    bad = tmp_path / "not.h5"
+    bad.write_bytes(b"PK\x03\x04" + b"\0" * 100)
+    with pytest.raises(hdf5_lite.Hdf5LiteError):
+        hdf5_lite.read_datasets(str(bad))
+    raw = bytearray(open(H5, "rb").read())
+    raw[8] = 2                                  # a version-2 superblock
+    v2 = tmp_path / "v2.h5"
+    v2.write_bytes(bytes(raw))
+    with pytest.raises(hdf5_lite.Hdf5LiteError):
+        hdf5_lite.read_datasets(str(v2))
+
+
+def test_reference_layout_joblib_plus_h5_end_to_end(tmp_path):
+    """``{svd_path}/Bu2019nsbh.joblib`` (the metadata dict of training.py:generate_svd_model, keys with ``_`` for ``:`` as the reference
+    stores sncosmo names) + ``{svd_path}/Bu2019nsbh_tf/{filter}.h5``: ``SVDLightCurveModel(svd_path=...)`` converts on the fly, writes
+    the flat file next to it and comes up with the trained weights and the basis truncated to n_coeff columns."""
+    import joblib
+    import shutil
+    from nmma_amd.em.model import SVDLightCurveModel
+    rng = np.random.default_rng(3)
+    nt, nc = 60, 10
+    tt = np.linspace(0.0, 21.0, nt)
+    meta = {}
+    for name in ("ztfr", "ps1__y"):             # (the second name exercises the "_" -> ":" mapping of model.py:604-606)
+        q, _ = np.linalg.qr(rng.standard_normal((nt, nt)))
+        meta[name] = dict(param_array_postprocess=rng.uniform(size=(28, 3)), param_mins=np.array([-3.0, -3.0, 0.0]),
+                          param_maxs=np.array([-1.0, -0.5, 90.0]), mins=-18.0 + rng.random(nt), maxs=-8.0 + rng.random(nt), tt=tt,
+                          n_coeff=nc, cAmat=rng.standard_normal((nc, 28)), cAstd=np.ones((nc, 28)), VA=q)
+    svd_path = tmp_path / "svdmodels"
+    (svd_path / "Bu2019nsbh_tf").mkdir(parents=True)
+    joblib.dump(meta, str(svd_path / "Bu2019nsbh.joblib"), compress=9)        # training.py: joblib.dump(self.svd_model, self.modelfile, compress=9)
+    shutil.copy(H5, str(svd_path / "Bu2019nsbh_tf" / "ztfr.h5"))
+    shutil.copy(H5, str(svd_path / "Bu2019nsbh_tf" / "ps1__y.h5"))
+    model = SVDLightCurveModel("Bu2019nsbh_tf", svd_path=str(svd_path), interpolation_type="tensorflow")
+    assert len(model.filters) == 2 and "ztfr" in model.filters
+    w = _weights()
+    for filt, t in model.svd_mag_model.items():
+        for key in ("W1", "b1", "W2", "b2"):
+            assert t[key].dtype == np.float32 and np.array_equal(t[key], w[key])
+        src = meta["ztfr" if filt == "ztfr" else "ps1__y"]
+        assert np.array_equal(t["VA"][:, :nc], src["VA"][:, :nc])          # (converted on the fly: the full matrix; from the flat file: n_coeff columns)
+        assert np.array_equal(t["mins"], src["mins"]) and np.array_equal(t["tt"], tt) and t["n_coeff"] == nc
+    assert os.path.isfile(str(svd_path / "Bu2019nsbh.npz"))
+    again = SVDLightCurveModel("Bu2019nsbh_tf", svd_path=str(svd_path), interpolation_type="tensorflow")      # now from the flat file
+    assert all(np.array_equal(again.svd_mag_model[f]["W2"], model.svd_mag_model[f]["W2"]) for f in model.svd_mag_model)
+    assert all(again.svd_mag_model[f]["VA"].shape == (nt, nc) for f in again.svd_mag_model)
+    # a missing network is an error, not a silent zero
+    os.remove(str(svd_path / "Bu2019nsbh.npz"))
+    os.remove(str(svd_path / "Bu2019nsbh_tf" / "ps1__y.h5"))
+    with pytest.raises(FileNotFoundError):
+        SVDLightCurveModel("Bu2019nsbh_tf", svd_path=str(svd_path), interpolation_type="tensorflow")
