@@ -32,9 +32,11 @@ class _Dataset:
 class File:
     """``File(path)`` -> ``.datasets``: ``{"group/sub/name": numpy array}`` for every dataset reachable from the root group."""
 
-    def __init__(self, path):
-        with open(path, "rb") as fh:
-            self.buf = fh.read()
+    def __init__(self, path=None, data=None):
+        if data is None:
+            with open(path, "rb") as fh:
+                data = fh.read()
+        self.buf = bytes(data)
         b = self.buf
         base = b.find(_SIG)
         if base != 0:
@@ -188,5 +190,6 @@ class File:
         return np.frombuffer(raw, dtype=ds.dtype).reshape(ds.shape).copy()
 
 
-def read_datasets(path):
-    return File(path).datasets
+def read_datasets(path=None, data=None):
+    """Every dataset of the file at ``path`` (or of the file image ``data``) as ``{"group/.../name": array}``."""
+    return File(path, data).datasets

@@ -96,6 +96,68 @@ def _dense_weights_from_h5(path):
     return w1, b1, w2, b2
 
 
+def _dense_pair(datasets, where):
+    """The two Dense layers among ``datasets`` (name -> array): groups that hold exactly one 2-D kernel and one 1-D bias of matching
+    width, ordered by shape chaining."""
+    groups = {}
+    for name, arr in datasets.items():
+        parent = name.rsplit("/", 1)[0] if "/" in name else ""
+        groups.setdefault(parent, []).append(np.asarray(arr))
+    dense = []
+    for members in groups.values():
+        if len(members) != 2:
+            continue
+        k = next((a for a in members if a.ndim == 2), None)
+        b = next((a for a in members if a.ndim == 1), None)
+        if k is not None and b is not None and b.shape[0] == k.shape[1]:
+            dense.append((k, b))
+    if len(dense) != 2:
+        raise ValueError(f"{where}: expected two Dense layers, found {len(dense)}")
+    if dense[0][0].shape[1] != dense[1][0].shape[0]:
+        dense.reverse()
+    (w1, b1), (w2, b2) = dense
+    if w1.shape[1] != w2.shape[0]:
+        raise ValueError(f"{where}: layer shapes do not chain: {w1.shape}, {w2.shape}")
+    return w1, b1, w2, b2
+
+
+def _dense_weights_from_keras_archive(path):
+    """(W1, b1, W2, b2) of a ``.keras`` archive (Keras 3: a zip holding ``config.json`` and ``model.weights.h5``; what
+    nmma/em/training.py saves today and nmma/em/model.py:635-643 loads first).  With keras importable the model is loaded as the
+    reference does; without it the weights file inside the archive is read directly (h5py or the built-in HDF5 reader) and the two
+    Dense layers are picked by their shapes.  The archive layout (``layers/<name>/vars/{0,1}``) is from Keras' public sources, NOT
+    pinned here -- keras is absent from the build image and the reference tree holds no ``.keras`` file."""
+    try:
+        import keras
+        if not hasattr(getattr(keras, "saving", None), "load_model") or not isinstance(getattr(keras, "Model", None), type):
+            raise ImportError("keras is not the real package")
+        net = keras.saving.load_model(path, compile=False)
+        dense = [l for l in net.layers if l.get_weights()]
+        (w1, b1), (w2, b2) = (l.get_weights() for l in dense)
+        return w1, b1, w2, b2
+    except ImportError:
+        pass
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        inner = next((n for n in z.namelist() if n.endswith("model.weights.h5")), None)
+        if inner is None:
+            raise ValueError(f"{path}: no model.weights.h5 in the archive")
+        raw = z.read(inner)
+    try:
+        import h5py
+        if not isinstance(getattr(h5py, "File", None), type):
+            raise ImportError
+        import io as _io
+        data = {}
+        with h5py.File(_io.BytesIO(raw), "r") as f:
+            f.visititems(lambda name, obj: data.__setitem__(name, np.array(obj)) if isinstance(obj, h5py.Dataset) else None)
+    except ImportError:
+        from . import hdf5_lite
+        data = hdf5_lite.read_datasets(data=raw)
+    data = {k: v for k, v in data.items() if not k.startswith("optimizer")}
+    return _dense_pair(data, path)
+
+
 def convert_reference_model(svd_path, model, out_path, filters=None, interpolation_type="tensorflow"):
     """Read the reference's model files and write the flat tensor file."""
     import joblib
@@ -107,10 +169,7 @@ def convert_reference_model(svd_path, model, out_path, filters=None, interpolati
     for filt in (filters or list(meta)):
         base = os.path.join(svd_path, f"{model}{spec}", filt.replace(":", "_"))
         if os.path.isfile(base + ".keras"):
-            import keras
-            net = keras.saving.load_model(base + ".keras", compile=False)
-            dense = [l for l in net.layers if l.get_weights()]
-            (w1, b1), (w2, b2) = (l.get_weights() for l in dense)
+            w1, b1, w2, b2 = _dense_weights_from_keras_archive(base + ".keras")
         elif os.path.isfile(base + ".h5"):
             w1, b1, w2, b2 = _dense_weights_from_h5(base + ".h5")
         else:

@@ -85,3 +85,34 @@ def test_reference_layout_joblib_plus_h5_end_to_end(tmp_path):
     os.remove(str(svd_path / "Bu2019nsbh_tf" / "ps1__y.h5"))
     with pytest.raises(FileNotFoundError):
         SVDLightCurveModel("Bu2019nsbh_tf", svd_path=str(svd_path), interpolation_type="tensorflow")
+
+
+def test_keras_archive_branch_runs_without_keras(tmp_path):
+    """``{filter}.keras`` (what the reference saves today and loads FIRST, model.py:635-643): the archive's ``model.weights.h5`` is read
+    directly and the two Dense layers are picked by their shapes.  The fixture's layout is restated from Keras' public sources
+    (tools/make_keras3_fixture.py) -- this test runs the branch, it does not pin Keras' format."""
+    import joblib
+    import shutil
+    from nmma_amd.em.model import SVDLightCurveModel
+    arch = os.path.join(HERE, "golden", "keras3_layout", "ztfr.keras")
+    w = _weights()
+    for got, key in zip(em_io._dense_weights_from_keras_archive(arch), ("W1", "b1", "W2", "b2")):
+        assert np.array_equal(got, w[key]), key
+    rng = np.random.default_rng(4)
+    nt = 30
+    q, _ = np.linalg.qr(rng.standard_normal((nt, nt)))
+    meta = {"ztfr": dict(param_mins=np.zeros(3), param_maxs=np.ones(3), mins=-18.0 + rng.random(nt), maxs=-8.0 + rng.random(nt),
+                         tt=np.linspace(0.0, 20.0, nt), n_coeff=10, VA=q)}
+    root = tmp_path / "m"
+    (root / "Bu2019nsbh").mkdir(parents=True)
+    joblib.dump(meta, str(root / "Bu2019nsbh.joblib"))
+    shutil.copy(arch, str(root / "Bu2019nsbh" / "ztfr.keras"))
+    shutil.copy(H5, str(root / "Bu2019nsbh" / "ztfr.h5"))          # (present too: the .keras file wins, as in the reference)
+    model = SVDLightCurveModel("Bu2019nsbh", svd_path=str(root), interpolation_type="keras")
+    assert np.array_equal(model.svd_mag_model["ztfr"]["W1"], w["W1"]) and np.array_equal(model.svd_mag_model["ztfr"]["b2"], w["b2"])
+    bad = tmp_path / "bad.keras"
+    import zipfile
+    with zipfile.ZipFile(str(bad), "w") as z:
+        z.writestr("config.json", "{}")
+    with pytest.raises(ValueError):
+        em_io._dense_weights_from_keras_archive(str(bad))
