@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "em_device.h"
+#include "stack2_tab.h"
 #include "walk_device.h"
 #include "em_math.h"
 #include "nmma_common.h"
@@ -2601,10 +2602,43 @@ __device__ __forceinline__ double wave_sum(double v) {
 // The curve sets of one stacking call, passed by value (no device-side pointer table).
 struct LcSets { const double* p[8]; };       // the curve sets of one stacking call, passed by value (no device-side pointer table)
 
+// The two-model table into LDS (STACK2_LDS_BYTES at tab_lds); the caller synchronises the workgroup before lc_stack_node reads it.
+__device__ __forceinline__ void stack2_stage(double* tab_lds, const int tid, const int n_threads) {
+    for (int j = tid; j < STACK2_NINT * STACK2_ROW; j += n_threads) tab_lds[j] = kStack2Tab[j];
+}
+
 // One node: vv[k] = model k's value at node g (already loaded).
 template <int KM>
-__device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv) {
+__device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv,
+                                                const double* tab2 = nullptr) {
     const int NS = P.NS;
+    if constexpr (KM == 2) {
+        // Two models (kilonova + afterglow, the reference's combined models), both finite at this node -- all but a few nodes:
+        // mag = min(m0, m1) - g(|m0 - m1|), g(D) = 2.5 log10(1 + 10^(-0.4 D)) from a table of degree-10 polynomials on 64 intervals of
+        // [0, 40) mag (stack2_tab.h, tools/gen_softplus_table.py: 1.7e-15 mag from the direct formula; beyond 40 mag g < 3e-16).
+        // tab2: the table staged in LDS by the caller (stack2_stage) -- every lane reads its own row, six 16-byte reads; from global
+        // memory those gathers cost as much as the exp and the log in fp64 they replace (~150 vector instructions a node).
+        if (n_models == 2 && tab2 != nullptr) {
+            const double v0 = vv[0], v1 = vv[1];
+            if ((v0 - v0 == 0.0) && (v1 - v1 == 0.0)) {
+                const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
+                if (D >= STACK2_DMAX) return lo;
+                const double sc = D * STACK2_INV_H;
+                int idx = (int)sc;
+                idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
+                const double t = 2.0 * (sc - (double)idx) - 1.0;
+                const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
+                const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
+                double p = fma(c0.x, t, c0.y);
+                p = fma(p, t, c1.x); p = fma(p, t, c1.y);
+                p = fma(p, t, c2.x); p = fma(p, t, c2.y);
+                p = fma(p, t, c3.x); p = fma(p, t, c3.y);
+                p = fma(p, t, c4.x); p = fma(p, t, c4.y);
+                p = fma(p, t, c5.x);
+                return lo - p;
+            }
+        }
+    }
     const double ln10 = 2.302585092994046;
     double amax = -HUGE_VAL, terms[KM];
     bool any_nan = false;
@@ -2716,6 +2750,16 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     // (SA -- the sample's curves staged in LDS -- is a compile-time switch like SD: `cur` below is then an LDS pointer to the compiler
     //  and a node costs a ds_read; as a run-time choice between LDS and global memory it was a flat load, several times the latency,
     //  on the serial bracket / finite-node walks of every datum)
+    // (two sets: the flux-sum table of lc_stack_node, complete before any curve is stacked.  It is only read while the curves are
+    //  staged, so it borrows the LDS of the staged photometry, which is filled afterwards -- a table of its own behind the slabs took
+    //  the fourth workgroup per CU away at config 3's shape; behind the last sample's slab when the photometry region is too small)
+    const bool tab_in_pho = SD && shared_bytes - grid_bytes >= STACK2_LDS_BYTES;
+    double* tab2 = tab_in_pho ? pho : reinterpret_cast<double*>(smem + shared_bytes + (size_t)(4 * SPW) * lds_per_sample);
+    if constexpr (SA && NM == 2) {
+        stack2_stage(tab2, threadIdx.x, 256);
+        __syncthreads();
+    }
+    (void)tab2; (void)tab_in_pho;
     if constexpr (SA) {                                // every load of the sample's curves in flight before anything waits
         const long g_base = b * M * NS;
         if constexpr (NM == 1) {
@@ -2736,12 +2780,15 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
                     const int j = j0 + i * G;
-                    if (j < M * NS) curves[j] = lc_stack_node<KM>(P, sets, n_models, g_base + j, v[i]);
+                    if (j < M * NS) curves[j] = lc_stack_node<KM>(P, sets, n_models, g_base + j, v[i], NM == 2 ? tab2 : nullptr);
                 }
             }
         }
     }
     for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
+    if constexpr (SA && NM == 2) {
+        if (tab_in_pho) __syncthreads();               // every wave is done with the table before the photometry overwrites it
+    }
     if constexpr (SD) {
         for (int j = threadIdx.x; j < ND; j += 256) {
             pho[j] = P.dt[j]; pho[ND + j] = P.dm[j]; pho[2 * ND + j] = P.dsig[j]; pho[3 * ND + j] = P.dsigtot[j]; pho[4 * ND + j] = P.dlogsig[j];
