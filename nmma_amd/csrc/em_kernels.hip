@@ -2607,37 +2607,41 @@ __device__ __forceinline__ void stack2_stage(double* tab_lds, const int tid, con
     for (int j = tid; j < STACK2_NINT * STACK2_ROW; j += n_threads) tab_lds[j] = kStack2Tab[j];
 }
 
+// Two models (kilonova + afterglow, the reference's combined models), both finite at this node -- all but a few nodes:
+// mag = min(m0, m1) - g(|m0 - m1|), g(D) = 2.5 log10(1 + 10^(-0.4 D)) from a table of degree-10 polynomials on 64 intervals of
+// [0, 40) mag (stack2_tab.h, tools/gen_softplus_table.py: 1.7e-15 mag from the direct formula; beyond 40 mag g < 3e-16).
+// tab2: the table staged in LDS by the caller (stack2_stage) -- every lane reads its own row, six 16-byte reads; from global
+// memory those gathers cost as much as the exp and the log in fp64 they replace (~150 vector instructions a node).
+// false: a non-finite value -- the node takes lc_stack_node's general path (gap filling).
+__device__ __forceinline__ bool stack2_fast(const double v0, const double v1, const double* tab2, double& r) {
+    if (!((v0 - v0 == 0.0) && (v1 - v1 == 0.0))) return false;
+    const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
+    r = lo;
+    if (D >= STACK2_DMAX) return true;
+    const double sc = D * STACK2_INV_H;
+    int idx = (int)sc;
+    idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
+    const double t = 2.0 * (sc - (double)idx) - 1.0;
+    const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
+    const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
+    double p = fma(c0.x, t, c0.y);
+    p = fma(p, t, c1.x); p = fma(p, t, c1.y);
+    p = fma(p, t, c2.x); p = fma(p, t, c2.y);
+    p = fma(p, t, c3.x); p = fma(p, t, c3.y);
+    p = fma(p, t, c4.x); p = fma(p, t, c4.y);
+    p = fma(p, t, c5.x);
+    r = lo - p;
+    return true;
+}
+
 // One node: vv[k] = model k's value at node g (already loaded).
 template <int KM>
 __device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv,
                                                 const double* tab2 = nullptr) {
     const int NS = P.NS;
     if constexpr (KM == 2) {
-        // Two models (kilonova + afterglow, the reference's combined models), both finite at this node -- all but a few nodes:
-        // mag = min(m0, m1) - g(|m0 - m1|), g(D) = 2.5 log10(1 + 10^(-0.4 D)) from a table of degree-10 polynomials on 64 intervals of
-        // [0, 40) mag (stack2_tab.h, tools/gen_softplus_table.py: 1.7e-15 mag from the direct formula; beyond 40 mag g < 3e-16).
-        // tab2: the table staged in LDS by the caller (stack2_stage) -- every lane reads its own row, six 16-byte reads; from global
-        // memory those gathers cost as much as the exp and the log in fp64 they replace (~150 vector instructions a node).
-        if (n_models == 2 && tab2 != nullptr) {
-            const double v0 = vv[0], v1 = vv[1];
-            if ((v0 - v0 == 0.0) && (v1 - v1 == 0.0)) {
-                const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
-                if (D >= STACK2_DMAX) return lo;
-                const double sc = D * STACK2_INV_H;
-                int idx = (int)sc;
-                idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
-                const double t = 2.0 * (sc - (double)idx) - 1.0;
-                const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
-                const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
-                double p = fma(c0.x, t, c0.y);
-                p = fma(p, t, c1.x); p = fma(p, t, c1.y);
-                p = fma(p, t, c2.x); p = fma(p, t, c2.y);
-                p = fma(p, t, c3.x); p = fma(p, t, c3.y);
-                p = fma(p, t, c4.x); p = fma(p, t, c4.y);
-                p = fma(p, t, c5.x);
-                return lo - p;
-            }
-        }
+        double r;
+        if (n_models == 2 && tab2 != nullptr && stack2_fast(vv[0], vv[1], tab2, r)) return r;
     }
     const double ln10 = 2.302585092994046;
     double amax = -HUGE_VAL, terms[KM];
@@ -2697,7 +2701,7 @@ __device__ __forceinline__ double group_total(double v) {
 }
 
 template <int G, int NM, bool SD, bool SA>
-__global__ __launch_bounds__(256) void em_lc_loglike(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
     const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
@@ -2740,7 +2744,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     double* praw = estacc + P.lc_nf_max;
     double* scal = praw + 8;
     double* curves = scal + 8;
-    (void)estacc;
+    (void)estacc; (void)app;
     const double* row = theta + b * ld;
     auto group_count = [&](const bool pred) -> int {   // lanes of THIS sample's group with pred (a ballot: no cross-lane fp64 reduction)
         unsigned long long m = __ballot(pred);
@@ -2753,6 +2757,63 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     // (two sets: the flux-sum table of lc_stack_node, complete before any curve is stacked.  It is only read while the curves are
     //  staged, so it borrows the LDS of the staged photometry, which is filled afterwards -- a table of its own behind the slabs took
     //  the fourth workgroup per CU away at config 3's shape; behind the last sample's slab when the photometry region is too small)
+    // (the cosmology grid is read by one wave only -- the block's scalar chains below -- which stages it itself: no block barrier between)
+    // Which wave: the workgroups that share a CU should pick different ones (wave i sits on SIMD i, and the SIMD's issue slots are
+    // what the chains cost).  Workgroups go round-robin over the 8 XCDs; k = blockIdx / 8 counts within the XCD, and whether the
+    // XCD's 32 CUs are then filled round-robin (k, k + 32, ... share a CU) or one after the other (4c .. 4c + 3), (k + k / 32) & 3
+    // differs among the workgroups of a CU.
+    const int kx = blockIdx.x >> 3;
+    const int pro_wave = (kx + (kx >> 5)) & 3;
+    // That wave first copies what its chains read from memory into LDS -- the cosmology grid, the theta rows of the block's samples
+    // (into each sample's own slab) -- so that the chains themselves wait for LDS and scalar loads only and run WHILE the curve loads
+    // issued before them are in flight: all the workgroups of a launch of 8192 rows are resident at once and move in phase, so the
+    // chip was either loading curves (HBM-bound) or running the chains (latency-bound), never both.
+    constexpr int SPB = 4 * SPW;
+    const bool th_lds = NS + P.lc_nf_max >= P.D;
+    unsigned char bad_s = 0;
+    if (wave == pro_wave) {
+        if (cosmo_lds)
+            for (int j = lane; j < P.n_cosmo; j += 64) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
+        if (th_lds)
+            for (int idx = lane; idx < SPB * P.D; idx += 64) {
+                const int sx = idx / P.D, c = idx - sx * P.D;
+                const long bx = (long)blockIdx.x * SPB + sx;
+                reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample)[c] = theta[(bx < B ? bx : B - 1) * ld + c];
+            }
+        if (lane < SPB && bad_rows != nullptr) {
+            const long bx = (long)blockIdx.x * SPB + lane;
+            bad_s = bad_rows[bx < B ? bx : B - 1];
+        }
+    }
+    // The per-sample scalar chains (sample_scalars: conversions, z(d_L), distance modulus -- several hundred dependent instructions
+    // with ONE useful lane per sample) of ALL the block's samples run side by side on the first lanes of that one wave.
+    auto scalar_chains = [&]() {
+        if (wave != pro_wave) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the LDS copies above, by other lanes of this wave)
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= SPB) return;
+        const long bs_raw = (long)blockIdx.x * SPB + lane;
+        const long bs = bs_raw < B ? bs_raw : B - 1;
+        double* slab_s = reinterpret_cast<double*>(smem + shared_bytes + (size_t)lane * lds_per_sample);
+        double* praw_s = slab_s + NS + P.lc_nf_max;
+        double* scal_s = praw_s + 8;
+        auto chains = [&](const double* row_s) {
+#ifdef NMMA_DBG_LC_NOPRO      // (measurement builds: what the per-sample scalar chain costs)
+            scal_s[S_ZP1] = 1.0; scal_s[S_IZP1] = 1.0; scal_s[S_TS] = row_s[0] * 1e-30; scal_s[S_DMOD] = 0.0; scal_s[S_RC] = 0.0; scal_s[S_EBV] = 0.0; scal_s[S_BAD] = 0.0;
+#else
+            double chk;
+            if (cosmo_lds) sample_scalars(P, row_s, praw_s, scal_s, chk, dgl, zgl);
+            else sample_scalars(P, row_s, praw_s, scal_s, chk);
+            for (int o = 0; o < P.O; ++o)         // (sampled time nodes may be non-finite: autocomplete_data masks them)
+                if (P.sys_kind[o] != NMMA_SYS_NODES)
+                    for (int q = P.sys_off[o]; q < P.sys_off[o + 1]; ++q) chk += apply_slot(P.sys_slots[q], row_s);
+            scal_s[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
+            if (bad_s != 0) scal_s[S_BAD] = 1.0;
+#endif
+        };
+        if (th_lds) chains(slab_s);            // (two inlined copies: the row is an LDS pointer to the compiler in this one)
+        else chains(theta + bs * ld);
+    };
     const bool tab_in_pho = SD && shared_bytes - grid_bytes >= STACK2_LDS_BYTES;
     double* tab2 = tab_in_pho ? pho : reinterpret_cast<double*>(smem + shared_bytes + (size_t)(4 * SPW) * lds_per_sample);
     if constexpr (SA && NM == 2) {
@@ -2760,30 +2821,66 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         __syncthreads();
     }
     (void)tab2; (void)tab_in_pho;
-    if constexpr (SA) {                                // every load of the sample's curves in flight before anything waits
-        const long g_base = b * M * NS;
-        if constexpr (NM == 1) {
-            const double* src = lc + g_base;
-            for (int j = gl; j < M * NS; j += G) curves[j] = src[j];
+    if constexpr (SA) {
+        // ... and the other three waves meanwhile stage the curves of ALL the block's samples (stacking two sets on the way), every
+        // load of a trip issued before the first is used.  Work item n = sample * NNP + node, NNP = the nodes of a sample rounded up
+        // to whole waves; the three waves take items 192 apart.
+        if (wave == pro_wave) {
+            scalar_chains();
         } else {
+            const int NN = M * NS, NNP = (NN + 63) & ~63, n_items = SPB * NNP;
+            const float inv_nnp = 1.0f / (float)NNP;
+            const int sl = ((((wave - pro_wave) & 3) - 1) << 6) + lane;
             constexpr int KM = NM > 0 ? NM : 8;
             const int n_models = NM > 0 ? NM : n_sets;
-            constexpr int NPT = 4;                     // nodes per lane and trip: all their loads issued before the first is used
-            for (int j0 = gl; j0 < M * NS; j0 += NPT * G) {
+            constexpr int NPT = NM == 0 ? 2 : 8;       // items per lane and trip
+            const int curves_off = NS + P.lc_nf_max + 16;
+            for (int n0 = sl; n0 < n_items; n0 += NPT * 192) {
                 double v[NPT][KM];
+                unsigned slow = 0u;
+                (void)slow;
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
-                    const int j = j0 + i * G;
+                    const int n = n0 + i * 192;
+                    const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;      // (exact: n < 2^20)
+                    const long bx = (long)blockIdx.x * SPB + sx;
+                    const long g = (bx < B ? bx : B - 1) * NN + j;
+                    const bool ok = n < n_items && j < NN;
 #pragma unroll
-                    for (int k = 0; k < KM; ++k) v[i][k] = (k < n_models && j < M * NS) ? sets.p[k][g_base + j] : 0.0;
+                    for (int k = 0; k < KM; ++k) v[i][k] = (ok && k < n_models) ? sets.p[k][g] : 0.0;
                 }
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
-                    const int j = j0 + i * G;
-                    if (j < M * NS) curves[j] = lc_stack_node<KM>(P, sets, n_models, g_base + j, v[i], NM == 2 ? tab2 : nullptr);
+                    const int n = n0 + i * 192;
+                    const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;
+                    const long bx = (long)blockIdx.x * SPB + sx;
+                    const long g = (bx < B ? bx : B - 1) * NN + j;
+                    if (n < n_items && j < NN) {
+                        double* dst = reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample) + curves_off + j;
+                        if constexpr (NM == 1) *dst = v[i][0];
+                        else if constexpr (NM == 2) {
+                            double r;
+                            if (stack2_fast(v[i][0], v[i][1], tab2, r)) *dst = r;
+                            else slow |= 1u << i;
+                        } else *dst = lc_stack_node<KM>(P, sets, n_models, g, v[i]);
+                    }
+                }
+                if constexpr (NM == 2) {               // (the few nodes with a gap to fill: one copy of the general code, values re-read)
+#pragma nounroll
+                    for (int i = 0; (slow >> i) != 0u; ++i) {
+                        if (((slow >> i) & 1u) == 0u) continue;
+                        const int n = n0 + i * 192;
+                        const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;
+                        const long bx = (long)blockIdx.x * SPB + sx;
+                        const long g = (bx < B ? bx : B - 1) * NN + j;
+                        const double vv[2] = {sets.p[0][g], sets.p[1][g]};
+                        reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample)[curves_off + j] = lc_stack_node<2>(P, sets, 2, g, vv, tab2);
+                    }
                 }
             }
         }
+    } else {
+        scalar_chains();
     }
     for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
     if constexpr (SA && NM == 2) {
@@ -2797,19 +2894,7 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         const int* src = reinterpret_cast<const int*>(P.item_desc);
         for (int j = threadIdx.x; j < P.n_items * ITEM_WORDS; j += 256) itl[j] = src[j];
     }
-    if (cosmo_lds)
-        for (int j = threadIdx.x; j < P.n_cosmo; j += 256) { dgl[j] = P.dist_grid[j]; zgl[j] = P.z_grid[j]; }
     __syncthreads();
-    if (gl == 0) {
-        double chk;
-        if (cosmo_lds) sample_scalars(P, row, praw, scal, chk, dgl, zgl);
-        else sample_scalars(P, row, praw, scal, chk);
-        for (int o = 0; o < P.O; ++o)         // (sampled time nodes may be non-finite: autocomplete_data masks them)
-            if (P.sys_kind[o] != NMMA_SYS_NODES)
-                for (int q = P.sys_off[o]; q < P.sys_off[o + 1]; ++q) chk += apply_slot(P.sys_slots[q], row);
-        scal[S_BAD] = (chk - chk == 0.0) ? 0.0 : 1.0;
-        if (bad_rows != nullptr && bad_rows[b] != 0) scal[S_BAD] = 1.0;
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double zp1 = scal[S_ZP1], tsh = scal[S_TS], dmod = scal[S_DMOD], rc = scal[S_RC], ebv = scal[S_EBV];
@@ -2818,7 +2903,11 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
     const double st0 = P.st0, st_inv_dt = P.st_inv_dt, izp1 = scal[S_IZP1];
 
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
+#ifdef NMMA_DBG_LC_NOSANITY
+    for (int m = 0; m < 0; ++m) {
+#else
     for (int m = 0; m < M; ++m) {
+#endif
         const double* cur = SA ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
         int nfin = 0;                                  // (a ballot per G nodes: no cross-lane fp64 reduction for a count)
         for (int j0 = 0; j0 < NS; j0 += G) {
@@ -2923,7 +3012,14 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
         constexpr bool FASTLANE = SD && SA;
         const bool fast_cfg = FASTLANE && !P.has_ebv && NS >= 2;
         const double t_first = stl[0] * zp1 + tsh, t_last = stl[NS - 1] * zp1 + tsh;
+        int* glist = reinterpret_cast<int*>(app);      // (the sample's first NS + lc_nf_max doubles of LDS: not used otherwise)
+        const int gcap = 2 * (NS + P.lc_nf_max);
+        int n_gen = 0;
+#ifdef NMMA_DBG_LC_NODATA
+        for (int d0 = 0; d0 < (ND > 100000 ? ND : 0); d0 += G) {
+#else
         for (int d0 = 0; d0 < ND; d0 += G) {
+#endif
             const int di = d0 + gl;
             bool general = di < ND;
             if (fast_cfg && general) {
@@ -2957,7 +3053,30 @@ __global__ __launch_bounds__(256) void em_lc_loglike(
                     }
                 }
             }
-            if (general) datum_term(di, d_item_p[di], chi, gp);
+            if (!fast_cfg) {
+                if (general) datum_term(di, d_item_p[di], chi, gp);
+                continue;
+            }
+            // The data the fast lane turned away (upper limits, epochs outside the window, non-finite nodes: a few per sample) are
+            // queued in the sample's LDS and take the general term densely packed after the loop: called here, one such lane made
+            // its whole wave walk the general term in every pass (4 of the 37 us at config 3's shape).
+            unsigned long long gm = __ballot(general);
+            if constexpr (G < 64) gm = (gm >> (grp * G)) & ((1ull << G) - 1ull);
+            const int slot = n_gen + __popcll(gm & ((1ull << gl) - 1ull));
+            if (general) {
+                if (slot < gcap) glist[slot] = di;
+                else datum_term(di, d_item_p[di], chi, gp);          // (queue full: in place)
+            }
+            n_gen += __popcll(gm);
+            n_gen = n_gen > gcap ? gcap : n_gen;
+        }
+        if (fast_cfg) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#ifdef NMMA_DBG_LC_NOGENERAL
+            if (ND > 100000)
+#endif
+            for (int i = gl; i < n_gen; i += G) { const int di = glist[i]; datum_term(di, d_item_p[di], chi, gp); }
         }
         chi_tot = group_total<G>(chi);
         gp_tot = group_total<G>(gp);

@@ -206,3 +206,29 @@ def test_stack_matches_logsumexp_for_any_number_of_models():
             assert np.array_equal(np.isfinite(got), ok) and both_inf[~ok].all(), (n_models, B)
             assert np.max(np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))) < 1e-13, (n_models, B)
     eng.close()
+
+
+def test_two_model_stack_table_edges():
+    """The two-model flux sum comes from a table of polynomials on 64 intervals of |m0 - m1| in [0, 40) mag (csrc/stack2_tab.h): every
+    interval boundary and its neighbours, equal magnitudes, the end of the table and beyond, against logsumexp at 1e-14 mag."""
+    import torch
+    from scipy.special import logsumexp
+    from tests.helpers import engine_from_case
+    case = cases.CASES["c2_default"]()
+    eng = engine_from_case(case)
+    filters = case["model_filters"]
+    M = len(filters)
+    NS = len(case["sample_times"] if case.get("sample_times") is not None else case["svd"][filters[0]]["tt"])
+    edges = np.arange(0, 65) * 0.625
+    d = np.concatenate([edges, np.nextafter(edges, -1.0)[1:], np.nextafter(edges, 100.0), [1e-300, 1e-9, 39.9999, 40.0001, 55.0, 700.0, 1e6],
+                        np.random.default_rng(3).uniform(0.0, 41.0, 4000)])
+    n = M * NS
+    B = (len(d) + n - 1) // n
+    dd = np.resize(d, B * n).reshape(B, M, NS)
+    base = np.random.default_rng(4).uniform(-20.0, -10.0, (B, M, NS))
+    ln10 = np.log(10.0)
+    for a, b in ((base, base + dd), (base + dd, base)):
+        want = -2.5 * logsumexp([-0.4 * ln10 * a, -0.4 * ln10 * b], axis=0) / ln10
+        got = eng.stack([torch.as_tensor(a, device="cuda:0"), torch.as_tensor(b, device="cuda:0")]).cpu().numpy()
+        assert np.max(np.abs(got - want)) < 1e-14 * 20.0
+    eng.close()
