@@ -2903,20 +2903,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     const double st0 = P.st0, st_inv_dt = P.st_inv_dt, izp1 = scal[S_IZP1];
 
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
+    // (four filters per trip, their reads issued before the first ballot: filter by filter the loop was a chain of LDS round trips,
+    //  2 of the 35 us at config 3's shape)
 #ifdef NMMA_DBG_LC_NOSANITY
-    for (int m = 0; m < 0; ++m) {
+    for (int m0 = 0; m0 < 0; m0 += 4) {
 #else
-    for (int m = 0; m < M; ++m) {
+    for (int m0 = 0; m0 < M; m0 += 4) {
 #endif
-        const double* cur = SA ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
-        int nfin = 0;                                  // (a ballot per G nodes: no cross-lane fp64 reduction for a count)
+        int nfin[4] = {0, 0, 0, 0};                    // (a ballot per G nodes: no cross-lane fp64 reduction for a count)
         for (int j0 = 0; j0 < NS; j0 += G) {
             const int j = j0 + gl;
-            double v = HUGE_VAL;
-            if (j < NS) v = cur[j];
-            nfin += group_count(v - v == 0.0);
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + q;
+                const double* cur = SA ? curves + m * NS : lc + ((size_t)b * M + m) * NS;
+                v[q] = HUGE_VAL;
+                if (m < M && j < NS) v[q] = cur[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nfin[q] += group_count(v[q] - v[q] == 0.0);
         }
-        if (nfin < 2) bad = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (m0 + q < M && nfin[q] < 2) bad = true;
     }
 
     // One datum: interpolate every source curve of the datum's band at its epoch, average, likelihood term.
@@ -3058,8 +3068,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
                 continue;
             }
             // The data the fast lane turned away (upper limits, epochs outside the window, non-finite nodes: a few per sample) are
-            // queued in the sample's LDS and take the general term densely packed after the loop: called here, one such lane made
-            // its whole wave walk the general term in every pass (4 of the 37 us at config 3's shape).
+            // queued in the sample's LDS and take the general term densely packed after the loop: called in place, one such lane made
+            // its whole wave walk the general term in every trip.  (The loop is bound by the fp64 issue rate of the SIMD -- four
+            // waves x ~150 instructions a trip -- not by the latency of a trip: two data per lane and trip in a branch-free form, more
+            // instructions for shorter chains, took 38.7 instead of 35.1 us at config 3's shape.)
             unsigned long long gm = __ballot(general);
             if constexpr (G < 64) gm = (gm >> (grp * G)) & ((1ull << G) - 1ull);
             const int slot = n_gen + __popcll(gm & ((1ull << gl) - 1ull));
