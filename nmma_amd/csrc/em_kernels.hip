@@ -2700,6 +2700,12 @@ __device__ __forceinline__ double group_total(double v) {
     } else return group_sum(v, 16);      // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
 }
 
+#ifdef NMMA_DBG_LC_STAMPS      // measurement builds: cycle stamps of workgroup 300's four waves at the phase boundaries
+__device__ unsigned long long g_lc_stamps[4 * 16];
+#define LC_STAMP(i) do { if (blockIdx.x == 300 && lane == 0) g_lc_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LC_STAMP(i) do { } while (0)
+#endif
 template <int G, int NM, bool SD, bool SA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
@@ -2764,6 +2770,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     // differs among the workgroups of a CU.
     const int kx = blockIdx.x >> 3;
     const int pro_wave = (kx + (kx >> 5)) & 3;
+    LC_STAMP(0);
     // That wave first copies what its chains read from memory into LDS -- the cosmology grid, the theta rows of the block's samples
     // (into each sample's own slab) -- so that the chains themselves wait for LDS and scalar loads only and run WHILE the curve loads
     // issued before them are in flight: all the workgroups of a launch of 8192 rows are resident at once and move in phase, so the
@@ -2833,21 +2840,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             const int sl = ((((wave - pro_wave) & 3) - 1) << 6) + lane;
             constexpr int KM = NM > 0 ? NM : 8;
             const int n_models = NM > 0 ? NM : n_sets;
-            constexpr int NPT = NM == 0 ? 2 : 8;       // items per lane and trip
+            constexpr int NPT = NM == 0 ? 2 : 8;       // items per lane and trip (12 or 16 -- more bytes in flight -- measured slower: 38.4 against 35.4 us)
             const int curves_off = NS + P.lc_nf_max + 16;
+            const long blk_base = (long)blockIdx.x * SPB * NN;
+            const long left = B - (long)blockIdx.x * SPB;
+            const int n_own = left < SPB ? (int)left : SPB;            // samples of this block inside the batch (>= 1)
             for (int n0 = sl; n0 < n_items; n0 += NPT * 192) {
                 double v[NPT][KM];
                 unsigned slow = 0u;
                 (void)slow;
+                // (addresses as a uniform base per set -- the block's first sample -- plus a 32-bit offset: ONE register per item; as
+                //  64-bit addresses per item and set they took the registers the loads in flight need)
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
                     const int n = n0 + i * 192;
                     const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;      // (exact: n < 2^20)
-                    const long bx = (long)blockIdx.x * SPB + sx;
-                    const long g = (bx < B ? bx : B - 1) * NN + j;
+                    const int sxe = sx < n_own ? sx : n_own - 1;           // (a sample beyond the batch re-reads the last row)
+                    const unsigned off = (unsigned)(sxe * NN + j);
                     const bool ok = n < n_items && j < NN;
 #pragma unroll
-                    for (int k = 0; k < KM; ++k) v[i][k] = (ok && k < n_models) ? sets.p[k][g] : 0.0;
+                    for (int k = 0; k < KM; ++k) v[i][k] = (ok && k < n_models) ? (sets.p[k] + blk_base)[off] : 0.0;
                 }
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
@@ -2882,6 +2894,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     } else {
         scalar_chains();
     }
+    LC_STAMP(1);
     for (int j = threadIdx.x; j < NS; j += 256) stl[j] = P.st[j];
     if constexpr (SA && NM == 2) {
         if (tab_in_pho) __syncthreads();               // every wave is done with the table before the photometry overwrites it
@@ -2897,10 +2910,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double zp1 = scal[S_ZP1], tsh = scal[S_TS], dmod = scal[S_DMOD], rc = scal[S_RC], ebv = scal[S_EBV];
+    LC_STAMP(2);
+    const double zp1 = scal[S_ZP1], tsh = scal[S_TS], dmod = scal[S_DMOD], rc = scal[S_RC], ebv = scal[S_EBV], izp1 = scal[S_IZP1];
     bool bad = always_floor != 0 || scal[S_BAD] != 0.0;
     const bool st_uniform = P.st_uniform != 0;
-    const double st0 = P.st0, st_inv_dt = P.st_inv_dt, izp1 = scal[S_IZP1];
+    const double st0 = P.st0, st_inv_dt = P.st_inv_dt;
 
     // sanity_check over ALL model filters: fewer than 2 finite magnitudes -> all-inf -> floor
     // (four filters per trip, their reads issued before the first ballot: filter by filter the loop was a chain of LDS round trips,
@@ -2929,6 +2943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             if (m0 + q < M && nfin[q] < 2) bad = true;
     }
 
+    LC_STAMP(3);
     // One datum: interpolate every source curve of the datum's band at its epoch, average, likelihood term.
     // k0 = first work item of the band (its sources are consecutive items); the bracket depends on the epoch only.
     auto datum_term = [&](const int di, const int k0, double& chi, double& gp) {
@@ -3082,7 +3097,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             n_gen += __popcll(gm);
             n_gen = n_gen > gcap ? gcap : n_gen;
         }
+        LC_STAMP(4);
         if (fast_cfg) {
+            // (A queue of one datum per sample -- the single upper limit of config 3's data set -- still costs 5 of the 35 us: the
+            //  latency of one chain through the general term and log_ndtr.  Handing the queues of all the block's samples to ONE wave,
+            //  a lane per sample, did not change the time: it is that chain's latency, not the SIMDs' issue slots.)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #ifdef NMMA_DBG_LC_NOGENERAL
@@ -3090,6 +3109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
 #endif
             for (int i = gl; i < n_gen; i += G) { const int di = glist[i]; datum_term(di, d_item_p[di], chi, gp); }
         }
+        LC_STAMP(5);
         chi_tot = group_total<G>(chi);
         gp_tot = group_total<G>(gp);
     } else {
@@ -3109,6 +3129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             }
         }
     }
+    LC_STAMP(6);
     if (gl == 0 && b_raw < B) {
         double tot = chi_tot + gp_tot;
         if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;      // (a NaN term of any band makes the total NaN)
