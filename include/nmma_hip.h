@@ -489,6 +489,7 @@ int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t
 
 /* Introspection used by bench.py / tests. */
 int32_t nmma_em_n_sample_times(const nmma_em_handle* h);
+int32_t nmma_em_device(const nmma_em_handle* h);            /* the HIP device the handle's tables live on (-1: null handle) */
 int64_t nmma_em_flops_per_eval(const nmma_em_handle* h);   /* SURVEY.md section 8d figure */
 int32_t nmma_em_last_launch_geometry(const nmma_em_handle* h, int32_t* grid_x, int32_t* grid_y,
                                      int32_t* block, int32_t* tile_samples, int32_t* lds_bytes);

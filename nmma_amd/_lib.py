@@ -191,6 +191,7 @@ PROTOTYPES = {
     "nmma_em_debug_timeline": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                            C.POINTER(C.c_int64)]),
     "nmma_em_n_sample_times": (C.c_int32, [C.c_void_p]),
+    "nmma_em_device": (C.c_int32, [C.c_void_p]),
     "nmma_em_flops_per_eval": (C.c_int64, [C.c_void_p]),
     "nmma_em_last_launch_geometry": (C.c_int32, [C.c_void_p] + [_pi] * 5),
     "nmma_em_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),

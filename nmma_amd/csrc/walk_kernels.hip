@@ -418,6 +418,7 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     if (n < 0 || NL < 3 || !q->live || !q->u0 || !q->loglstar || !q->key || !q->u || !q->v || !q->logl || !q->counts ||
         (!q->walks_per_chain && q->walks < 1))
         return fail("nmma_em_walk_queue: bad argument (at least three live points, walks >= 1)");
+    if (nmma_em_device(h) != ws->device) return fail("nmma_em_walk_queue: the workspace belongs to another device than the likelihood handle");
     if (q->constraints && (q->constraints->device != ws->device || q->constraints->n_cols > D))
         return fail("nmma_em_walk_queue: the constraint program belongs to another device or reads columns the walk does not sample");
     q->gpu_ms = 0.0;

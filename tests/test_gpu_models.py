@@ -92,6 +92,38 @@ def test_loglike_lc_reproduces_svd_path():
         eng.close()
 
 
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_likelihood_from_curves_on_every_golden_case(name):
+    """The generic tail (``em_lc_loglike``: every systematics kind, limits, averaged bands, extinction, masked nodes, unobserved model
+    filters, unequal grids) fed with the surrogate's own source-frame curves must give the reference's golden log L of EVERY SVD case,
+    for each of its three lane groupings."""
+    import os
+    import torch
+    from tests.helpers import engine_from_case
+    case = cases.CASES[name]()
+    gold = cases.load_golden(name)["logl"]
+    eng = engine_from_case(case)
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    lc = eng.model_lightcurves(th)
+    floor = gold == FLOOR
+    atol_rows = int(case.get("logl_atol_rows", 0))
+    for grp in (None, "16", "64"):
+        if grp is not None:
+            os.environ["NMMA_LC_GROUP"] = grp
+        try:
+            got = eng.loglike_lc(th, lc).cpu().numpy()
+        finally:
+            os.environ.pop("NMMA_LC_GROUP", None)
+        assert np.array_equal(got == FLOOR, floor), (name, grp)
+        err = rel_err(got[~floor], gold[~floor])
+        if atol_rows:            # (a documented near-cancelling row: absolute tolerance, see tests/cases.py)
+            worst = np.argsort(err)[::-1][:atol_rows]
+            assert np.all(np.abs(got[~floor][worst] - gold[~floor][worst]) <= case["logl_atol"]), (name, grp)
+            err = np.delete(err, worst)
+        assert err.size == 0 or err.max() <= 1e-6, (name, grp, err.max())
+    eng.close()
+
+
 def test_combined_union_grids_and_filter_fallbacks():
     """The general combination (model.py:1362-1374, :1434-1448, :1490-1503): sub-models with different sample_times
     and filter lists, an averaged band listed by one model only, a band only one model provides, an early failure."""
