@@ -45,7 +45,7 @@ eng1.close()
 
 # ---- config 3 shape: SVD curves + external curves -> stack -> likelihood from curves
 c3 = cases_combined.case_combined()
-B = 8192
+B = int(os.environ.get("NMMA_PERF_C3_ROWS", "8192"))        # (65536: eight resident rounds instead of one)
 _, th6 = syn.draw_theta(777, B, cases_combined.NAMES[:6])
 rng = np.random.default_rng(778)
 theta = np.concatenate([th6, rng.uniform(-17.5, -14.0, (B, 1)), rng.uniform(0.8, 1.6, (B, 1))], axis=1)
