@@ -2706,6 +2706,26 @@ __device__ unsigned long long g_lc_stamps[4 * 16];
 #else
 #define LC_STAMP(i) do { } while (0)
 #endif
+// A sample's sum in ONE order whatever the grouping: virtual lane v = (index of the term) mod 64 adds its terms in increasing
+// index order; a group of G lanes carries 64 / G virtual lanes per lane (a[q]: v = lane-in-group + G q); the 64 partial sums are
+// added as four DPP rows of 16, then (R0 + R1) + (R2 + R3).  16, 32 or 64 lanes per sample then give the same bits, so the grouping
+// can follow the batch size without a row's value depending on the size of its batch.
+template <int G>
+__device__ __forceinline__ double group_total_canon(const double (&a)[64 / G]) {
+    double R0, R1, R2, R3;
+    if constexpr (G == 16) {
+        R0 = group_sum(a[0], 16); R1 = group_sum(a[1], 16); R2 = group_sum(a[2], 16); R3 = group_sum(a[3], 16);
+    } else if constexpr (G == 32) {
+        const double s0 = group_sum(a[0], 16), s1 = group_sum(a[1], 16);
+        const int base = (int)(threadIdx.x & 32);
+        R0 = __shfl(s0, base, 64); R1 = __shfl(s0, base + 16, 64); R2 = __shfl(s1, base, 64); R3 = __shfl(s1, base + 16, 64);
+    } else {
+        const double s0 = group_sum(a[0], 16);
+        R0 = __shfl(s0, 0, 64); R1 = __shfl(s0, 16, 64); R2 = __shfl(s0, 32, 64); R3 = __shfl(s0, 48, 64);
+    }
+    return (R0 + R1) + (R2 + R3);
+}
+
 template <int G, int NM, bool SD, bool SA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
@@ -3026,7 +3046,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     if (chi_parts == nullptr) {
         // all photometry points of all bands in one pass over the lanes (a band with a dozen points would otherwise leave
         // most of the wave idle for a whole pass): d_item[di] = first work item of the datum's band
-        double chi = 0.0, gp = 0.0;
+        constexpr int NA = 64 / G;                     // virtual lanes per lane (group_total_canon)
+        double chi_a[NA], gp_a[NA];
+#pragma unroll
+        for (int q = 0; q < NA; ++q) { chi_a[q] = 0.0; gp_a[q] = 0.0; }
+        auto add_chi = [&](const int h, const double c) {            // (h: the trip's index mod NA -- uniform over the wave)
+            if constexpr (NA == 1) chi_a[0] += c;
+            else {
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (h == q) chi_a[q] += c;
+            }
+        };
+        auto add_gp = [&](const int h, const double g) {
+            if constexpr (NA == 1) gp_a[0] += g;
+            else {
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (h == q) gp_a[q] += g;
+            }
+        };
+        auto general_term = [&](const int h, const int di) {         // one datum through the general term, into virtual lane h
+            double c = 0.0, g = 0.0;
+            datum_term(di, d_item_p[di], c, g);
+            add_chi(h, c);
+            add_gp(h, g);
+        };
         // FAST LANE (compile-time staged data only).  The common datum -- a detection inside the model window whose band has one
         // source, a constant systematic, no finite limit, no extinction, and whose two bracket nodes are finite -- needs none of
         // the general term's machinery (source loop, finite-node walks, systematics kinds, truncation mass, upper limits: ~3 000
@@ -3046,6 +3091,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
         for (int d0 = 0; d0 < ND; d0 += G) {
 #endif
             const int di = d0 + gl;
+            const int h = (d0 / G) & (NA - 1);
             bool general = di < ND;
             if (fast_cfg && general) {
                 const ItemDesc& it0 = item_p[d_item_p[di]];
@@ -3072,14 +3118,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
                         const double est = (x0 == t) ? (y0 + dmod) + rc : lerp_np(t, x0, x1, (y0 + dmod) + rc, (y1 + dmod) + rc);
                         const double x = (dm_p[di] - est) / sig;
                         if (est < dinf() && x == x) {
-                            chi += ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - dlogsig_p[di];
+                            add_chi(h, ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - dlogsig_p[di]);
                             general = false;
                         }
                     }
                 }
             }
             if (!fast_cfg) {
-                if (general) datum_term(di, d_item_p[di], chi, gp);
+                if (general) general_term(h, di);
                 continue;
             }
             // The data the fast lane turned away (upper limits, epochs outside the window, non-finite nodes: a few per sample) are
@@ -3092,7 +3138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             const int slot = n_gen + __popcll(gm & ((1ull << gl) - 1ull));
             if (general) {
                 if (slot < gcap) glist[slot] = di;
-                else datum_term(di, d_item_p[di], chi, gp);          // (queue full: in place)
+                else general_term(h, di);                            // (queue full: in place)
             }
             n_gen += __popcll(gm);
             n_gen = n_gen > gcap ? gcap : n_gen;
@@ -3107,20 +3153,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
 #ifdef NMMA_DBG_LC_NOGENERAL
             if (ND > 100000)
 #endif
-            for (int i = gl; i < n_gen; i += G) { const int di = glist[i]; datum_term(di, d_item_p[di], chi, gp); }
+            for (int i0 = 0; i0 < n_gen; i0 += G)              // (the queue is in increasing datum order for every grouping)
+                if (i0 + gl < n_gen) general_term((i0 / G) & (NA - 1), glist[i0 + gl]);
         }
         LC_STAMP(5);
-        chi_tot = group_total<G>(chi);
-        gp_tot = group_total<G>(gp);
+        chi_tot = group_total_canon<G>(chi_a);
+        gp_tot = group_total_canon<G>(gp_a);
     } else {
         // per-filter parts requested: one pass per band
         for (int k = 0; k < P.n_items; ++k) {
             const ItemDesc& it = item_p[k];
             if (it.ks != 0) continue;
-            double chi = 0.0, gp = 0.0;
-            for (int dd = gl; dd < it.nf; dd += G) datum_term(it.d0 + dd, k, chi, gp);
-            chi = group_total<G>(chi);
-            gp = group_total<G>(gp);
+            constexpr int NA = 64 / G;
+            double chi_a[NA], gp_a[NA];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) { chi_a[q] = 0.0; gp_a[q] = 0.0; }
+            for (int d0 = 0; d0 < it.nf; d0 += G) {
+                double c = 0.0, g = 0.0;
+                if (d0 + gl < it.nf) datum_term(it.d0 + d0 + gl, k, c, g);
+                const int h = (d0 / G) & (NA - 1);
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (h == q) { chi_a[q] += c; gp_a[q] += g; }
+            }
+            const double chi = group_total_canon<G>(chi_a);
+            const double gp = group_total_canon<G>(gp_a);
             chi_tot += chi;
             gp_tot += gp;
             if (gl == 0 && b_raw < B) {

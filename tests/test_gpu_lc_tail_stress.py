@@ -121,7 +121,7 @@ def test_lc_tail_against_the_oracle(shape):
                 want[b] = lik.log_likelihood(p)
             th = torch.as_tensor(theta, device="cuda:0")
             dev_sets = [torch.as_tensor(s, device="cuda:0") for s in sets]
-            for grp in (None, "16", "64"):
+            for grp in (None, "16", "32"):
                 if grp is not None:
                     os.environ["NMMA_LC_GROUP"] = grp
                 try:
