@@ -89,14 +89,18 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     w = smp.EnsembleWalkSampler(ndim=len(names), periodic=[1], reflective=[2], walks=7)
     table = smp.device_prior_table(pri, names, w.periodic, w.reflective)
     rng = np.random.default_rng(71)
-    for n in (1, 37, 1000):
+    for n in (1, 37, 1000, 4096):
         n_live = 300
         live = rng.uniform(0.2, 0.8, (n_live, len(names)))
         u0 = live[rng.integers(0, n_live, n)].copy()
         bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.3))
         keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
         steps = 7 if n != 37 else (2 + np.arange(n) % 6).astype(np.int32)
-        fused = eng.walk_queue(table, live, u0, bound, keys, steps)
+        os.environ["NMMA_WALK_FUSE_SMALL"] = "1"        # (queues this small take two launches per step by default: the band split is faster)
+        try:
+            fused = eng.walk_queue(table, live, u0, bound, keys, steps)
+        finally:
+            del os.environ["NMMA_WALK_FUSE_SMALL"]
         os.environ["NMMA_WALK_NO_FUSE"] = "1"
         try:
             two = eng.walk_queue(table, live, u0, bound, keys, steps)
