@@ -2270,6 +2270,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
+        bool own_totals = !SPLITTABLE || nb <= 1;       // (wave-uniform)
         if (vt < TS && tile0 + vt < B) {
             const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
             if (!SPLITTABLE || nb <= 1) {
@@ -2293,7 +2294,34 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 }
             }
         }
-        if constexpr (WALKF) {
+        if (SPLITTABLE && nb > 1) {
+            // The group that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused
+            // epilogue above, bit for bit -- and re-arms the counter for the next launch.  (Counters: the 64 KiB in front of the
+            // workspace, zeroed when it is allocated.  Release / acquire at agent scope: the bands of a tile run on any XCD.)
+            unsigned* cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(gp_parts) - SPLIT_COUNTER_BYTES) + blockIdx.x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            unsigned prev = 0;
+            if (vt == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev == (unsigned)(nb - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (vt == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (vt < TS && tile0 + vt < B) {
+                    double c = 0.0, g = 0.0;
+                    const int nO = P.O;
+                    for (int y = 0; y < nO; ++y) {
+                        c += gp_parts[(long)y * B + tile0 + vt];
+                        g += gp_parts[((long)nO + y) * B + tile0 + vt];
+                    }
+                    double tot = c + g;
+                    if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
+                    out[tile0 + vt] = tot;
+                    if constexpr (WALKF) reinterpret_cast<double*>(smem + L.stage)[vt] = tot;
+                }
+                own_totals = true;       // (split launch: the group that added the bands owns the tile's MCMC step)
+            }
+        }
+        if (WALKF && own_totals) {
             // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch
             double* totl = reinterpret_cast<double*>(smem + L.stage);
             sync_wait(sync + 7 * W + 4, 1, P.watchdog, 900);          // (the first phase finished long ago)
@@ -2323,31 +2351,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 #else
             if (vt == 0) wf->counts[0] = wpre[0].cnt0 + (int)wpre[WNR - 1].gamma;      // (keep the first phase alive)
 #endif
-        }
-        if (SPLITTABLE && nb > 1) {
-            // The group that arrives LAST at its tile's counter adds the bands in band order -- the running sums of the fused
-            // epilogue above, bit for bit -- and re-arms the counter for the next launch.  (Counters: the 64 KiB in front of the
-            // workspace, zeroed when it is allocated.  Release / acquire at agent scope: the bands of a tile run on any XCD.)
-            unsigned* cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(gp_parts) - SPLIT_COUNTER_BYTES) + blockIdx.x;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            unsigned prev = 0;
-            if (vt == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            prev = __builtin_amdgcn_readfirstlane(prev);
-            if (prev == (unsigned)(nb - 1)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (vt == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (vt < TS && tile0 + vt < B) {
-                    double c = 0.0, g = 0.0;
-                    const int nO = P.O;
-                    for (int y = 0; y < nO; ++y) {
-                        c += gp_parts[(long)y * B + tile0 + vt];
-                        g += gp_parts[((long)nO + y) * B + tile0 + vt];
-                    }
-                    double tot = c + g;
-                    if (always_floor != 0 || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;
-                    out[tile0 + vt] = tot;
-                }
-            }
         }
     }
 }

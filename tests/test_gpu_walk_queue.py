@@ -96,11 +96,14 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
         bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.3))
         keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
         steps = 7 if n != 37 else (2 + np.arange(n) % 6).astype(np.int32)
-        os.environ["NMMA_WALK_FUSE_SMALL"] = "1"        # (queues this small take two launches per step by default: the band split is faster)
+        fused = eng.walk_queue(table, live, u0, bound, keys, steps)      # (small queues: the launch is split by band AND carries the step)
+        os.environ["NMMA_WALK_NO_SPLIT"] = "1"          # every workgroup walks all bands and steps its own tile
         try:
-            fused = eng.walk_queue(table, live, u0, bound, keys, steps)
+            unsplit = eng.walk_queue(table, live, u0, bound, keys, steps)
         finally:
-            del os.environ["NMMA_WALK_FUSE_SMALL"]
+            del os.environ["NMMA_WALK_NO_SPLIT"]
+        for a, b in zip(fused, unsplit):
+            assert _same(a, b), (name, n, "split / unsplit")
         os.environ["NMMA_WALK_NO_FUSE"] = "1"
         try:
             two = eng.walk_queue(table, live, u0, bound, keys, steps)
