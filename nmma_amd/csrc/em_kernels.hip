@@ -3088,76 +3088,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
         int* glist = reinterpret_cast<int*>(app);      // (the sample's first NS + lc_nf_max doubles of LDS: not used otherwise)
         const int gcap = 2 * (NS + P.lc_nf_max);
         int n_gen = 0;
+        // ONE loop, two passes, so that the general term (~3 000 instructions of code) is inlined ONCE: pass 0 walks the data (fast lane;
+        // what it turns away is queued, or -- queue full, or no fast lane for this configuration -- evaluated in place), pass 1 the
+        // queue.  (Three inlined copies -- in place, overflow, queue -- cost 1 us of instruction fetch at config 3's shape.)
+        const int cap_eff = fast_cfg ? gcap : 0;
 #ifdef NMMA_DBG_LC_NODATA
-        for (int d0 = 0; d0 < (ND > 100000 ? ND : 0); d0 += G) {
+        const int nd_eff = ND > 100000 ? ND : 0;
 #else
-        for (int d0 = 0; d0 < ND; d0 += G) {
+        const int nd_eff = ND;
 #endif
-            const int di = d0 + gl;
-            const int h = (d0 / G) & (NA - 1);
-            bool general = di < ND;
-            if (fast_cfg && general) {
-                const ItemDesc& it0 = item_p[d_item_p[di]];
-                const double t = dt_p[di], sig = dsigtot_p[di];
-                if (it0.nsrc == 1 && it0.kind == NMMA_SYS_CONST && it0.lim == dinf() && t >= t_first && t < t_last && sig > 0.0 && sig < dinf()) {
-                    int lo;
-                    if (st_uniform) {
-                        lo = (int)(((t - tsh) * izp1 - st0) * st_inv_dt);
-                        lo = lo < 0 ? 0 : (lo > NS - 2 ? NS - 2 : lo);
-                        while (lo > 0 && stl[lo] * zp1 + tsh > t) --lo;
-                        while (lo < NS - 2 && stl[lo + 1] * zp1 + tsh <= t) ++lo;
-                    } else {
-                        int hi = NS - 1;
-                        lo = 0;
-                        while (hi - lo > 1) {
-                            const int mid = (lo + hi) >> 1;
-                            if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                LC_STAMP(4);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the queue: written by other lanes of this wave)
+                __builtin_amdgcn_wave_barrier();
+#ifdef NMMA_DBG_LC_NOGENERAL
+                n_gen = 0;
+#endif
+            }
+            const int n_pass = pass == 0 ? nd_eff : n_gen;
+            for (int d0 = 0; d0 < n_pass; d0 += G) {
+                const int h = (d0 / G) & (NA - 1);
+                int di = d0 + gl;
+                bool general = di < n_pass;
+                if (pass == 1) {
+                    di = general ? glist[di] : 0;      // (the queue is in increasing datum order for every grouping)
+                } else if (fast_cfg && general) {
+                    const ItemDesc& it0 = item_p[d_item_p[di]];
+                    const double t = dt_p[di], sig = dsigtot_p[di];
+                    if (it0.nsrc == 1 && it0.kind == NMMA_SYS_CONST && it0.lim == dinf() && t >= t_first && t < t_last && sig > 0.0 && sig < dinf()) {
+                        int lo;
+                        if (st_uniform) {
+                            lo = (int)(((t - tsh) * izp1 - st0) * st_inv_dt);
+                            lo = lo < 0 ? 0 : (lo > NS - 2 ? NS - 2 : lo);
+                            while (lo > 0 && stl[lo] * zp1 + tsh > t) --lo;
+                            while (lo < NS - 2 && stl[lo + 1] * zp1 + tsh <= t) ++lo;
+                        } else {
+                            int hi = NS - 1;
+                            lo = 0;
+                            while (hi - lo > 1) {
+                                const int mid = (lo + hi) >> 1;
+                                if (stl[mid] * zp1 + tsh <= t) lo = mid; else hi = mid;
+                            }
                         }
-                    }
-                    const double* cur = curves + it0.m * NS;
-                    const double y0 = cur[lo], y1 = cur[lo + 1];
-                    if ((y0 - y0 == 0.0) && (y1 - y1 == 0.0)) {
-                        const double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
-                        const double est = (x0 == t) ? (y0 + dmod) + rc : lerp_np(t, x0, x1, (y0 + dmod) + rc, (y1 + dmod) + rc);
-                        const double x = (dm_p[di] - est) / sig;
-                        if (est < dinf() && x == x) {
-                            add_chi(h, ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - dlogsig_p[di]);
-                            general = false;
+                        const double* cur = curves + it0.m * NS;
+                        const double y0 = cur[lo], y1 = cur[lo + 1];
+                        if ((y0 - y0 == 0.0) && (y1 - y1 == 0.0)) {
+                            const double x0 = stl[lo] * zp1 + tsh, x1 = stl[lo + 1] * zp1 + tsh;
+                            const double est = (x0 == t) ? (y0 + dmod) + rc : lerp_np(t, x0, x1, (y0 + dmod) + rc, (y1 + dmod) + rc);
+                            const double x = (dm_p[di] - est) / sig;
+                            if (est < dinf() && x == x) {
+                                add_chi(h, ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - dlogsig_p[di]);
+                                general = false;
+                            }
                         }
                     }
                 }
+                // The data the fast lane turned away (upper limits, epochs outside the window, non-finite nodes: a few per sample) are
+                // queued in the sample's LDS and take the general term densely packed in pass 1: called in place, one such lane made
+                // its whole wave walk the general term in every trip.  (The fast lane is bound by the fp64 issue rate of the SIMD --
+                // four waves x ~150 instructions a trip -- not by the latency of a trip: two data per lane and trip in a branch-free
+                // form, more instructions for shorter chains, took 38.7 instead of 35.1 us at config 3's shape.  A queue of one datum
+                // per sample -- the single upper limit of config 3's data set -- costs 5 of the 35 us: the latency of one chain
+                // through the general term and log_ndtr; handing the queues of all the block's samples to ONE wave, a lane per sample,
+                // did not change the time.)
+                bool in_place = general;
+                if (pass == 0) {
+                    unsigned long long gm = __ballot(general);
+                    if constexpr (G < 64) gm = (gm >> (grp * G)) & ((1ull << G) - 1ull);
+                    const int slot = n_gen + __popcll(gm & ((1ull << gl) - 1ull));
+                    if (general && slot < cap_eff) { glist[slot] = di; in_place = false; }
+                    n_gen += __popcll(gm);
+                    n_gen = n_gen > cap_eff ? cap_eff : n_gen;
+                }
+                if (in_place) general_term(h, di);
             }
-            if (!fast_cfg) {
-                if (general) general_term(h, di);
-                continue;
-            }
-            // The data the fast lane turned away (upper limits, epochs outside the window, non-finite nodes: a few per sample) are
-            // queued in the sample's LDS and take the general term densely packed after the loop: called in place, one such lane made
-            // its whole wave walk the general term in every trip.  (The loop is bound by the fp64 issue rate of the SIMD -- four
-            // waves x ~150 instructions a trip -- not by the latency of a trip: two data per lane and trip in a branch-free form, more
-            // instructions for shorter chains, took 38.7 instead of 35.1 us at config 3's shape.)
-            unsigned long long gm = __ballot(general);
-            if constexpr (G < 64) gm = (gm >> (grp * G)) & ((1ull << G) - 1ull);
-            const int slot = n_gen + __popcll(gm & ((1ull << gl) - 1ull));
-            if (general) {
-                if (slot < gcap) glist[slot] = di;
-                else general_term(h, di);                            // (queue full: in place)
-            }
-            n_gen += __popcll(gm);
-            n_gen = n_gen > gcap ? gcap : n_gen;
-        }
-        LC_STAMP(4);
-        if (fast_cfg) {
-            // (A queue of one datum per sample -- the single upper limit of config 3's data set -- still costs 5 of the 35 us: the
-            //  latency of one chain through the general term and log_ndtr.  Handing the queues of all the block's samples to ONE wave,
-            //  a lane per sample, did not change the time: it is that chain's latency, not the SIMDs' issue slots.)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#ifdef NMMA_DBG_LC_NOGENERAL
-            if (ND > 100000)
-#endif
-            for (int i0 = 0; i0 < n_gen; i0 += G)              // (the queue is in increasing datum order for every grouping)
-                if (i0 + gl < n_gen) general_term((i0 / G) & (NA - 1), glist[i0 + gl]);
         }
         LC_STAMP(5);
         chi_tot = group_total_canon<G>(chi_a);
