@@ -68,7 +68,7 @@ def test_queue_call_is_bit_identical_to_the_step_loop(torch_cuda, config2):
         assert np.all(ql[moved] > bound[moved]) and _same(eng.loglike(np.ascontiguousarray(qv)), ql)
 
 
-@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid"])
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape"])
 def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     """The queue's one-launch MCMC step (accept + next proposal in the likelihood kernel's epilogue: ``nmma_em_loglike_walk``,
     ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (``NMMA_WALK_NO_FUSE=1``) and against the
