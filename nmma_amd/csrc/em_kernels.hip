@@ -327,6 +327,8 @@ __device__ __forceinline__ double exp_neg(const double x) {
 // (the ring depth NBUF is a launch parameter, LdsW::nbuf: what fits in LDS, at most 4)
 // prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
 constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
+// (the fused MCMC step parks [tot 16 | 5 x 2 rounds x 64 | 2 x 16 doubles | 6 x 16 ints | prior table] in the staging area of a 16-sample tile)
+static_assert((16 * STAGE_COLS + 2 * STAGE_COSMO) * 8 >= (16 + 5 * 2 * 64 + 2 * 16 + 3 * 16) * 8 + 8 * 40, "parked walk state");
 // fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
 constexpr int TMAP_MAX = 512;
 constexpr int DENSE_NBUF = 2, DENSE_STRIDE = 17;   // dense lean task: node-magnitude buffers of 16 samples, row stride in doubles (odd: bank spread)
@@ -654,7 +656,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
 // of the walk's step `wstep` and the proposal of the next one for the tile's chains (walk_device.h: the device functions of
 // walk_step_kernel, same arithmetic) and writes the tile's theta rows for the next launch.  Its own instantiations: the walk code
 // must not touch the register allocation of the tuned flavours.
-template <int R, int KP, int NMW, int NVW, int FASTM, bool WALKF = false>
+template <int R, int KP, int NMW, int NVW, int FASTM, int WALKF = 0>
 __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
@@ -697,8 +699,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
     const int W = P.n_items;
     gci32p items = as_global(P.items);
-    // (WALKF: the fused MCMC step keeps a group of 8 lanes per chain -- up to 8 sampled dimensions -- and 16-sample tiles)
-    constexpr int WNR = WALKF ? TS / 8 : 1;
+    // (WALKF = 8: the fused MCMC step keeps a group of that many lanes per chain -- one per sampled dimension -- and 16-sample tiles)
+    constexpr int WT = WALKF ? WALKF : 8;             // lanes per chain (8: up to 8 sampled dimensions; the parked state below is sized for it)
+    constexpr int WCR = 64 / WT;                      // chains per round of one wave
+    constexpr int WNR = WALKF ? TS / WCR : 1;
     // (staging area after the prologue: tot[TS] | parked walk state 5 x WNR x 64 + 2 TS doubles + 6 TS ints | prior table)
     nmma_walk_prior* wspl = reinterpret_cast<nmma_walk_prior*>(reinterpret_cast<double*>(smem + L.stage) + TS + 5 * WNR * 64 + 2 * TS + 3 * TS);
 
@@ -2147,29 +2151,34 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     for (int j = lane; j < wf->ndim * 10; j += 64) reinterpret_cast<uint32_t*>(wspl)[j] = src[j];
                 }
 #ifndef NMMA_DBG_WALK_NOPRE
-                WalkPre wq[WNR];
-                WalkPreKey wkey[WNR];
-                double wr[WNR][7];
+                constexpr int WPR = WNR < 2 ? WNR : 2;       // rounds in flight together
 #pragma unroll
-                for (int r = 0; r < WNR; ++r) {      // every round's state loads first ...
-                    const long c = tile0 + r * 8 + (lane >> 3);
-                    walk_step_pre_a(wf->ndim, c < B ? c : B - 1, lane & 7, wf->key, wf->u, wf->v, wf->prop, theta, wf->inside, wf->loglstar, wf->counts,
-                                    wf->n_steps, (uint64_t)wstep, wq[r], wkey[r]);
-                }
+                for (int r0 = 0; r0 < WNR; r0 += WPR) {
+                    WalkPre wq[WPR];
+                    WalkPreKey wkey[WPR];
+                    double wr[WPR][7];
 #pragma unroll
-                for (int r = 0; r < WNR; ++r)        // ... then the hashes and the live points they address ...
-                    walk_step_pre_b(wf->ndim, lane & 7, wf->live, (long)wf->n_live, wf->first_step + (uint64_t)wstep, wkey[r], wq[r], wr[r]);
+                    for (int rr = 0; rr < WPR; ++rr) {   // the pair's state loads first ...
+                        const long c = tile0 + (r0 + rr) * WCR + lane / WT;
+                        walk_step_pre_a(wf->ndim, c < B ? c : B - 1, lane & (WT - 1), wf->key, wf->u, wf->v, wf->prop, theta, wf->inside, wf->loglstar, wf->counts,
+                                        wf->n_steps, (uint64_t)wstep, wq[rr], wkey[rr]);
+                    }
 #pragma unroll
-                for (int r = 0; r < WNR; ++r) {      // ... then the move's scale; park everything
-                    walk_step_pre_c(wf->ndim, wr[r], wq[r]);
-                    const int e = r * 64 + lane;
-                    pl[e] = wq[r].lj - wq[r].li; pl[WNR * 64 + e] = wq[r].uu; pl[2 * WNR * 64 + e] = wq[r].vv; pl[3 * WNR * 64 + e] = wq[r].pp;
-                    pl[4 * WNR * 64 + e] = wq[r].th;
-                    if ((lane & 7) == 0) {
-                        const int cl = r * 8 + (lane >> 3);
-                        pcd[cl] = wq[r].gamma; pcd[TS + cl] = wq[r].lstar;
-                        pci[cl] = wq[r].in0; pci[TS + cl] = wq[r].active; pci[2 * TS + cl] = wq[r].cnt0; pci[3 * TS + cl] = wq[r].cnt1;
-                        pci[4 * TS + cl] = wq[r].cnt2; pci[5 * TS + cl] = wq[r].cnt3;
+                    for (int rr = 0; rr < WPR; ++rr)     // ... then the hashes and the live points they address ...
+                        walk_step_pre_b(wf->ndim, lane & (WT - 1), wf->live, (long)wf->n_live, wf->first_step + (uint64_t)wstep, wkey[rr], wq[rr], wr[rr]);
+#pragma unroll
+                    for (int rr = 0; rr < WPR; ++rr) {   // ... then the move's scale; park everything
+                        const int r = r0 + rr;
+                        walk_step_pre_c(wf->ndim, wr[rr], wq[rr]);
+                        const int e = r * 64 + lane;
+                        pl[e] = wq[rr].lj - wq[rr].li; pl[WNR * 64 + e] = wq[rr].uu; pl[2 * WNR * 64 + e] = wq[rr].vv; pl[3 * WNR * 64 + e] = wq[rr].pp;
+                        pl[4 * WNR * 64 + e] = wq[rr].th;
+                        if ((lane & (WT - 1)) == 0) {
+                            const int cl = r * WCR + lane / WT;
+                            pcd[cl] = wq[rr].gamma; pcd[TS + cl] = wq[rr].lstar;
+                            pci[cl] = wq[rr].in0; pci[TS + cl] = wq[rr].active; pci[2 * TS + cl] = wq[rr].cnt0; pci[3 * TS + cl] = wq[rr].cnt1;
+                            pci[4 * TS + cl] = wq[rr].cnt2; pci[5 * TS + cl] = wq[rr].cnt3;
+                        }
                     }
                 }
 #endif
@@ -2266,7 +2275,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
-    WalkPre wpre[WNR];
+    WalkPre wpre[WNR < 2 ? WNR : 2];
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
@@ -2325,31 +2334,35 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch
             double* totl = reinterpret_cast<double*>(smem + L.stage);
             sync_wait(sync + 7 * W + 4, 1, P.watchdog, 900);          // (the first phase finished long ago)
-            {
-                const double* pl = totl + TS;
-                const double* pcd = pl + 5 * WNR * 64;
-                const int* pci = reinterpret_cast<const int*>(pcd + 2 * TS);
+            const double* pl = totl + TS;
+            const double* pcd = pl + 5 * WNR * 64;
+            const int* pci = reinterpret_cast<const int*>(pcd + 2 * TS);
+            constexpr int WPR = WNR < 2 ? WNR : 2;           // (rounds handled together, as in the first phase)
 #pragma unroll
-                for (int r = 0; r < WNR; ++r) {
-                    const int e = r * 64 + vt, cl = r * 8 + (vt >> 3);
-                    WalkPre& w = wpre[r];
+            for (int r0 = 0; r0 < WNR; r0 += WPR) {
+#pragma unroll
+                for (int rr = 0; rr < WPR; ++rr) {
+                    const int r = r0 + rr;
+                    const int e = r * 64 + vt, cl = r * WCR + vt / WT;
+                    WalkPre& w = wpre[rr];
                     w.li = 0.0; w.lj = pl[e]; w.uu = pl[WNR * 64 + e]; w.vv = pl[2 * WNR * 64 + e]; w.pp = pl[3 * WNR * 64 + e]; w.th = pl[4 * WNR * 64 + e];
                     w.gamma = pcd[cl]; w.lstar = pcd[TS + cl];
                     w.in0 = pci[cl]; w.active = pci[TS + cl]; w.cnt0 = pci[2 * TS + cl]; w.cnt1 = pci[3 * TS + cl]; w.cnt2 = pci[4 * TS + cl];
                     w.cnt3 = pci[5 * TS + cl];
                 }
-            }
 #ifndef NMMA_DBG_WALK_NOPOST
 #pragma unroll
-            for (int r = 0; r < WNR; ++r) {
-                const int cl = r * 8 + (vt >> 3);
-                const long c = tile0 + cl;
-                if (c < B)
-                    walk_step_post<false>(wspl, wf->ndim, 8, c, vt & 7, totl[cl], wpre[r], wf->u, wf->v, wf->logl, wf->counts, wf->prop, const_cast<double*>(theta),
-                                   wf->inside, wf->con_ops, wf->n_con_ops, !wlast);
+                for (int rr = 0; rr < WPR; ++rr) {
+                    const int cl = (r0 + rr) * WCR + vt / WT;
+                    const long c = tile0 + cl;
+                    if (c < B)
+                        walk_step_post<false>(wspl, wf->ndim, WT, c, vt & (WT - 1), totl[cl], wpre[rr], wf->u, wf->v, wf->logl, wf->counts, wf->prop,
+                                              const_cast<double*>(theta), wf->inside, wf->con_ops, wf->n_con_ops, !wlast);
+                }
+#endif
             }
-#else
-            if (vt == 0) wf->counts[0] = wpre[0].cnt0 + (int)wpre[WNR - 1].gamma;      // (keep the first phase alive)
+#ifdef NMMA_DBG_WALK_NOPOST
+            if (vt == 0) wf->counts[0] = wpre[0].cnt0 + (int)wpre[0].gamma;      // (keep the first phase alive)
 #endif
         }
     }

@@ -68,7 +68,20 @@ def test_queue_call_is_bit_identical_to_the_step_loop(torch_cuda, config2):
         assert np.all(ql[moved] > bound[moved]) and _same(eng.loglike(np.ascontiguousarray(qv)), ql)
 
 
-@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape"])
+def _per_filter_syserr_case():
+    """One sampled systematic PER observed filter (a YAML systematics file without time nodes): 6 + 9 = 15 sampled dimensions on the
+    lean task with sampled systematics (FASTM 3)."""
+    from nmma_amd import synthetic as syn
+    from tests import cases
+    filters = syn.AT2017GFO_FILTERS
+    sys_names = [f"em_syserr_{k}" for k in range(len(filters))]
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"] + sys_names
+    c = cases._base(seed=5234, names=names, batch=48)
+    c["systematics"] = dict(mode="mixed", names=dict(zip(filters, sys_names)), nodes={})
+    return c
+
+
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape", "c4_syserr", "syserr_per_filter"])
 def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     """The queue's one-launch MCMC step (accept + next proposal in the likelihood kernel's epilogue: ``nmma_em_loglike_walk``,
     ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (``NMMA_WALK_NO_FUSE=1``) and against the
@@ -78,10 +91,10 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     from tests import cases
     from tests.helpers import engine_from_case
     torch = torch_cuda
-    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    case = _per_filter_syserr_case() if name == "syserr_per_filter" else (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
     eng = engine_from_case(case)
     names = case["names"]
-    assert len(names) <= 8
+    assert len(names) <= 16        # (more than 8 sampled dimensions: 16 lanes per chain in the fused step -- c4_syserr, syserr_per_filter)
     th = case["theta"]
     lo, hi = th.min(axis=0) - 1e-3, th.max(axis=0) + 1e-3
     pri = {k: UniformPrior(float(a), float(b)) for k, a, b in zip(names, lo, hi)}

@@ -13,7 +13,7 @@ from tests import cases  # noqa: E402
 from tests.helpers import UniformPrior, engine_from_case  # noqa: E402
 
 rng = np.random.default_rng(5)
-for name in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["c2_default", "c2_dt05_limit", "averaging", "log_grid", "syserr_param"]):
+for name in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["c2_default", "c2_dt05_limit", "averaging", "log_grid", "syserr_param", "c4_shape", "c4_syserr"]):
     case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
     eng = engine_from_case(case)
     names = case["names"]
