@@ -10,7 +10,7 @@ for n in "$@"; do
 import csv
 for r in csv.DictReader(open("$f")):
     n = r["Name"]
-    if "em_logl" in n and "true" in n:
+    if "em_logl" in n and n.split(">")[0].rstrip().endswith(", 8"):
         print("$n".ljust(10), n[:50], r["Calls"], "avg", r["AverageNs"], "min", r["MinNs"])
 PY
 done
