@@ -295,14 +295,23 @@ def main():
                                      "batch_per_gpu": other["B"], "global_batch": other["global_batch"],
                                      "exchange": exchange_label(other), "kernel_ms": o_ms}
         if not args.no_cpu_baseline and world == 1:      # (the profiled command lines pass --no-cpu-baseline: device launches only)
-            line["host_call_ms"] = host_call_ms(eng, case, syn)
-            ms = device_walk_step_ms(eng, case, syn)
-            line["device_walk"] = {"chains": 4096, "ms_per_mcmc_step": ms, "evals_per_s": 4096 / (ms * 1e-3),
-                                   "what": "lock-step ensemble walk on the device: likelihood -> accept + next proposal, two launches per step"}
-            line["device_walk_queue"] = device_walk_queue(case, syn, line["device_walk"]["evals_per_s"])
+            # (context blocks: a failure in one of them must not cost the contract line)
+            def context(key, fn):
+                try:
+                    line[key] = fn()
+                except Exception as exc:      # noqa: BLE001
+                    line[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            context("host_call_ms", lambda: host_call_ms(eng, case, syn))
+
+            def walk_block():
+                ms = device_walk_step_ms(eng, case, syn)
+                return {"chains": 4096, "ms_per_mcmc_step": ms, "evals_per_s": 4096 / (ms * 1e-3),
+                        "what": "lock-step ensemble walk on the device: likelihood -> accept + next proposal, two launches per step"}
+            context("device_walk", walk_block)
+            context("device_walk_queue", lambda: device_walk_queue(case, syn, line["device_walk"]["evals_per_s"]))
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
-            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_seconds)
+            context("cpu_baseline_all_cores", lambda: cpu_baseline_all_cores(args.cpu_seconds))
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None and dist.is_initialized():
