@@ -2700,22 +2700,18 @@ __device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& se
 }
 
 
-// G lanes per parameter vector: 64 (one wave per sample) or 16 -- FOUR samples per wave.  The kernel is bound by instruction
-// issue, not by HBM or occupancy: with a wave per sample the per-sample scalar chain (sample_scalars: one active
-// lane) and the last, partly filled pass over the photometry are paid per sample; with 16-lane groups four samples share them.
+// em_lc_loglike<G, NM, SD, SA>: the generic tail of the reference path from detector-frame curves on -- sanity_check, autocomplete_data's
+// dynamic finite mask, systematics, Gaussian / truncated / upper-limit terms, floor -- for curves another kernel produced or the caller
+// supplies (Me2017, combined models).  G lanes per parameter vector (64: a wave per sample; 32 / 16: two / four samples per wave), 256
+// threads per workgroup; a sample's terms are added in one order whatever G (group_total_canon).  One wave of the workgroup runs the
+// per-sample scalar chains while the other three stage all the workgroup's curves into LDS.  At 8192 rows every workgroup of the launch
+// is resident at once, so the kernel's time is a workgroup's chain of phases (HBM-bound staging, then latency and fp64 issue), not a
+// throughput: DESIGN 3.3, profiles/r04_config3_tail.md.
 // NM: how the sample's curves come about -- 1: set 0 as it is; 2 / 0: the flux sum of two / of n_sets (<= 8) sets, node by node
 // (stack_magnitudes, model.py:1486-1510, with its per-model gap filling: lc_stack_node) WHILE the curves are staged into LDS, so
 // that a combined model's stacked set is never written to memory and read back (72.5 MB -> 48.6 MB per call at config 3's shape,
-// one launch instead of two).  bad_rows (or NULL): rows whose sub-model delivered no light curve (floor).
-template <int G>
-__device__ __forceinline__ double group_total(double v) {
-    if constexpr (G == 64) return wave_sum(v);
-    else if constexpr (G == 32) {        // (the sum lands in the group's last row: lanes 16-31 / 48-63; hand it to the whole group)
-        v = group_sum(v, 32);
-        return __shfl(v, (int)((threadIdx.x & 32) | 31), 64);
-    } else return group_sum(v, 16);      // (a 16-lane group is one DPP row: after row_mirror every lane holds the row's sum)
-}
-
+// one launch instead of two).  SD / SA: photometry / curves staged in LDS (compile-time, so that the pointers are LDS pointers to
+// the compiler).  bad_rows (or NULL): rows whose sub-model delivered no light curve (floor).
 #ifdef NMMA_DBG_LC_STAMPS      // measurement builds: cycle stamps of workgroup 300's four waves at the phase boundaries
 __device__ unsigned long long g_lc_stamps[4 * 16];
 #define LC_STAMP(i) do { if (blockIdx.x == 300 && lane == 0) g_lc_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
