@@ -41,7 +41,12 @@ def kernel_table(lib):
     def flush():
         if cur in out:
             # (branch targets are printed as absolute offsets: drop them, they move with the position in the code object)
-            text = "\n".join(re.sub(r"^(s_c?branch\S*)\s+\S+", r"\1", re.sub(r"<[^>]*>", "", ln).split("//")[0].rstrip()) for ln in body)
+            # (and pc-relative literals -- s_getpc_b64 + s_add_u32 sN, sN, 0xffxxxxxx -- which move with the layout of the unit, and
+            #  the padding behind the last instruction: a kernel's code is the same whatever else its translation unit holds)
+            while body and body[-1].split()[0] in ("s_nop", "s_code_end"):
+                body.pop()
+            text = "\n".join(re.sub(r"^(s_add_u32 s\d+, s\d+,) 0xff[0-9a-f]{6}$", r"\1 <pcrel>",
+                                    re.sub(r"^(s_c?branch\S*)\s+\S+", r"\1", re.sub(r"<[^>]*>", "", ln).split("//")[0].rstrip())) for ln in body)
             out[cur]["insts"] = len(body)
             out[cur]["sha"] = hashlib.sha1(text.encode()).hexdigest()[:12]
     for line in dis.splitlines():
