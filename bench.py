@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=25, help="the K-step region is timed this many times; value = the median region")
     ap.add_argument("--clock-warmup-steps", type=int, default=1536,
                     help="untimed steps BEFORE the W warmup steps: the GPU's clocks need ~30 ms of continuous load (~900 launches) to settle")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="length of the `sustained` context leg (back-to-back steps on the same handle; 0 = skip)")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="live points per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,8 +139,10 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     import gc
 
-    def measure(scaling):
-        """W untimed + K timed steps of one scaling mode: (elapsed max over ranks, rows of this rank, global batch, pipelined, prof)."""
+    def measure(scaling, cold=False):
+        """W untimed + K timed steps of one scaling mode: (elapsed max over ranks, rows of this rank, global batch, pipelined, prof).
+        cold: FIRST time one contract-shaped region -- W warm-up steps, K timed steps, nothing before them -- as the process's first
+        load on the GPU (`value_cold`: what the driver's flags measure without the clock warm-up)."""
         if scaling == "strong":
             from nmma_amd.parallel import shard_bounds
             lo, hi = shard_bounds(args.batch, world, rank)
@@ -200,11 +204,33 @@ def main():
         # rocprofv3 trace in profiles/r04_bench_kernel_stats.csv); a sampler lives in the steady state, the driver's 20-step region
         # would not.
         done = 0                # steps issued so far (the pipelined form alternates its two buffers on this count)
+        cold_elapsed = None
+        if cold:
+            for _ in range(args.warmup):
+                step(done)
+                done += 1
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(done, done + args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+                torch.cuda.synchronize()
+            cold_elapsed = time.perf_counter() - t0
+            done += args.steps
+            if use_dist:
+                t = torch.tensor([cold_elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                cold_elapsed = float(t.item())
+        n_before_clock = done
         for _ in range(args.clock_warmup_steps):        # (a fixed count: every rank issues the same collectives)
             step(done)
             done += 1
         torch.cuda.synchronize()
-        n_clock = done
+        n_clock = done - n_before_clock
         for _ in range(args.warmup):
             step(done)
             done += 1
@@ -249,7 +275,7 @@ def main():
         last = (outs[(n_done - 1) & 1] if pipelined else out).cpu().numpy()
         assert np.all(np.isfinite(last)) and np.all(last < 0)
         return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry(), n_clock=n_clock,
-                    spread_pct=spread, best=min(times), worst=max(times))
+                    spread_pct=spread, best=min(times), worst=max(times), cold_elapsed=cold_elapsed, thetas=thetas, out=out)
 
     def exchange_label(m):
         if not use_dist:
@@ -258,7 +284,7 @@ def main():
             return "gloo all_gather (TEST MODE: ranks share one GPU)"
         return "RCCL all_gather of logL per step" + (", pipelined with the next evaluation" if m["pipelined"] else "")
 
-    main_mode = measure(args.scaling)
+    main_mode = measure(args.scaling, cold=True)
     # with more than one GPU the other scaling mode is measured in the same invocation and reported under "other_scaling"
     other = measure("strong" if args.scaling == "weak" else "weak") if world > 1 else None
 
@@ -274,6 +300,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 MLP + f64",
             "data": "synthetic", "repeats": args.repeats, "spread_pct": m["spread_pct"], "clock_warmup_launches": m["n_clock"],
+            # the contract-shaped single region (W warm-up steps, K timed steps) run as the process's FIRST load, before the clock warm-up
+            "value_cold": evals / m["cold_elapsed"], "ms_per_step_cold": 1e3 * m["cold_elapsed"] / args.steps,
+            "value_is": f"steady state: median of {args.repeats} timed K-step regions after {m['n_clock']} untimed clock-warm-up steps + W; "
+                        "value_cold is the single W + K region of a fresh process; sustained.evals_per_s is >= 5 s of back-to-back steps",
             "ms_per_step_best": 1e3 * m["best"] / args.steps, "ms_per_step_worst": 1e3 * m["worst"] / args.steps,
             "config": {"workload": "BASELINE config 2: Bu2019lm SVD surrogate (NP=4, NH=2048, NC=10, NT=211), "
                                    "AT2017gfo 6-filter synthetic photometry (99 epochs, 1 upper limit), "
@@ -294,6 +324,11 @@ def main():
                                      "unit": "evals/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
                                      "batch_per_gpu": other["B"], "global_batch": other["global_batch"],
                                      "exchange": exchange_label(other), "kernel_ms": o_ms}
+        if world == 1 and args.sustained_seconds > 0:
+            try:
+                line["sustained"] = sustained_leg(eng, m["thetas"], m["out"], B, args.sustained_seconds, line["value"], fused_ms)
+            except Exception as exc:      # noqa: BLE001
+                line["sustained"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline and world == 1:      # (the profiled command lines pass --no-cpu-baseline: device launches only)
             # (context blocks: a failure in one of them must not cost the contract line)
             def context(key, fn):
@@ -317,6 +352,52 @@ def main():
     if dist is not None and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sustained_leg(eng, thetas, out, batch, seconds, value, kernel_ms_region, chunk=8192):
+    """>= `seconds` of back-to-back steps on the same handle -- what a sampler's likelihood sees after the first second.  The timed
+    regions of `value` are ~0.6 ms each, 30 ms after the clocks settled; power and thermal management act on seconds.  Chunks of
+    `chunk` steps; per chunk the wall time and the kernel time from HIP events on the launch stream (every 16th group of 8
+    launches).  Context, never `value`; the line's `roofline` is restated on this leg's kernel time as `roofline_frac`."""
+    import gc
+    import numpy as np
+    import torch
+    os.environ["NMMA_PROFILE_GROUP"], os.environ["NMMA_PROFILE_STRIDE"] = "8", "16"
+    n_sets = len(thetas)
+    gc.collect()
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        chunks, done = [], 0
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < seconds:
+            eng.profile_begin(chunk)
+            t0 = time.perf_counter()
+            for i in range(done, done + chunk):
+                eng.loglike(thetas[i % n_sets], out=out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            p = eng.profile_end()
+            chunks.append((t0 - t_start, t1 - t0, 1e3 * p["fused_ms_total"] / max(1, p["n_launches"])))
+            done += chunk
+        total = time.perf_counter() - t_start
+    finally:
+        gc.enable()
+    start, wall, kern_us = (np.array(v) for v in zip(*chunks))
+    first, last = start < 1.0, start >= start[-1] - 1.0
+    k_first, k_last = float(kern_us[first].mean()), float(kern_us[last].mean())
+    rate = done * batch / total
+    k_all = float(kern_us.mean())
+    return {"seconds": total, "steps": done, "evals_per_s": rate, "ratio_to_value": rate / value,
+            "ms_per_step": 1e3 * total / done, "kernel_us_first_second": k_first, "kernel_us_last_second": k_last,
+            "kernel_us_mean": k_all, "kernel_us_min_chunk": float(kern_us.min()), "kernel_us_max_chunk": float(kern_us.max()),
+            "drift_pct": 100.0 * (k_last - k_first) / k_first,
+            "evals_per_s_first_second": float(chunk * batch * first.sum() / wall[first].sum()),
+            "evals_per_s_last_second": float(chunk * batch * last.sum() / wall[last].sum()),
+            "roofline_frac": eng.flops_per_eval * batch / (k_all * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "kernel_us_timed_regions": 1e3 * kernel_ms_region,
+            "what": f"back-to-back steps of the same workload for >= {seconds:g} s in chunks of {chunk} (synchronised per chunk); kernel time from HIP "
+                    "events on the launch stream; drift_pct = last second's kernel time against the first second's"}
 
 
 def host_call_ms(eng, case, syn):

@@ -13,7 +13,7 @@ rm -rf $o; mkdir -p $o
 export TMPDIR=/tmp
 python3 bench.py --steps 200 --warmup 20 > $o/bench_line.json 2> $o/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_line_driver_flags.json 2> $o/bench_driver.err     # what the driver runs
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $o/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --sustained-seconds 0 > $o/stats_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05 -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05.log 2>&1
 export NMMA_EM_NO_LEAN_LIM=1       # the same case on the extended task (em_logl<.., 2>), which had the finite limits before
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_dt05ext -- python3 tools/perf_case.py c2_dt05_limit 4096 > $o/stats_dt05ext.log 2>&1
@@ -38,21 +38,21 @@ bash tools/pmc_c4.sh $tag > $o/pmc_c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_at2017gfo -- python3 tools/perf_case.py at2017gfo 4096 > $o/stats_at2017gfo.log 2>&1
 # small batches: kernel time against the batch size with and without the band split; bench lines at 512 rows and at one row
 python3 tools/perf_small_batch.py > $o/small_batch.log 2>&1
-python3 bench.py --steps 200 --warmup 20 --batch 512 --no-cpu-baseline > $o/bench_line_b512.json 2> $o/bench_b512.err
-python3 bench.py --steps 200 --warmup 20 --batch 1 --no-cpu-baseline > $o/bench_line_b1.json 2> $o/bench_b1.err
+python3 bench.py --steps 200 --warmup 20 --batch 512 --no-cpu-baseline --sustained-seconds 0 > $o/bench_line_b512.json 2> $o/bench_b512.err
+python3 bench.py --steps 200 --warmup 20 --batch 1 --no-cpu-baseline --sustained-seconds 0 > $o/bench_line_b1.json 2> $o/bench_b1.err
 # groups of three / two bands per workgroup
-python3 bench.py --steps 200 --warmup 20 --batch 1024 --no-cpu-baseline > $o/bench_line_b1024.json 2> $o/bench_b1024.err
-python3 bench.py --steps 200 --warmup 20 --batch 2048 --no-cpu-baseline > $o/bench_line_b2048.json 2> $o/bench_b2048.err
+python3 bench.py --steps 200 --warmup 20 --batch 1024 --no-cpu-baseline --sustained-seconds 0 > $o/bench_line_b1024.json 2> $o/bench_b1024.err
+python3 bench.py --steps 200 --warmup 20 --batch 2048 --no-cpu-baseline --sustained-seconds 0 > $o/bench_line_b2048.json 2> $o/bench_b2048.err
 python3 tools/perf_table.py > $o/perf_table.log 2>&1
 # the lock-step ensemble walk on the device against the host walk (MCMC steps of 4096 chains)
 for n in 1024 2048 4096 16384; do python3 tools/perf_device_walk.py $n 400; done > $o/device_walk.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_device_walk -- python3 tools/perf_device_walk.py 4096 400 > $o/stats_device_walk.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/pmc_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0 > $o/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq2.log 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $o/pmc_sq3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/pmc_sq3.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0 > $o/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $o/pmc_sq2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0 > $o/pmc_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $o/pmc_sq3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0 > $o/pmc_sq3.log 2>&1
 find $o -name "*kernel_stats.csv" | head
 cat $o/bench_line.json
 # the sampler queue (4096 records x 100 steps): kernel times of the fused MCMC step and of the queue's other launches
