@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 5
+#define NMMA_ABI_VERSION 6
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -158,6 +158,12 @@ typedef struct nmma_em_config {
     const int32_t* sys_slot_offsets; /* [O+1] CSR offsets into sys_slots / sys_node_times */
     const nmma_slot* sys_slots;   /* per node: where its sigma_sys comes from */
     const double* sys_node_times; /* per node: time of the node (ignored for NMMA_SYS_PARAM) */
+
+    /* ---- combined models (CombinedLightCurveModelContainer, model.py:1342-1510): 1 = the likelihood's model is the flux sum of
+     * this handle's surrogate and ONE more transient whose source-frame curves arrive per call on the handle's own sample_times and
+     * model filters (nmma_em_loglike_stack2) -- the handle is then laid out for the one-launch form of that call; 0 otherwise ---- */
+    int32_t stack_operands;
+    int32_t pad_stack;
 } nmma_em_config;
 
 typedef struct nmma_em_handle nmma_em_handle;
@@ -212,6 +218,22 @@ int32_t nmma_em_loglike_lc(nmma_em_handle* h, const double* theta_dev, int64_t B
  * delivered no light curve for this row (model.py:1423-1426) -> floor. */
 int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* const* lc_dev_sets,
                                 int32_t n_sets, const uint8_t* bad_rows_dev, double* out_dev, void* stream);
+
+/* The COMBINED model of two transients that share sample_times and filters -- what the reference's drivers build: every sub-model
+ * gets filters=filters, sample_times=setup_sample_times(args), model.py:1591-1614 -- in ONE launch on an NMMA_MODEL_SVD handle created
+ * with stack_operands = 1: replaces B calls of CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes (model.py:1411-1459,
+ * :1486-1510) -> MultiFilterTransient.log_likelihood (em_likelihood.py:186-204, :313-352).  lc2_dev[B][M][NS]: the second transient's
+ * source-frame absolute magnitudes on the handle's sample_times and model filters (+inf / NaN where it has no value: interior gaps
+ * are interpolated over its finite nodes, +inf outside them, as autocomplete_data does for the reference, utils.py:626-645).  The
+ * likelihood kernel takes the curves as an operand: every datum loads the two nodes it interpolates between and the flux sum is
+ * formed on those two nodes next to the kilonova's two reconstructed ones -- the kilonova's curves are never written out.  Rows that
+ * meet an interior gap of lc2 (rare) are re-evaluated in the same call by the kernels behind nmma_em_model_lightcurves +
+ * nmma_em_loglike_lc_sets, restricted to those rows.  bad_rows_dev (or NULL): [B] bytes, non-zero = a sub-model delivered no light
+ * curve for this row (model.py:1423-1426) -> floor.  Returns 2 -- nothing launched -- when the handle has no one-launch form (not
+ * created with stack_operands = 1; a task flavour other than the lean one; sample_times reaching beyond the surrogate's grid;
+ * unequally spaced sample_times): the caller then takes nmma_em_model_lightcurves + nmma_em_loglike_lc_sets.  Asynchronous. */
+int32_t nmma_em_loglike_stack2(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* lc2_dev,
+                               const uint8_t* bad_rows_dev, double* out_dev, void* stream);
 
 /* Flux addition of n_models light-curve sets lc_k[B][M][NS] given on the handle's sample_times
  * (CombinedLightCurveModelContainer.gen_detector_lc + stack_magnitudes, model.py:1440-1448,

@@ -16,14 +16,14 @@ SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: translation units of the library; every other file under csrc/ and include/ is a dependency of both
 #: translation units of libnmma_hip.so, longest first (they compile concurrently; build_library caps the number in flight).  em_logl's
 #: 38 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s.
-SOURCES = ("em_logl_f5.hip", "em_logl_f02.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_kernels.hip", "em_logl_f1.hip",
-           "gw_kernels.hip", "walk_kernels.hip")
+SOURCES = ("em_logl_f5.hip", "em_kernels.hip", "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip",
+           "em_logl_f1.hip", "gw_kernels.hip", "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
 UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -81,6 +81,7 @@ class EmConfig(C.Structure):
         ("detection_limit", _pd), ("n_sources", _pi), ("sources", _pi),
         ("sys_kind", _pi), ("sys_const", _pd), ("sys_n_nodes", _pi), ("sys_slot_offsets", _pi),
         ("sys_slots", C.POINTER(Slot)), ("sys_node_times", _pd),
+        ("stack_operands", C.c_int32), ("pad_stack", C.c_int32),
     ]
 
 
@@ -153,6 +154,7 @@ PROTOTYPES = {
                                        C.c_void_p]),
     "nmma_em_loglike_lc_sets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "nmma_em_loglike_stack2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_lc_regrid": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _pd, _pi, _pi, C.c_int64, C.c_void_p,
                                    C.c_void_p]),

@@ -587,7 +587,19 @@ struct LdsW {
     int32_t nodes;      // dense lean task (em_logl<.., 6>): DENSE_NBUF buffers of [dense_rows][DENSE_STRIDE] fp64 node magnitudes of 16 samples
     int32_t nf_max;
     int32_t nbuf;       // depth of the partial-sum ring (items the MFMA role may run ahead)
+    // (combined-model flavour, em_logl<.., 7>: `nodes` is the offset of the two-model flux-sum table, stack2_tab.h, STACK2_LDS_BYTES --
+    //  the flavour is never dense, and a field of its own would move the kernel arguments behind this struct for every flavour)
 };
+
+// Per-call operands of em_logl's combined-model flavour (FASTM 7), passed by value behind the other kernel arguments:
+// the second transient's source-frame curves [B][M][NS] on the handle's sample_times and model filters, and the rows for which
+// a sub-model delivered no light curve (or NULL).
+// gap_rows[B]: written by the kernel for every row -- 1 = the row met an interior non-finite node of lc2 and must be re-evaluated
+// by the materialising kernels (nmma_em_loglike_stack2 launches them restricted to those rows), 0 = out[b] is final.
+struct EmAux { const double* lc2; const unsigned char* bad_rows; unsigned char* gap_rows; };
+struct EmNoAux {};      // (what every other flavour takes in that place: their kernel arguments stay as they were)
+template <int FASTM> struct em_aux_of { typedef EmNoAux type; };
+template <> struct em_aux_of<7> { typedef EmAux type; };
 
 // One candidate layout: `nbuf` ring slots, photometry staged or not.
 // Dynamic LDS a launch may ask for: the 160 KiB of a CU minus the kernel's static words (g_wd_trip), rounded down to the
@@ -596,7 +608,7 @@ constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
 
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
                                          int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0,
-                                         int dat_point_bytes = 32, int dense_rows = 0) {
+                                         int dat_point_bytes = 32, int dense_rows = 0, int stack_bytes = 0) {
     const int TS = 16 * R;
     const bool bracket_lookup = NS < 0;        // (NS < 0: unequally spaced sample_times -- the lean tasks' lookup table sits behind the grid)
     NS = NS < 0 ? -NS : NS;
@@ -617,9 +629,9 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.epar = off;  off = align16(off + (all_fast ? n_sys_slots * TS * 8 : 0));        // fast modes: sysv[slot][sample]
     L.exttab = off; off = align16(off + ext_rows * TS * 8);          // lean task with extinction: ext_mag[item][sample]
     L.xn = off;   off = align16(off + M * NP * 2 * 8);               // (pmin, 1/pspan) per model filter and parameter
-    L.bad = off;  off = align16(off + 5 * TS * 4);                   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts)
+    L.bad = off;  off = align16(off + (5 + (stack_bytes ? 1 : 0)) * TS * 4);   // bad[TS] (NaN terms) | badp[4][TS] (prologue parts) | combined model: gap[TS]
     L.cdl = off;  off = align16(off + (dense_rows ? 0 : 16 * 2 * 4 * 16 * 8));      // per wave (any role): 2 x 4 slots x 16 coefficients (the dense task has none)
-    L.nodes = off; off = align16(off + DENSE_NBUF * dense_rows * DENSE_STRIDE * 8);
+    L.nodes = off; off = align16(off + DENSE_NBUF * dense_rows * DENSE_STRIDE * 8 + stack_bytes);      // (never both)
     L.itab = off; off = align16(off + n_items * ITEM_WORDS * 4);     // per-item descriptors
     L.nf_max = nf_avg_max;
     L.est = off;  off = align16(off + TS * nf_avg_max * 8);
@@ -636,7 +648,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 //  that share the CUs, e.g. RCCL's while a collective overlaps the likelihood)
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
                                      int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4, int dat_point_bytes = 32,
-                                     int dense_rows = 0) {
+                                     int dense_rows = 0, int stack_bytes = 0) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     if (want > ring_max) want = ring_max < 1 ? 1 : ring_max;
@@ -644,10 +656,126 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
             // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes, dense_rows);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes, dense_rows, stack_bytes);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error
+}
+
+// ---------------------------------------------------------------------------------------
+// Flux sum of light-curve sets (stack_magnitudes, model.py:1486-1510): shared by the stacking / likelihood-from-curves kernels
+// (em_kernels.hip) and by em_logl's combined-model flavour, which stacks a second transient's curves onto the kilonova's bracket nodes.
+// ---------------------------------------------------------------------------------------
+// The curve sets of one stacking call, passed by value (no device-side pointer table).
+struct LcSets { const double* p[8]; };       // the curve sets of one stacking call, passed by value (no device-side pointer table)
+
+// The two-model table into LDS (STACK2_LDS_BYTES at tab_lds); the caller synchronises the workgroup before lc_stack_node reads it.
+__device__ __forceinline__ void stack2_stage(double* tab_lds, const int tid, const int n_threads) {
+    for (int j = tid; j < STACK2_NINT * STACK2_ROW; j += n_threads) tab_lds[j] = kStack2Tab[j];
+}
+
+// Two models (kilonova + afterglow, the reference's combined models), both finite at this node -- all but a few nodes:
+// mag = min(m0, m1) - g(|m0 - m1|), g(D) = 2.5 log10(1 + 10^(-0.4 D)) from a table of degree-10 polynomials on 64 intervals of
+// [0, 40) mag (stack2_tab.h, tools/gen_softplus_table.py: 1.7e-15 mag from the direct formula; beyond 40 mag g < 3e-16).
+// tab2: the table staged in LDS by the caller (stack2_stage) -- every lane reads its own row, six 16-byte reads; from global
+// memory those gathers cost as much as the exp and the log in fp64 they replace (~150 vector instructions a node).
+// false: a non-finite value -- the node takes lc_stack_node's general path (gap filling).
+__device__ __forceinline__ bool stack2_fast(const double v0, const double v1, const double* tab2, double& r) {
+    if (!((v0 - v0 == 0.0) && (v1 - v1 == 0.0))) return false;
+    const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
+    r = lo;
+    if (D >= STACK2_DMAX) return true;
+    const double sc = D * STACK2_INV_H;
+    int idx = (int)sc;
+    idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
+    const double t = 2.0 * (sc - (double)idx) - 1.0;
+    const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
+    const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
+    double p = fma(c0.x, t, c0.y);
+    p = fma(p, t, c1.x); p = fma(p, t, c1.y);
+    p = fma(p, t, c2.x); p = fma(p, t, c2.y);
+    p = fma(p, t, c3.x); p = fma(p, t, c3.y);
+    p = fma(p, t, c4.x); p = fma(p, t, c4.y);
+    p = fma(p, t, c5.x);
+    r = lo - p;
+    return true;
+}
+
+// One node: vv[k] = model k's value at node g (already loaded).
+template <int KM>
+__device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv,
+                                                const double* tab2 = nullptr) {
+    const int NS = P.NS;
+    if constexpr (KM == 2) {
+        double r;
+        if (n_models == 2 && tab2 != nullptr && stack2_fast(vv[0], vv[1], tab2, r)) return r;
+    }
+    const double ln10 = 2.302585092994046;
+    double amax = -HUGE_VAL, terms[KM];
+    bool any_nan = false;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        terms[k] = -HUGE_VAL;
+        if (k >= n_models) continue;
+        double v = vv[k];                 // (the curves of a set are contiguous: node g of the set)
+        if (!(v - v == 0.0)) {            // non-finite node: interpolate between finite neighbours
+            // (only here is the node's place in its curve needed: the 64-bit division stays off the common path)
+            const long cidx = g / NS;
+            const int j = (int)(g - cidx * NS);
+            const double* cur = sets.p[k] + (size_t)cidx * NS;
+            int jl = j - 1, jr = j + 1;
+            while (jl >= 0 && !(cur[jl] - cur[jl] == 0.0)) --jl;
+            while (jr < NS && !(cur[jr] - cur[jr] == 0.0)) ++jr;
+            v = (jl >= 0 && jr < NS) ? lerp_np(P.st[j], P.st[jl], P.st[jr], cur[jl], cur[jr]) : HUGE_VAL;
+        }
+        const double a = -2.0 / 5.0 * ln10 * v;
+        terms[k] = a;
+        if (a != a) any_nan = true;
+        if (a > amax) amax = a;
+    }
+    double res;
+    if (any_nan) res = HUGE_VAL - HUGE_VAL;
+    else if (!(amax - amax == 0.0)) res = amax;          // every model -inf (no flux) or +inf
+    else {
+        double sacc = 0.0;
+        // (exp(0) is exactly 1: the largest term needs no exponential -- half of them for two models.  Own exp for arguments <= 0
+        //  and log for [1, 8] -- exp_neg / log_pos, ~1 ulp: the library's two calls were a third of a node's instructions)
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < n_models) sacc += (terms[k] == amax) ? 1.0 : exp_neg(terms[k] - amax);
+        res = log_pos(sacc) + amax;
+    }
+    // (x (1 / ln 10) instead of / ln 10: one rounding more than the reference's expression -- 1 ulp of a magnitude -- for a
+    //  division's ~35 instructions less per node)
+    return (-5.0 / 2.0 * res) * 0.43429448190325176;
+}
+
+// em_logl's combined-model flavour (FASTM 7): stack2_fast without its early returns -- the same operations in the same order for a
+// finite pair (bit-identical result), garbage for a non-finite one (the caller sorts those out) -- so that the lean task stays one
+// straight-line scheduling region.
+__device__ __forceinline__ double stack2_node(const double v0, const double v1, const double* tab2) {
+    const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
+    const double sc = D * STACK2_INV_H;
+    int idx = (int)sc;
+    idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
+    idx = idx < 0 ? 0 : idx;
+    const double t = 2.0 * (sc - (double)idx) - 1.0;
+    const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
+    const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
+    double p = fma(c0.x, t, c0.y);
+    p = fma(p, t, c1.x); p = fma(p, t, c1.y);
+    p = fma(p, t, c2.x); p = fma(p, t, c2.y);
+    p = fma(p, t, c3.x); p = fma(p, t, c3.y);
+    p = fma(p, t, c4.x); p = fma(p, t, c4.y);
+    p = fma(p, t, c5.x);
+    return (D >= STACK2_DMAX) ? lo : lo - p;
+}
+// lc_stack_node's general form for (kn, +inf): the second model contributes no flux -- terms {a, -inf}, sum of exponentials exactly 1,
+// log exactly 0 -- operation for operation (NaN for a non-finite kn).
+__device__ __forceinline__ double stack2_no_flux(const double kn) {
+    const double ln10 = 2.302585092994046;
+    const double a = -2.0 / 5.0 * ln10 * kn;
+    return (-5.0 / 2.0 * a) * 0.43429448190325176;
 }
 
 }  // namespace nmma

@@ -41,7 +41,10 @@ struct nmma_em_handle {
     double* chi = nullptr;
     double* gp = nullptr;
     int64_t parts_cap = 0;
-    double* lc_ws = nullptr;        // [B][M][NS] model light curves (non-SVD models)
+    double* lc_ws = nullptr;        // [B][M][NS] model light curves (non-SVD models; the surrogate's curves of rows nmma_em_loglike_stack2 re-evaluates)
+    int stack2_ok = 0;              // the handle has the one-launch form of the combined model (em_logl<.., 7>; nmma_em_loglike_stack2)
+    unsigned char* gap_ws = nullptr;    // [B] rows em_logl<.., 7> flagged for re-evaluation
+    int64_t gap_cap = 0;
     int ring_max = 4;               // NMMA_EM_RING: upper bound on em_logl's LDS ring of item slots
     // nmma_lc_regrid's tables on the device, [src times | source index | n sources], one entry per DISTINCT table set seen (a
     // combined model calls with one set per regridded sub-model, the same sets every batch): keyed by content
@@ -103,7 +106,7 @@ static int split_level(const nmma_em_handle* h, int R, int FAST, int64_t B, bool
     const int n_bands = h->lvl_n[0];
     const long tiles = (long)((B + 16 * R - 1) / (16 * R));
     int lvl = -1;
-    if (R == 1 && FAST != 0 && FAST != 2 && !per_filter_parts && h->band_dev_d != nullptr && n_bands >= 2 && h->split_mode != 0 &&
+    if (R == 1 && FAST != 0 && FAST != 2 && FAST != 7 && !per_filter_parts && h->band_dev_d != nullptr && n_bands >= 2 && h->split_mode != 0 &&
         tiles * (long)sizeof(unsigned) <= SPLIT_COUNTER_BYTES) {
         if (h->split_mode == 1) lvl = 0;
         else {
@@ -118,6 +121,7 @@ static int split_level(const nmma_em_handle* h, int R, int FAST, int64_t B, bool
 // em_logl's launcher; defined in em_logl.h and instantiated explicitly by the em_logl_*.hip units (em_kernels.hip only calls it)
 template <int R, int KP, int NMW, int NVW, int FAST, int WALKF = 0>
 hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, int64_t ld, double* out,
-                           double* chi, double* gp, hipStream_t s, const nmma_walk_fuse* wf = nullptr, uint64_t wstep = 0, int wlast = 0);
+                           double* chi, double* gp, hipStream_t s, const nmma_walk_fuse* wf = nullptr, uint64_t wstep = 0, int wlast = 0,
+                           EmAux aux = EmAux{nullptr, nullptr, nullptr});
 
 }  // namespace nmma

@@ -41,10 +41,31 @@ __host__ inline LdsOff lds_layout(int mode, int R, int NC, int NT, int NS) {
     return L;
 }
 
+// Which of a workgroup's units of work (tiles of em_fused, row blocks of em_lc_loglike: unit u = first + i * stride, i = 0 .. 63) hold a
+// row flagged in only_rows: bit i of the result, the same in every wave of the workgroup (each wave does the loads itself: no LDS, no
+// barrier).  A unit covers `rows` (4 .. 32, a power of two) consecutive rows; only_rows is padded with zeros to whole units.
+__device__ __forceinline__ unsigned long long flagged_units(const unsigned char* __restrict__ only_rows, const long first, const long stride,
+                                                            const long n_units, const int rows) {
+    const long u = first + (long)(threadIdx.x & 63) * stride;
+    bool any = false;
+    if (u < n_units) {
+        const unsigned char* p = only_rows + u * rows;
+        if (rows >= 8) {
+            unsigned long long acc = 0;
+            for (int q = 0; q < rows / 8; ++q) acc |= reinterpret_cast<const unsigned long long*>(p)[q];
+            any = acc != 0;
+        } else {
+            any = *reinterpret_cast<const unsigned*>(p) != 0;
+        }
+    }
+    return __ballot(any);
+}
+
+// The kernel proper: tile `bidx` of 16 R parameter vectors, model filter m.
 template <int MODE, int R, int WPB, int KP>
-__global__ __launch_bounds__(64 * WPB, 2) void em_fused(
+__device__ __forceinline__ void em_fused_body(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff L,
-    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out) {
+    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out, const unsigned bidx, const int m) {
     constexpr int TS = 16 * R;
     constexpr int NTHR = 64 * WPB;
     constexpr int RECF = rec_floats(KP);
@@ -62,8 +83,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long tile0 = (long)blockIdx.x * TS;
-    const int m = blockIdx.y;  // model filter
+    const long tile0 = (long)bidx * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
 
     if constexpr (MODE == MODE_LC) {
@@ -231,6 +251,31 @@ __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     }
 }
 
+// ONLY: the launch is restricted to the tiles that hold a row with only_rows[b] != 0 (the combined-model call re-evaluates the rows its
+// one-launch kernel flagged: nmma_em_loglike_stack2) -- a SMALL grid whose workgroups each look at every gridDim.x-th tile's flags
+// (64 tiles per load round) and run the kernel for the flagged ones: with nothing flagged the launch costs little more than an
+// empty kernel (as one workgroup per tile leaving after a load it cost 5 us at config 3's shape).
+template <int MODE, int R, int WPB, int KP, bool ONLY = false>
+__global__ __launch_bounds__(64 * WPB, 2) void em_fused(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff L,
+    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out, const unsigned char* __restrict__ only_rows) {
+    if constexpr (!ONLY) {
+        em_fused_body<MODE, R, WPB, KP>(Pp, theta, B, ld, L, coeff_out, tobs_out, mag_out, blockIdx.x, (int)blockIdx.y);
+    } else {
+        constexpr int TS = 16 * R;
+        const long n_tiles = (B + TS - 1) / TS;
+        for (long first = blockIdx.x; first < n_tiles; first += 64L * gridDim.x) {
+            unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_tiles, TS);
+            while (mask != 0) {
+                const int i = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                em_fused_body<MODE, R, WPB, KP>(Pp, theta, B, ld, L, coeff_out, tobs_out, mag_out, (unsigned)(first + (long)i * gridDim.x), (int)blockIdx.y);
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // =======================================================================================
 // em_lc_loglike: likelihood from SUPPLIED source-frame light curves lc[B][M][NS] (absolute
 // magnitudes on the handle's sample_times, +inf / NaN where the model has no value) --
@@ -251,91 +296,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
-
-// The curve sets of one stacking call, passed by value (no device-side pointer table).
-struct LcSets { const double* p[8]; };       // the curve sets of one stacking call, passed by value (no device-side pointer table)
-
-// The two-model table into LDS (STACK2_LDS_BYTES at tab_lds); the caller synchronises the workgroup before lc_stack_node reads it.
-__device__ __forceinline__ void stack2_stage(double* tab_lds, const int tid, const int n_threads) {
-    for (int j = tid; j < STACK2_NINT * STACK2_ROW; j += n_threads) tab_lds[j] = kStack2Tab[j];
-}
-
-// Two models (kilonova + afterglow, the reference's combined models), both finite at this node -- all but a few nodes:
-// mag = min(m0, m1) - g(|m0 - m1|), g(D) = 2.5 log10(1 + 10^(-0.4 D)) from a table of degree-10 polynomials on 64 intervals of
-// [0, 40) mag (stack2_tab.h, tools/gen_softplus_table.py: 1.7e-15 mag from the direct formula; beyond 40 mag g < 3e-16).
-// tab2: the table staged in LDS by the caller (stack2_stage) -- every lane reads its own row, six 16-byte reads; from global
-// memory those gathers cost as much as the exp and the log in fp64 they replace (~150 vector instructions a node).
-// false: a non-finite value -- the node takes lc_stack_node's general path (gap filling).
-__device__ __forceinline__ bool stack2_fast(const double v0, const double v1, const double* tab2, double& r) {
-    if (!((v0 - v0 == 0.0) && (v1 - v1 == 0.0))) return false;
-    const double lo = v0 < v1 ? v0 : v1, D = fabs(v0 - v1);
-    r = lo;
-    if (D >= STACK2_DMAX) return true;
-    const double sc = D * STACK2_INV_H;
-    int idx = (int)sc;
-    idx = idx > STACK2_NINT - 1 ? STACK2_NINT - 1 : idx;
-    const double t = 2.0 * (sc - (double)idx) - 1.0;
-    const double2* cf = reinterpret_cast<const double2*>(tab2) + idx * (STACK2_ROW / 2);
-    const double2 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
-    double p = fma(c0.x, t, c0.y);
-    p = fma(p, t, c1.x); p = fma(p, t, c1.y);
-    p = fma(p, t, c2.x); p = fma(p, t, c2.y);
-    p = fma(p, t, c3.x); p = fma(p, t, c3.y);
-    p = fma(p, t, c4.x); p = fma(p, t, c4.y);
-    p = fma(p, t, c5.x);
-    r = lo - p;
-    return true;
-}
-
-// One node: vv[k] = model k's value at node g (already loaded).
-template <int KM>
-__device__ __forceinline__ double lc_stack_node(const EmDev& P, const LcSets& sets, const int n_models, const long g, const double* vv,
-                                                const double* tab2 = nullptr) {
-    const int NS = P.NS;
-    if constexpr (KM == 2) {
-        double r;
-        if (n_models == 2 && tab2 != nullptr && stack2_fast(vv[0], vv[1], tab2, r)) return r;
-    }
-    const double ln10 = 2.302585092994046;
-    double amax = -HUGE_VAL, terms[KM];
-    bool any_nan = false;
-#pragma unroll
-    for (int k = 0; k < KM; ++k) {
-        terms[k] = -HUGE_VAL;
-        if (k >= n_models) continue;
-        double v = vv[k];                 // (the curves of a set are contiguous: node g of the set)
-        if (!(v - v == 0.0)) {            // non-finite node: interpolate between finite neighbours
-            // (only here is the node's place in its curve needed: the 64-bit division stays off the common path)
-            const long cidx = g / NS;
-            const int j = (int)(g - cidx * NS);
-            const double* cur = sets.p[k] + (size_t)cidx * NS;
-            int jl = j - 1, jr = j + 1;
-            while (jl >= 0 && !(cur[jl] - cur[jl] == 0.0)) --jl;
-            while (jr < NS && !(cur[jr] - cur[jr] == 0.0)) ++jr;
-            v = (jl >= 0 && jr < NS) ? lerp_np(P.st[j], P.st[jl], P.st[jr], cur[jl], cur[jr]) : HUGE_VAL;
-        }
-        const double a = -2.0 / 5.0 * ln10 * v;
-        terms[k] = a;
-        if (a != a) any_nan = true;
-        if (a > amax) amax = a;
-    }
-    double res;
-    if (any_nan) res = HUGE_VAL - HUGE_VAL;
-    else if (!(amax - amax == 0.0)) res = amax;          // every model -inf (no flux) or +inf
-    else {
-        double sacc = 0.0;
-        // (exp(0) is exactly 1: the largest term needs no exponential -- half of them for two models.  Own exp for arguments <= 0
-        //  and log for [1, 8] -- exp_neg / log_pos, ~1 ulp: the library's two calls were a third of a node's instructions)
-#pragma unroll
-        for (int k = 0; k < KM; ++k)
-            if (k < n_models) sacc += (terms[k] == amax) ? 1.0 : exp_neg(terms[k] - amax);
-        res = log_pos(sacc) + amax;
-    }
-    // (x (1 / ln 10) instead of / ln 10: one rounding more than the reference's expression -- 1 ulp of a magnitude -- for a
-    //  division's ~35 instructions less per node)
-    return (-5.0 / 2.0 * res) * 0.43429448190325176;
-}
-
 
 // em_lc_loglike<G, NM, SD, SA>: the generic tail of the reference path from detector-frame curves on -- sanity_check, autocomplete_data's
 // dynamic finite mask, systematics, Gaussian / truncated / upper-limit terms, floor -- for curves another kernel produced or the caller
@@ -375,11 +335,13 @@ __device__ __forceinline__ double group_total_canon(const double (&a)[64 / G]) {
     return (R0 + R1) + (R2 + R3);
 }
 
-template <int G, int NM, bool SD, bool SA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
+// The kernel proper for row block `bidx` (4 * 64 / G parameter vectors).  ONLY: only the rows with only_rows[b] != 0 are stored.
+template <int G, int NM, bool SD, bool SA, bool ONLY>
+__device__ __forceinline__ void em_lc_loglike_body(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
     const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample,
-    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
+    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
+    const unsigned char* __restrict__ only_rows, const unsigned bidx) {
     static_assert(G == 64 || G == 32 || G == 16, "a wave per sample, or two / four samples per wave");
     constexpr int SPW = 64 / G;                        // samples per wave
     const EmDev& P = *Pp;
@@ -387,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1), grp = lane / G;     // lane within the sample's group; the group within the wave
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long b_raw = ((long)blockIdx.x * 4 + wave) * SPW + grp;
+    const long b_raw = ((long)bidx * 4 + wave) * SPW + grp;
     const long b = b_raw < B ? b_raw : B - 1;          // (a group beyond the batch recomputes the last row and stores nothing)
     const int NS = P.NS, M = P.M;
     const double* __restrict__ lc = sets.p[0];
@@ -437,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     // what the chains cost).  Workgroups go round-robin over the 8 XCDs; k = blockIdx / 8 counts within the XCD, and whether the
     // XCD's 32 CUs are then filled round-robin (k, k + 32, ... share a CU) or one after the other (4c .. 4c + 3), (k + k / 32) & 3
     // differs among the workgroups of a CU.
-    const int kx = blockIdx.x >> 3;
+    const int kx = bidx >> 3;
     const int pro_wave = (kx + (kx >> 5)) & 3;
     LC_STAMP(0);
     // That wave first copies what its chains read from memory into LDS -- the cosmology grid, the theta rows of the block's samples
@@ -453,11 +415,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
         if (th_lds)
             for (int idx = lane; idx < SPB * P.D; idx += 64) {
                 const int sx = idx / P.D, c = idx - sx * P.D;
-                const long bx = (long)blockIdx.x * SPB + sx;
+                const long bx = (long)bidx * SPB + sx;
                 reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample)[c] = theta[(bx < B ? bx : B - 1) * ld + c];
             }
         if (lane < SPB && bad_rows != nullptr) {
-            const long bx = (long)blockIdx.x * SPB + lane;
+            const long bx = (long)bidx * SPB + lane;
             bad_s = bad_rows[bx < B ? bx : B - 1];
         }
     }
@@ -468,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the LDS copies above, by other lanes of this wave)
         __builtin_amdgcn_wave_barrier();
         if (lane >= SPB) return;
-        const long bs_raw = (long)blockIdx.x * SPB + lane;
+        const long bs_raw = (long)bidx * SPB + lane;
         const long bs = bs_raw < B ? bs_raw : B - 1;
         double* slab_s = reinterpret_cast<double*>(smem + shared_bytes + (size_t)lane * lds_per_sample);
         double* praw_s = slab_s + NS + P.lc_nf_max;
@@ -511,8 +473,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
             const int n_models = NM > 0 ? NM : n_sets;
             constexpr int NPT = NM == 0 ? 2 : 8;       // items per lane and trip (12 or 16 -- more bytes in flight -- measured slower: 38.4 against 35.4 us)
             const int curves_off = NS + P.lc_nf_max + 16;
-            const long blk_base = (long)blockIdx.x * SPB * NN;
-            const long left = B - (long)blockIdx.x * SPB;
+            const long blk_base = (long)bidx * SPB * NN;
+            const long left = B - (long)bidx * SPB;
             const int n_own = left < SPB ? (int)left : SPB;            // samples of this block inside the batch (>= 1)
             for (int n0 = sl; n0 < n_items; n0 += NPT * 192) {
                 double v[NPT][KM];
@@ -534,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
                 for (int i = 0; i < NPT; ++i) {
                     const int n = n0 + i * 192;
                     const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;
-                    const long bx = (long)blockIdx.x * SPB + sx;
+                    const long bx = (long)bidx * SPB + sx;
                     const long g = (bx < B ? bx : B - 1) * NN + j;
                     if (n < n_items && j < NN) {
                         double* dst = reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample) + curves_off + j;
@@ -552,7 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
                         if (((slow >> i) & 1u) == 0u) continue;
                         const int n = n0 + i * 192;
                         const int sx = (int)(((float)n + 0.5f) * inv_nnp), j = n - sx * NNP;
-                        const long bx = (long)blockIdx.x * SPB + sx;
+                        const long bx = (long)bidx * SPB + sx;
                         const long g = (bx < B ? bx : B - 1) * NN + j;
                         const double vv[2] = {sets.p[0][g], sets.p[1][g]};
                         reinterpret_cast<double*>(smem + shared_bytes + (size_t)sx * lds_per_sample)[curves_off + j] = lc_stack_node<2>(P, sets, 2, g, vv, tab2);
@@ -841,10 +803,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
         }
     }
     LC_STAMP(6);
-    if (gl == 0 && b_raw < B) {
+    if (gl == 0 && b_raw < B && (!ONLY || only_rows[b] != 0)) {
         double tot = chi_tot + gp_tot;
         if (bad || !(tot - tot == 0.0)) tot = NMMA_LOGL_FLOOR;      // (a NaN term of any band makes the total NaN)
         out[b] = tot;
+    }
+}
+
+// em_lc_loglike<G, NM, SD, SA, ONLY>: one workgroup per row block; ONLY (the re-evaluation of the rows the combined model's one-launch
+// kernel flagged): a small grid whose workgroups each look at every gridDim.x-th row block's flags and run the kernel for the
+// flagged ones (see em_fused).
+template <int G, int NM, bool SD, bool SA, bool ONLY = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
+    const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample,
+    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
+    const unsigned char* __restrict__ only_rows) {
+    if constexpr (!ONLY) {
+        em_lc_loglike_body<G, NM, SD, SA, false>(Pp, theta, B, ld, sets, n_sets, bad_rows, lds_per_sample, always_floor, out, chi_parts, gp_parts,
+                                                 only_rows, blockIdx.x);
+    } else {
+        constexpr int SPB = 4 * (64 / G);
+        const long n_blocks = (B + SPB - 1) / SPB;
+        for (long first = blockIdx.x; first < n_blocks; first += 64L * gridDim.x) {
+            unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_blocks, SPB);
+            while (mask != 0) {
+                const int i = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                em_lc_loglike_body<G, NM, SD, SA, true>(Pp, theta, B, ld, sets, n_sets, bad_rows, lds_per_sample, always_floor, out, chi_parts,
+                                                        gp_parts, only_rows, (unsigned)(first + (long)i * gridDim.x));
+                __syncthreads();
+            }
+        }
     }
 }
 

@@ -18,15 +18,21 @@ template <int R, int KP, int NMW, int NVW, int FASTM, int WALKF>
 __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_logl(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsW L,
     const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
-    long long* __restrict__ dbg, const nmma_walk_fuse* __restrict__ wf, const unsigned long long wstep, const int wlast) {
+    long long* __restrict__ dbg, const nmma_walk_fuse* __restrict__ wf, const unsigned long long wstep, const int wlast, const typename em_aux_of<FASTM>::type aux) {
     constexpr int TS = 16 * R;
     constexpr int PF = (R == 1) ? 8 : 4;
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
-    constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2;    // small batches: one band per workgroup (launch_logl_one)
+    constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2 && FASTM != 7;    // small batches: one band per workgroup (launch_logl_one)
     constexpr bool DENSE = FASTM == 6;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
+    // FASTM == 7: the lean task with extras (as 3) for a COMBINED model of two transients that share sample_times and filters
+    // (CombinedLightCurveModelContainer, model.py:1411-1459 -- what the reference's drivers build, :1591-1614): the second transient's
+    // source-frame curves aux.lc2[B][M][NS] are an operand; every datum loads its two bracket nodes of them and the flux sum
+    // (stack_magnitudes, :1486-1510) is formed on those two nodes only, next to the kilonova's two reconstructed nodes -- the
+    // kilonova's curves are never written out (em_fused<MODE_LC_ABS> + em_lc_loglike: two launches and 24 + 48 MB of traffic at config 3's shape)
+    constexpr bool COMB = FASTM == 7;
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     // (blockIdx.y > 0 only in the split launch of small batches: one copy of the configuration per observed band)
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                             if (nodes && odd) repair_nodes(reinterpret_cast<double*>(smem + L.epar) + q0 * TS + lane, TS, P.sys_node_t + q0, q1 - q0);
                     }
                     bad[lane] = 0;
-
+                    if constexpr (COMB) bad[5 * TS + lane] = 0;       // gap[TS]: the sample met an interior gap of the second transient's curve
                 }
 #endif
                 badp[vwave * TS + lane] = (chk - chk == 0.0) ? 0 : 1;
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;
+            if constexpr (COMB) bad[5 * TS + vt] = 0;
         }
         // The table copies below do not depend on the per-sample chains above: with the staged prologue the chains occupy
         // likelihood waves 0-3 only, so waves 4-7 take ALL the copies and the two run side by side (a band's workgroup of the
@@ -277,6 +284,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             gci32p src = as_global(reinterpret_cast<const int*>(P.item_desc));
             int* dst = reinterpret_cast<int*>(smem + L.itab);
             for (int j = cvt; j < W * ITEM_WORDS; j += cnv) dst[j] = src[j];
+        }
+        if constexpr (COMB) {       // the two-model flux-sum table (stack2_tab.h): every lane gathers its own row from LDS
+            double* dst = reinterpret_cast<double*>(smem + L.nodes);
+            for (int j = cvt; j < STACK2_NINT * STACK2_ROW; j += cnv) dst[j] = kStack2Tab[j];
         }
         }
 
@@ -831,6 +842,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         bool inside_[NSL], valid_[NSL];
         int lo_[NSL];
         lds_c2p D_[NSL];
+        // combined model: the second transient's magnitudes at the slot's two bracket nodes, requested in stage P (their L2 / HBM
+        // latency passes while the task waits for the surrogate) -- the only global-memory reads of the task
+        double g2_[COMB ? NSL : 1][2];
+        gcf64p lc2g = nullptr;
+        if constexpr (COMB) lc2g = as_global(aux.lc2);
         // The kernels that take further passes over a filter with more than 32 points (both slots of a lane then belong to ONE
         // sample) keep that sample's scalars and window in registers across the passes: 12 fewer VALU instructions per pass.
         constexpr bool HOIST = LEANX && !TYPEB;
@@ -886,6 +902,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             dtx_[u] = t - (stl_l[lo] * zp1 + tsh);            // t - x0
             lo_[u] = lo;
             asm volatile("" : "+v"(dtx_[u]), "+v"(lo_[u]));   // (evaluated here, before the wait for the MLP)
+            if constexpr (COMB) {
+                long bb = tile0 + s_[u];
+                bb = bb < B ? bb : B - 1;
+                const unsigned off = (unsigned)((bb * P.M + it.m) * NS + lo);      // (in doubles from aux.lc2; < 2^32: checked by the launcher)
+                g2_[u][0] = lc2g[off]; g2_[u][1] = lc2g[off + 1u];
+            }
         }
         };
         stage_p(0);
@@ -1055,6 +1077,32 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 } else {
                     ynode_[0][u] = ya; ynode_[1][u] = yb;
                 }
+            }
+        }
+        if constexpr (COMB) {
+            // stack_magnitudes (model.py:1486-1510) on the slot's two nodes: min(kn, m2) - g(|kn - m2|) from the table in LDS
+            // (stack2_node: the arithmetic of the stacking kernels' stack2_fast, em_common.h).  STRAIGHT-LINE code on purpose: a
+            // branch here -- even a one-line conditional store -- splits the task's one scheduling region and hipcc then spills
+            // hundreds of registers.  A node where the second transient has no finite value: at the first / last node of the grid
+            // it is the edge of that transient's time range -- no flux, the general form's value for (kn, +inf) -- anywhere else it
+            // may be a gap that autocomplete_data fills from the transient's finite neighbours (utils.py:634-645): the sample is
+            // flagged (an LDS OR issued by every lane) and re-evaluated after this launch by the kernels that materialise the curves.
+            const double* tab2 = reinterpret_cast<const double*>(smem + L.nodes);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                bool gap = false;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double kn = ynode_[e][u], m2 = g2_[u][e];
+                    const int j = lo_[u] + e;
+                    const bool m2_fin = (m2 - m2 == 0.0);
+                    const bool edge = !m2_fin & ((j == 0) | (j == NS - 1));
+                    const double r = stack2_node(kn, m2, tab2);
+                    ynode_[e][u] = edge ? stack2_no_flux(kn) : r;
+                    gap |= !m2_fin & !edge;
+                }
+                const int flag = (gap & valid_[u]) ? 1 : 0;
+                __hip_atomic_fetch_or((lds_ip)(bad + 5 * TS + s_[u]), flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         double est_[NSL], m_[NSL];
@@ -1601,7 +1649,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         if (!P.st_uniform) { if (sysp) lean_gen_task(tb, T{}, T{}, T{}, k, t); else lean_gen_task(tb, T{}, F{}, T{}, k, t); }
                         else if (sysp) { if (two) lean_gen_task(tb, T{}, T{}, F{}, k, t); else lean_gen_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_gen_task(tb, T{}, F{}, F{}, k, t); else lean_gen_task(tb, F{}, F{}, F{}, k, t); }
-                    } else if constexpr (FASTM == 3) {
+                    } else if constexpr (FASTM == 3 || FASTM == 7) {
                         if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
                         else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
                     } else if constexpr (FASTM == 6) {   // dense: more than 16 points in every filter (host); any sample grid -- the
@@ -1638,8 +1686,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
         bool own_totals = !SPLITTABLE || nb <= 1;       // (wave-uniform)
+        if constexpr (COMB) {
+            if (vt < TS && tile0 + vt >= B) aux.gap_rows[tile0 + vt] = 0;      // (the flag array is padded to whole tiles)
+        }
         if (vt < TS && tile0 + vt < B) {
-            const bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
+            bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
+            if constexpr (COMB) {       // a sub-model delivered no light curve for this row (model.py:1423-1426)
+                if (aux.bad_rows != nullptr && aux.bad_rows[tile0 + vt] != 0) isbad = true;
+                // (a flagged row's value -- NaN terms from the nodes without a value, hence the floor -- is replaced by the materialising
+                //  kernels that follow this launch; they floor the row themselves where that is the answer)
+                aux.gap_rows[tile0 + vt] = bad[5 * TS + vt] != 0 ? 1 : 0;
+            }
             if (!SPLITTABLE || nb <= 1) {
                 double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order
                 for (int k = 0; k < W; ++k) { c += chi_tot[k * TS + vt]; g += gp_tot[k * TS + vt]; }
@@ -1728,12 +1785,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 
 template <int R, int KP, int NMW, int NVW, int FAST, int WALKF>
 hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, int64_t ld, double* out,
-                                  double* chi, double* gp, hipStream_t s, const nmma_walk_fuse* wf, uint64_t wstep, int wlast) {
+                                  double* chi, double* gp, hipStream_t s, const nmma_walk_fuse* wf, uint64_t wstep, int wlast, EmAux aux) {
     constexpr int LOGL_THREADS = logl_threads(NMW, NVW);
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
-                                   (P.all_fast == 1 && P.lean_x) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0);
+                                   (P.all_fast == 1 && (P.lean_x || FAST == 7)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
+                                   P.dense ? ((P.NT + 15) & ~15) : 0, FAST == 7 ? STACK2_LDS_BYTES : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
     if (L.total > LDS_DYNAMIC_MAX) {
@@ -1765,6 +1822,8 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
             h->split_cap = cap;
         }
     }
+    typename em_aux_of<FAST>::type kaux{};
+    if constexpr (FAST == 7) kaux = aux;
     const dim3 grid((unsigned)tiles, (unsigned)n_groups);
     h->g_x = grid.x; h->g_y = grid.y; h->g_block = LOGL_THREADS; h->g_tile = TS; h->g_lds = L.total;
     if (L.total > 64 * 1024) {
@@ -1778,10 +1837,10 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     if (split) {
         double* band_ws = reinterpret_cast<double*>(reinterpret_cast<char*>(h->split_ws) + SPLIT_COUNTER_BYTES);
         hipLaunchKernelGGL((em_logl<R, KP, NMW, NVW, FAST, WALKF>), grid, dim3(LOGL_THREADS), L.total, s, h->band_dev_d + h->lvl_off[lvl], theta, (long)B, (long)ld, L,
-                           h->always_floor, out, static_cast<double*>(nullptr), band_ws, h->dbg, wf, (unsigned long long)wstep, wlast);
+                           h->always_floor, out, static_cast<double*>(nullptr), band_ws, h->dbg, wf, (unsigned long long)wstep, wlast, kaux);
     } else {
         hipLaunchKernelGGL((em_logl<R, KP, NMW, NVW, FAST, WALKF>), grid, dim3(LOGL_THREADS), L.total, s, h->dev_d, theta, (long)B, (long)ld, L,
-                           h->always_floor, out, chi, gp, h->dbg, wf, (unsigned long long)wstep, wlast);
+                           h->always_floor, out, chi, gp, h->dbg, wf, (unsigned long long)wstep, wlast, kaux);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -1792,7 +1851,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
 
 #define NMMA_LOGL_INSTANCE(R, KP, NMW, FASTM, WALKF)                                                                          \
     template hipError_t launch_logl_one<R, KP, NMW, 8, FASTM, WALKF>(nmma_em_handle*, const double*, int64_t, int64_t, double*, double*, \
-                                                                     double*, hipStream_t, const nmma_walk_fuse*, uint64_t, int)
+                                                                     double*, hipStream_t, const nmma_walk_fuse*, uint64_t, int, EmAux)
 // a flavour at both tile sizes and both parameter-count classes (+ its fused MCMC step at 16-sample tiles)
 #define NMMA_LOGL_FLAVOUR(NMW, FASTM)          \
     NMMA_LOGL_INSTANCE(1, 1, NMW, FASTM, 0);   \

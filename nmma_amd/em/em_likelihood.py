@@ -36,10 +36,12 @@ class MultiFilterTransient:
         self.set_detection_limit(detection_limit)
         self.priors = priors
         self._engine, self._names = None, None
+        self._engine2, self._names2, self._stack2_off = None, None, False      # a combined model's one-launch engine
 
     def set_detection_limit(self, detection_limit):
         self.detection_limit = utils.set_filter_associated_dict(detection_limit, self.observed_filters)
         self._engine = None
+        self._engine2 = None
 
     def __repr__(self):
         return f"{self.__class__.__name__} (light_curve_model={self.light_curve_model})"
@@ -47,6 +49,7 @@ class MultiFilterTransient:
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engine"] = None          # rebuilt lazily per process (core/mpi_setup.py:614-636)
+        state["_engine2"] = None
         return state
 
     # ---- theta layout -------------------------------------------------------------------
@@ -64,32 +67,51 @@ class MultiFilterTransient:
         return names, fixed
 
     def engine(self, names=None):
-        from ..engine import EMEngine
         if names is None:
             names = self._names or self.sampling_layout()[0]
         names = list(names)
+        self._check_names(names)
+        if self._engine is None or names != self._names:
+            if self._engine is not None:
+                self._engine.close()
+            model = self.light_curve_model
+            self._engine = self._build_engine(names, model.gpu_filters, model.engine_kwargs())
+            self._names = names
+        return self._engine
+
+    @staticmethod
+    def _check_names(names):
         if "Omega_matter" in names:
             # the device scales distances with a sampled H0 (one grid serves every H0 in a flat universe); a sampled matter
             # density changes the shape of z(d_L) and would need a grid per sample
             from .. import _lib as L
             raise L.NMMAHipError("a sampled Omega_matter needs a z(d_L) relation per sample, which the device path does not "
                                  "tabulate: sample 'redshift' instead, or fix Omega_matter")
-        if self._engine is None or names != self._names:
-            if self._engine is not None:
-                self._engine.close()
-            _, fixed = self.sampling_layout()
-            fixed = {k: v for k, v in fixed.items() if k not in names}
+
+    def _build_engine(self, names, gpu_filters, engine_kwargs):
+        from ..engine import EMEngine
+        _, fixed = self.sampling_layout()
+        fixed = {k: v for k, v in fixed.items() if k not in names}
+        obs = [f for f in self.observed_filters if len(self.light_curve_times[f]) > 0]
+        sources = utils.resolve_sources(obs, gpu_filters, known_filters=set(self.model_filter_mapping.values()))
+        return EMEngine(parameter_names=names, fixed=fixed,
+                        data=(self.light_curve_times, self.light_curves, self.light_curve_uncertainties),
+                        observed_filters=obs, sources=sources, detection_limit=self.detection_limit,
+                        systematics=self.systematics_handler.kernel_spec(), **engine_kwargs)
+
+    def stack2_engine(self, names=None):
+        """The one-launch engine of a combined model (``CombinedLightCurveModelContainer.stack2_plan``): the surrogate's engine
+        with the likelihood's photometry, laid out to take the other sub-model's curves as an operand."""
+        names = list(names if names is not None else (self._names2 or self._names or self.sampling_layout()[0]))
+        self._check_names(names)
+        if self._engine2 is None or names != self._names2:
+            if self._engine2 is not None:
+                self._engine2.close()
             model = self.light_curve_model
-            obs = [f for f in self.observed_filters if len(self.light_curve_times[f]) > 0]
-            sources = utils.resolve_sources(obs, model.gpu_filters,
-                                            known_filters=set(self.model_filter_mapping.values()))
-            self._engine = EMEngine(
-                parameter_names=names, fixed=fixed,
-                data=(self.light_curve_times, self.light_curves, self.light_curve_uncertainties),
-                observed_filters=obs, sources=sources, detection_limit=self.detection_limit,
-                systematics=self.systematics_handler.kernel_spec(), **model.engine_kwargs())
-            self._names = names
-        return self._engine
+            kn, _ = model.stack2_plan()
+            self._engine2 = self._build_engine(names, kn.gpu_filters, model.stack2_engine_kwargs())
+            self._names2 = names
+        return self._engine2
 
     # ---- evaluation -------------------------------------------------------------------
     def log_likelihood(self, parameters):
@@ -107,17 +129,29 @@ class MultiFilterTransient:
         """theta[B, D] (numpy or torch CUDA tensor; columns = ``names`` or the sampled prior
         keys) -> logL[B] with the reference's floor already applied.  For combined models
         ``external_lc`` maps external sub-model names to their light-curve tensors."""
-        eng = self.engine(names)
         model = self.light_curve_model
         if hasattr(model, "stacked_lightcurves_abs"):       # CombinedLightCurveModelContainer
             import torch
             th = torch.as_tensor(np.asarray(theta)) if not isinstance(theta, torch.Tensor) else theta
-            th = th.to(f"cuda:{eng.device}", dtype=torch.float64)
-            # (the flux sum of the sub-models is formed on chip while the likelihood kernel stages a sample's curves)
-            sets, failed = model.stacked_sets(th, eng.parameter_names, external_lc, stack_engine=eng)
-            out = eng.loglike_lc_sets(th, sets, failed)
+            out = None
+            if not self._stack2_off and model.stack2_plan() is not None:
+                # two sub-models on one grid (the reference drivers' case): ONE launch, the surrogate's curves never leave the chip
+                eng2 = self.stack2_engine(names)
+                th = th.to(f"cuda:{eng2.device}", dtype=torch.float64)
+                lc2, failed = model.second_operand(th, eng2.parameter_names, external_lc)
+                out = eng2.loglike_stack2(th, lc2, failed)
+                if out is None:                             # (the handle has no one-launch form: decided once per likelihood)
+                    self._stack2_off = True
+                    self._engine2.close()
+                    self._engine2 = None
+            if out is None:
+                eng = self.engine(names)
+                th = th.to(f"cuda:{eng.device}", dtype=torch.float64)
+                # (the flux sum of the sub-models is formed on chip while the likelihood kernel stages a sample's curves)
+                sets, failed = model.stacked_sets(th, eng.parameter_names, external_lc, stack_engine=eng)
+                out = eng.loglike_lc_sets(th, sets, failed)
             return out if isinstance(theta, torch.Tensor) else out.cpu().numpy()
-        return eng.loglike(theta)
+        return self.engine(names).loglike(theta)
 
     def final_diagnostics(self, bestfit_params, args, result=None):
         return self.light_curve_model.gen_detector_lc(dict(bestfit_params))

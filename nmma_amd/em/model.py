@@ -468,6 +468,46 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
             parameters = m.parameter_conversion(parameters)
         return parameters
 
+    def stack2_plan(self):
+        """``(surrogate_model, other_model)`` when the combination can be evaluated in ONE launch (``EMEngine.loglike_stack2``): two
+        sub-models that already live on the combination's grid and filters -- what the reference's drivers build, every sub-model
+        with the same ``filters`` and ``sample_times`` (model.py:1591-1614) -- one of them an SVD surrogate, whose curves then never
+        leave the chip; else None (union grids / filter lists: ``stacked_sets`` + ``EMEngine.loglike_lc_sets``)."""
+        if len(self.lc_models) != 2 or any(plan is not None for plan in self._regrid):
+            return None
+        for i, m in enumerate(self.lc_models):
+            if isinstance(m, SVDLightCurveModel):
+                return m, self.lc_models[1 - i]
+        return None
+
+    def stack2_engine_kwargs(self):
+        """Engine arguments of the one-launch form: the surrogate's tensors with the COMBINATION's grid, cosmology and extinction
+        settings (the ones the likelihood-from-curves engine of the materialising path gets from ``engine_kwargs``)."""
+        kn, _ = self.stack2_plan()
+        own = self.engine_kwargs()
+        kw = kn.engine_kwargs()
+        kw.pop("extinction_law", None)
+        kw.update(sample_times=self.model_times, cosmo_grid=own["cosmo_grid"], device=own["device"], ebv_coeff=own["ebv_coeff"],
+                  filter_nu0=own["filter_nu0"], stack_operands=1)
+        return kw
+
+    def second_operand(self, theta, names, external_lc=None):
+        """The other sub-model's source-frame set ``[B, M, NS]`` for ``EMEngine.loglike_stack2`` and the rows for which it
+        delivered no light curve (bool CUDA tensor or None) -- see ``stacked_sets`` for ``external_lc``."""
+        import torch
+        _, m = self.stack2_plan()
+        failed = None
+        if isinstance(m, ExternalLightCurveModel):
+            val = (external_lc or {})[m.model]
+            if isinstance(val, (tuple, list)):
+                val, ok = val
+                bad = ~(ok.to(torch.bool) if isinstance(ok, torch.Tensor) else torch.as_tensor(np.asarray(ok, dtype=bool)))
+                failed = bad.to(f"cuda:{self.device}")
+            lc = torch.as_tensor(val).to(f"cuda:{self.device}")
+        else:
+            lc = m.lightcurves_abs(theta, names)
+        return lc, failed
+
     def stacked_sets(self, theta, names, external_lc=None, stack_engine=None):
         """The sub-models' source-frame sets ``[B, M, NS]`` on the union grid / filters (the operands of ``stack_magnitudes``) and
         the rows for which a sub-model delivered no light curve (bool CUDA tensor [B], or None).  ``external_lc`` maps the name of

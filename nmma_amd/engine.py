@@ -104,7 +104,7 @@ class EMEngine:
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
-                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None):
+                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None, stack_operands=0):
         self._handle = None
         self._host_out = {}
         lib = L.load_library()
@@ -283,6 +283,8 @@ class EMEngine:
         else:
             self.n_data = 0
 
+        # (a combined model whose second transient arrives per call: lay the handle out for the one-launch form, ``loglike_stack2``)
+        cfg.stack_operands = int(stack_operands)
         h = C.c_void_p()
         L.check(lib.nmma_em_create(C.byref(cfg), C.byref(h)), "nmma_em_create")
         self._handle = h
@@ -471,6 +473,35 @@ class EMEngine:
         L.check(self._lib.nmma_em_loglike_lc_sets(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0), ptrs, len(lcs),
                                                   C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
                                                   self._stream()), "nmma_em_loglike_lc_sets")
+        return out
+
+    def loglike_stack2(self, theta, lc2, bad_rows=None, out=None, stream=None):
+        """logL of the COMBINED model {this engine's surrogate + a second transient} in one launch: ``lc2[B, M, NS]`` are the second
+        transient's source-frame curves on this engine's sample_times and model filters; the flux sum is formed on the two nodes
+        every datum interpolates between (``nmma_em_loglike_stack2``).  Returns None when the handle has no one-launch form (not
+        created with ``stack_operands=1``, or a configuration outside it): the caller then materialises the surrogate's curves
+        (``model_lightcurves``) and takes ``loglike_lc_sets`` on a likelihood-from-curves engine."""
+        import torch
+        t = self._dev_theta(theta)
+        shape = (t.shape[0], len(self.model_filters), self.n_sample_times)
+        lc2 = lc2.to(device=t.device, dtype=torch.float64).contiguous()
+        if tuple(lc2.shape) != shape:
+            raise L.NMMAHipError(f"lc2 must be [B, M, NS] = {shape}, got {tuple(lc2.shape)}")
+        bad = None
+        if bad_rows is not None:
+            bad = bad_rows.to(device=t.device, dtype=torch.uint8).contiguous()
+            if tuple(bad.shape) != (t.shape[0],):
+                raise L.NMMAHipError("bad_rows must be [B]")
+        if out is None:
+            out = torch.empty(t.shape[0], dtype=torch.float64, device=t.device)
+        else:
+            self._check_out(out, t.shape[0])
+        status = self._lib.nmma_em_loglike_stack2(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0), C.c_void_p(lc2.data_ptr()),
+                                                  C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
+                                                  self._stream(stream))
+        if status == 2:
+            return None
+        L.check(status, "nmma_em_loglike_stack2")
         return out
 
     def stack(self, lcs):

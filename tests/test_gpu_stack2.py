@@ -1,0 +1,194 @@
+"""The combined model of two transients in ONE launch (``nmma_em_loglike_stack2``: ``em_logl<.., 7>`` takes the second transient's
+curves as an operand and forms the flux sum on the two nodes every datum interpolates between) -- against the golden log L of
+the reference's own CombinedLightCurveModelContainer (nmma/em/model.py:1411-1510), against the materialising path
+(``em_fused<MODE_LC_ABS>`` -> ``em_lc_loglike``), with gaps / edges / failed rows in the second transient's curves, and the
+conditions under which a handle has no one-launch form."""
+import numpy as np
+import pytest
+
+from nmma_amd import synthetic as syn
+from tests import cases, cases_combined
+from tests.helpers import SimplePrior, rel_err
+
+pytestmark = pytest.mark.gpu
+FLOOR = -1.7976931348623157e308
+# One-launch form vs materialising path.  NOT bit-identical by construction: the materialising path reconstructs all nodes on the
+# fp64 matrix cores and divides by the SVD-grid spacing (em_fused); the lean task reconstructs the bracket rows as FMA chains and
+# multiplies by the reciprocal spacing (DEVIATIONS.md).  Node magnitudes agree to a few ulp; log L to ~1e-13 relative.
+FUSED_VS_MATERIALISED_RTOL = 1e-10
+
+
+def _engines(case, stack_operands=1, sample_times=None):
+    from nmma_amd.engine import EMEngine
+    st = case["sample_times"] if sample_times is None else sample_times
+    one = EMEngine(case["svd"], case["filters"], case["model_parameters"], case["names"], sample_times=st,
+                   cosmo_grid=case["cosmo_grid"], data=case["data"], observed_filters=case["filters"], stack_operands=stack_operands)
+    kn = EMEngine(case["svd"], case["filters"], case["model_parameters"], case["names"], sample_times=st, cosmo_grid=case["cosmo_grid"])
+    tail = EMEngine(None, case["filters"], [], case["names"], sample_times=st, cosmo_grid=case["cosmo_grid"],
+                    data=case["data"], observed_filters=case["filters"], model_kind="external")
+    return one, kn, tail
+
+
+def _theta(seed, B):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([syn.draw_theta(seed + 1, B, cases_combined.NAMES[:6])[1], rng.uniform(-17.5, -14.0, (B, 1)),
+                           rng.uniform(0.8, 1.6, (B, 1))], axis=1)
+
+
+def _plugin(case):
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"], model_parameters=case["model_parameters"],
+                            sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"])
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(case["filters"], error_budget=1.0, light_curve_times=times)
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    return EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors, filters=case["filters"])
+
+
+def test_golden_combined_goes_through_the_one_launch_form():
+    """The reference's combined model (golden ``combined``: its own container on the imported source) through the plugin: the
+    likelihood picks the one-launch engine (two sub-models on one grid), never builds the likelihood-from-curves engine, and
+    matches the golden log L at 1e-6; the materialising path on the same inputs agrees with it to 1e-10."""
+    import torch
+    case = cases_combined.case_combined()
+    gold = cases.load_golden("combined")
+    _, grb_oracle = cases_combined.oracle_likelihood(case)
+    lik = _plugin(case)
+    st = case["sample_times"]
+    ext = np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), st)[f] for f in case["filters"]])
+                    for row in case["theta"]])
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and sub._engine is None and not sub._stack2_off        # the one-launch engine, and only it
+    err = rel_err(got, gold["logl"])
+    print(f"combined through em_logl<.., 7>: max rel err vs the reference {err.max():.3e}")
+    assert np.array_equal(got == FLOOR, gold["logl"] == FLOOR) and err.max() <= 1e-6
+    sub._stack2_off = True                                                                 # force the materialising path
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    assert sub._engine is not None
+    assert rel_err(got, mat).max() <= FUSED_VS_MATERIALISED_RTOL
+    # a sub-model without a light curve for some rows (model.py:1423-1426): floor, the other rows untouched
+    sub._stack2_off = False
+    ok = np.ones(len(ext), dtype=bool)
+    ok[[3, 17]] = False
+    got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
+    assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+@pytest.mark.parametrize("B", [1, 5, 16, 17, 333, 4100])
+def test_one_launch_against_materialised_with_gaps_and_edges(B):
+    """Second-transient curves with everything the operand contract allows: finite, +inf at the first / last nodes (the edge of its
+    time range: handled in the task), +inf over the first three nodes, NaN / inf holes in the middle (gaps autocomplete_data fills),
+    a curve without any finite node.  Rows that met an interior non-finite node are re-evaluated by the materialising kernels in
+    the same call: the SAME bits as the materialising path; every other row agrees to 1e-10."""
+    import torch
+    case = cases_combined.case_combined()
+    one, kn, tail = _engines(case)
+    M, NS = len(case["filters"]), len(case["sample_times"])
+    rng = np.random.default_rng(700 + B)
+    theta = _theta(70 + B, B)
+    th = torch.as_tensor(theta, device="cuda:0")
+    lc2 = rng.uniform(-17.0, -12.0, (B, M, NS))
+    kind = rng.integers(0, 6, B)                       # 0, 1: all finite; 2: first node inf; 3: first three; 4: holes; 5: last node + a dark curve
+    lc2[kind == 2, :, 0] = np.inf
+    lc2[kind == 3, :, :3] = np.inf
+    holes = (rng.uniform(size=lc2.shape) < 0.04) & (kind == 4)[:, None, None]
+    lc2[holes] = rng.choice([np.inf, np.nan, -np.inf], size=int(holes.sum()))
+    lc2[kind == 5, :, NS - 1] = np.inf
+    lc2[kind == 5, 1, :] = np.inf
+    lc2_t = torch.as_tensor(lc2, device="cuda:0")
+    got = one.loglike_stack2(th, lc2_t)
+    assert got is not None
+    one.check()
+    want = tail.loglike_lc_sets(th, [kn.model_lightcurves(th), lc2_t])
+    got, want = got.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(got == FLOOR, want == FLOOR)
+    fin = want > FLOOR
+    assert rel_err(got[fin], want[fin]).max() <= FUSED_VS_MATERIALISED_RTOL if fin.any() else True
+    # the rows the kernel flagged carry the materialising kernels' own values (which rows those are follows from the data: a
+    # non-finite node strictly inside the grid that a datum's bracket touches -- rows of kind 3 and 4 are the candidates)
+    cand = np.isin(kind, (3, 4))
+    exact = got == want
+    print(f"B={B}: {int((~exact).sum())} rows differ in the last bits, {int(cand.sum())} candidates for re-evaluation, "
+          f"max rel {rel_err(got[fin], want[fin]).max() if fin.any() else 0:.2e}")
+    if B >= 333:
+        assert exact[kind == 4].mean() > 0.5           # most rows with holes met one and were re-evaluated: bit-identical
+    # a sub-model failure flag floors the row whatever its curves hold
+    bad = torch.zeros(B, dtype=torch.bool, device="cuda:0")
+    bad[B // 2] = True
+    flagged = one.loglike_stack2(th, lc2_t, bad).cpu().numpy()
+    assert flagged[B // 2] == FLOOR
+    keep = np.arange(B) != B // 2
+    assert np.array_equal(flagged[keep], got[keep])
+    for e in (one, kn, tail):
+        e.close()
+
+
+def test_one_launch_properties_and_batch_independence():
+    """Determinism, permutation equivariance and independence of the batch size / tile geometry (16-sample tiles up to 4096 rows,
+    32-sample tiles beyond) -- also for rows that are re-evaluated."""
+    import torch
+    case = cases_combined.case_combined()
+    one, kn, tail = _engines(case)
+    M, NS = len(case["filters"]), len(case["sample_times"])
+    B = 5000
+    rng = np.random.default_rng(9)
+    theta = _theta(91, B)
+    lc2 = rng.uniform(-17.0, -12.0, (B, M, NS))
+    lc2[::7, :, 0] = np.inf
+    lc2[3::11, 2, 10] = np.nan
+
+    def fn(rows):
+        return one.loglike_stack2(torch.as_tensor(theta[rows], device="cuda:0"), torch.as_tensor(lc2[rows], device="cuda:0")).cpu().numpy()
+    rows = np.arange(B)
+    a = fn(rows)
+    assert np.array_equal(a, fn(rows))
+    perm = rng.permutation(B)
+    assert np.array_equal(fn(perm), a[perm])
+    for n in (1, 100, 777, 4096):
+        assert np.array_equal(fn(rows[:n]), a[:n]), n
+    for e in (one, kn, tail):
+        e.close()
+
+
+def test_handles_without_a_one_launch_form_say_so():
+    """``loglike_stack2`` returns None (the library: 2, nothing launched) for a handle not created for it, for sample_times that
+    reach beyond the surrogate's grid (the flux sum is then finite where the kilonova is not: the task's window test would be
+    wrong), and for unequally spaced sample_times; the plugin then takes the materialising path and says so once."""
+    import torch
+    case = cases_combined.case_combined()
+    M = len(case["filters"])
+    th = torch.as_tensor(_theta(5, 8), device="cuda:0")
+    one, kn, tail = _engines(case, stack_operands=0)
+    assert one.loglike_stack2(th, torch.zeros((8, M, len(case["sample_times"])), dtype=torch.float64, device="cuda:0")) is None
+    for e in (one, kn, tail):
+        e.close()
+    tt_end = float(np.max(next(iter(case["svd"].values()))["tt"]))
+    beyond = np.arange(0.1, tt_end + 3.0, 0.5)
+    one, kn, tail = _engines(case, sample_times=beyond)
+    assert one.loglike_stack2(th, torch.zeros((8, M, len(beyond)), dtype=torch.float64, device="cuda:0")) is None
+    for e in (one, kn, tail):
+        e.close()
+    logt = np.geomspace(0.1, 20.0, 40)
+    one, kn, tail = _engines(case, sample_times=logt)
+    assert one.loglike_stack2(th, torch.zeros((8, M, len(logt)), dtype=torch.float64, device="cuda:0")) is None
+    for e in (one, kn, tail):
+        e.close()
+
+
+def test_union_grid_combination_keeps_the_materialising_path():
+    """Sub-models with different grids / filter lists (golden ``combined_union``) have no one-launch plan."""
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    case = cases_combined.case_combined_union()
+    kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"], model_parameters=case["model_parameters"],
+                            sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", case["grb_filters"], case["grb_times"])
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
+    assert comb.stack2_plan() is None
+    same = CombinedLightCurveModelContainer([kn, ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"])],
+                                            cosmo_grid=case["cosmo_grid"])
+    assert same.stack2_plan() is not None and same.stack2_plan()[0] is kn

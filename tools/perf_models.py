@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Exercise the kernels beyond em_logl under a profiler: me2017_lc + em_lc_loglike (config 1, B = 128 and 8192),
+"""Exercise the kernels beyond em_logl under a profiler (config 3 also in ONE launch: nmma_em_loglike_stack2): me2017_lc + em_lc_loglike (config 1, B = 128 and 8192),
 lc_stack_kernel + em_fused<MODE_LC_ABS> + em_lc_loglike (config 3 shape, B = 8192), em_fused coefficient / light-curve
 outputs (B = 4096).  Prints wall times per call (torch events)."""
 import os
@@ -66,6 +66,18 @@ def combined_materialised():       # round 3's form: lc_stack_kernel writes the 
     lc = kn.model_lightcurves(t)
     return tail.loglike_lc(t, tail.stack([lc, ext]))
 
+
+# the one-launch form (round 5): the surrogate engine carries the photometry and takes the second transient's curves as an operand
+one = EMEngine(c3["svd"], c3["filters"], c3["model_parameters"], c3["names"], sample_times=c3["sample_times"], cosmo_grid=c3["cosmo_grid"],
+               data=c3["data"], observed_filters=c3["filters"], stack_operands=1)
+assert one.loglike_stack2(t, ext) is not None
+ref = combined()
+got = one.loglike_stack2(t, ext)
+rel = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+print(f"config 3 shape B={B}: ONE launch (em_logl<.., 7> + two restricted re-evaluation launches) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call; "
+      f"max rel diff to the materialising path {rel:.2e}")
+os.environ["NMMA_STACK2_NO_FIXUP"] = "1"      # (read once per process by the library: measured in a child process below)
+one.close()
 
 lc_fixed = kn.model_lightcurves(t)
 stacked = tail.stack([lc_fixed, ext])
