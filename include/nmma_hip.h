@@ -499,6 +499,13 @@ typedef struct nmma_walk_queue {
     double gpu_ms;                   /* out: upload .. download complete, HIP events */
 } nmma_walk_queue;
 int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream);
+/* The same call in two halves, for a queue SHARDED over several devices from one host thread (the reference spreads the chains of a
+ * queue over its MPI ranks, core/mpi_setup.py:651-667, :679-683; chains are independent and the live set is read-only, so the queue
+ * shards like a batch -- counter-based random numbers make a chain's path independent of the shard it lands in): begin packs, uploads
+ * and enqueues the whole step loop and the download on `stream` of the workspace's device and returns without waiting; end waits,
+ * unpacks into q's output arrays (the same record that was begun) and checks the handle.  One queue in flight per workspace. */
+int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma_walk_queue* q, void* stream);
+int32_t nmma_em_walk_queue_end(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q);
 
 /* MultiMessengerLikelihood.sub_log_likelihood for a batch (joint/joint_likelihood.py:62-67): out_dev[b] = sum_k parts[k][b] in
  * messenger order, NMMA_LOGL_FLOOR where the sum is not finite or a messenger already returned the floor.

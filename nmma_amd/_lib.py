@@ -181,6 +181,8 @@ PROTOTYPES = {
     "nmma_walk_ws_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
     "nmma_walk_ws_destroy": (None, [C.c_void_p]),
     "nmma_em_walk_queue": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue), C.c_void_p]),
+    "nmma_em_walk_queue_begin": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue), C.c_void_p]),
+    "nmma_em_walk_queue_end": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue)]),
     "nmma_gw_create": (C.c_int32, [C.POINTER(GwConfig), C.POINTER(C.c_void_p)]),
     "nmma_gw_destroy": (None, [C.c_void_p]),
     "nmma_gw_loglike": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -202,12 +202,14 @@ class NMMALikelihoodMixin:
         key = (constraint_signature(self._constraints), tuple(names), tuple(sorted((k, float(v)) for k, v in (fixed or {}).items())),
                int(device))
         cache = self.__dict__.setdefault("_con_programs", {})
-        if key not in cache:
-            if len(cache) >= 8:
-                for prog in cache.values():
-                    if prog is not None:
-                        prog.close()
-                cache.clear()
+        if key in cache:
+            cache[key] = cache.pop(key)           # (most recently used last)
+        else:
+            # least recently used out, ONE entry at a time and never closed here: a program handed to a pool or a walk may still be
+            # in use (a closed handle would make the walk run unconstrained); it frees its device memory when the last reference
+            # goes (ConstraintProgram.__del__).  64 entries: 8 devices x a few column layouts.
+            while len(cache) >= 64:
+                cache.pop(next(iter(cache)))
             ops = trace_constraints(self._constraints, list(names), fixed, self.conversion_chain())
             cache[key] = ConstraintProgram(ops, len(names), device) if ops else None
         return cache[key]

@@ -385,6 +385,11 @@ struct nmma_walk_ws {
     unsigned char* dev = nullptr;
     unsigned char* pin = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // a queue enqueued by nmma_em_walk_queue_begin and not yet collected by nmma_em_walk_queue_end
+    bool pending = false;
+    hipStream_t pend_stream = nullptr;
+    long pend_n = 0, pend_d = 0;
+    size_t pend_u = 0, pend_v = 0, pend_logl = 0, pend_cnt = 0;
 };
 
 int32_t nmma_walk_ws_create(int32_t device, nmma_walk_ws** out) {
@@ -409,9 +414,13 @@ void nmma_walk_ws_destroy(nmma_walk_ws* ws) {
     delete ws;
 }
 
-int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream) {
+// nmma_em_walk_queue in two halves, so that ONE host thread can keep several devices busy (a queue sharded over the devices'
+// handles: begin on every device, then end on every device).  begin packs and uploads, enqueues the whole step loop and the
+// download on `stream` and returns without waiting; end waits for that stream, unpacks into q's output arrays and checks the handle.
+int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma_walk_queue* q, void* stream) {
     using namespace nmma;
     if (!h || !ws || !q) return fail("nmma_em_walk_queue: null argument");
+    if (ws->pending) return fail("nmma_em_walk_queue_begin: the workspace already holds a queue that was not collected (nmma_em_walk_queue_end)");
     WalkSpec S;
     if (walk_spec(q->priors, q->ndim, &S, "nmma_em_walk_queue")) return 1;
     const long n = (long)q->n, D = q->ndim, NL = (long)q->n_live;
@@ -421,8 +430,8 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     if (nmma_em_device(h) != ws->device) return fail("nmma_em_walk_queue: the workspace belongs to another device than the likelihood handle");
     if (q->constraints && (q->constraints->device != ws->device || q->constraints->n_cols > D))
         return fail("nmma_em_walk_queue: the constraint program belongs to another device or reads columns the walk does not sample");
-    q->gpu_ms = 0.0;
-    if (n == 0) return 0;
+    ws->pend_n = n; ws->pend_d = D; ws->pend_stream = static_cast<hipStream_t>(stream);
+    if (n == 0) { ws->pending = true; return 0; }
     if (hipSetDevice(ws->device) != hipSuccess) return fail("nmma_em_walk_queue: hipSetDevice failed");
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -525,16 +534,38 @@ int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue*
     NMQ(hipGetLastError(), "launch");
     NMQ(hipMemcpyAsync(p + o_u, d + o_u, down_end - o_u, hipMemcpyDeviceToHost, s), "download");
     NMQ(hipEventRecord(ws->ev1, s), "event");
-    NMQ(hipStreamSynchronize(s), "stream");
+    ws->pend_u = o_u; ws->pend_v = o_v; ws->pend_logl = o_logl; ws->pend_cnt = o_cnt;
+    ws->pending = true;
+    return 0;
+}
+
+int32_t nmma_em_walk_queue_end(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q) {
+    using namespace nmma;
+    if (!h || !ws || !q) return fail("nmma_em_walk_queue_end: null argument");
+    if (!ws->pending) return fail("nmma_em_walk_queue_end: no queue was begun on this workspace");
+    ws->pending = false;
+    q->gpu_ms = 0.0;
+    const long n = ws->pend_n, D = ws->pend_d;
+    if (n == 0) return 0;
+    if (n != (long)q->n || D != q->ndim || !q->u || !q->v || !q->logl || !q->counts)
+        return fail("nmma_em_walk_queue_end: the queue record does not match the one that was begun");
+    if (hipSetDevice(ws->device) != hipSuccess) return fail("nmma_em_walk_queue_end: hipSetDevice failed");
+    NMQ(hipStreamSynchronize(ws->pend_stream), "stream");
     float ms = 0.f;
     NMQ(hipEventElapsedTime(&ms, ws->ev0, ws->ev1), "event time");
 #undef NMQ
     q->gpu_ms = ms;
-    memcpy(q->u, p + o_u, sizeof(double) * n * D);
-    memcpy(q->v, p + o_v, sizeof(double) * n * D);
-    memcpy(q->logl, p + o_logl, sizeof(double) * n);
-    memcpy(q->counts, p + o_cnt, sizeof(int32_t) * 4 * n);
+    const unsigned char* p = ws->pin;
+    memcpy(q->u, p + ws->pend_u, sizeof(double) * n * D);
+    memcpy(q->v, p + ws->pend_v, sizeof(double) * n * D);
+    memcpy(q->logl, p + ws->pend_logl, sizeof(double) * n);
+    memcpy(q->counts, p + ws->pend_cnt, sizeof(int32_t) * 4 * n);
     return nmma_em_check(h) ? 1 : 0;
+}
+
+int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream) {
+    if (nmma_em_walk_queue_begin(h, ws, q, stream)) return 1;
+    return nmma_em_walk_queue_end(h, ws, q);
 }
 
 }  // extern "C"

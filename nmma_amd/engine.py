@@ -577,11 +577,16 @@ class EMEngine:
         L.check(self._lib.nmma_em_check(self._handle), "nmma_em_check")
 
     def walk_queue(self, table, live, u0, loglstar, keys, walks, constraints=None, first_step=1, stream=None):
-        """One queue of the nested sampler -- ``len(u0)`` chains of the fixed-length ensemble walk, ``walks`` steps each (an int
-        or one length per chain) -- in ONE library call (``nmma_em_walk_queue``): packed upload, per step the likelihood launch
-        and accept + next proposal, fresh prior draws for chains that never moved, packed download.  Host arrays in and out:
-        ``(u[n, D], v[n, D], logl[n], counts[n, 4] = accept, reject, outside-the-cube, likelihood calls)``; ``self.last_walk_gpu_ms``
-        holds the device time of the call.  ``constraints``: a ``nmma_amd.core.constraints.ConstraintProgram`` or None."""
+        """One queue of the nested sampler in ONE library call (``nmma_em_walk_queue``): ``table`` = ``device_prior_table``'s array of
+        ``WalkPrior``, ``live[n_live, D]`` the unit-cube live points, ``u0[n, D]`` the chains' start points, ``loglstar`` (scalar or
+        [n]) their likelihood bounds, ``keys[n]`` their random-number keys, ``walks`` (int or [n]) their lengths, ``constraints`` a
+        :class:`nmma_amd.core.constraints.ConstraintProgram` or None.  Returns ``(u, v, logl, counts[n, 4])`` as numpy arrays."""
+        return self.walk_queue_end(self.walk_queue_begin(table, live, u0, loglstar, keys, walks, constraints, first_step, stream))
+
+    def walk_queue_begin(self, table, live, u0, loglstar, keys, walks, constraints=None, first_step=1, stream=None):
+        """First half of :meth:`walk_queue` (``nmma_em_walk_queue_begin``): packs, uploads and enqueues the whole queue on this engine's
+        device and returns a token WITHOUT waiting -- a queue sharded over several devices is begun on every engine, then collected
+        with :meth:`walk_queue_end` (``GPUPool(devices=[...])``).  One queue in flight per engine."""
         import torch
         live, u0 = _f64(live), _f64(u0)
         n, ndim = u0.shape
@@ -594,6 +599,9 @@ class EMEngine:
         wl = np.ascontiguousarray(walks, dtype=np.int32) if per_chain else None
         if keys.shape != (n,) or (per_chain and wl.shape != (n,)):
             raise L.NMMAHipError("walk_queue: one key (and walk length) per chain")
+        if constraints is not None and constraints.handle is None:
+            # (a closed program would silently run the walk unconstrained)
+            raise L.NMMAHipError("walk_queue: the constraint program has been closed")
         if getattr(self, "_walk_ws", None) is None:
             ws = C.c_void_p()
             L.check(self._lib.nmma_walk_ws_create(self.device, C.byref(ws)), "nmma_walk_ws_create")
@@ -608,9 +616,15 @@ class EMEngine:
         q.constraints = constraints.handle if constraints is not None else None
         q.u, q.v, q.logl, q.counts = u.ctypes.data, v.ctypes.data, logl.ctypes.data, counts.ctypes.data
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        L.check(self._lib.nmma_em_walk_queue(self._handle, self._walk_ws, C.byref(q), C.c_void_p(s.cuda_stream)), "nmma_em_walk_queue")
+        L.check(self._lib.nmma_em_walk_queue_begin(self._handle, self._walk_ws, C.byref(q), C.c_void_p(s.cuda_stream)), "nmma_em_walk_queue_begin")
+        # (everything the library reads until `end` stays referenced by the token)
+        return (q, (u, v, logl, counts), (table, live, u0, star, keys, wl, constraints, s))
+
+    def walk_queue_end(self, token):
+        q, outs, _keep = token
+        L.check(self._lib.nmma_em_walk_queue_end(self._handle, self._walk_ws, C.byref(q)), "nmma_em_walk_queue_end")
         self.last_walk_gpu_ms = float(q.gpu_ms)
-        return u, v, logl, counts
+        return outs
 
     def close(self):
         if getattr(self, "_walk_ws", None):

@@ -55,6 +55,54 @@ class ShardedEvaluator:
         return torch.cat(pieces)
 
 
+class ShardedQueue:
+    """One queue of the nested sampler over ``world`` ranks (one process per GPU): ``run(live, u0, loglstar, keys, walks)`` returns
+    ``(u, v, logl, counts)`` for ALL chains on every rank.  Rank r walks the chains ``shard_bounds(n, world, r)`` with
+    ``local_fn(live, u0_shard, loglstar_shard, keys_shard, walks_or_shard)`` -- e.g. ``lambda *a: engine.walk_queue(table, *a)`` --
+    and the shards' records are exchanged with ONE all-gather (RCCL over xGMI with backend ``nccl``; a packed [slot, 2 D + 5]
+    float64 buffer per rank).  The reference spreads a queue's chains over its MPI ranks the same way
+    (``nmma/core/mpi_setup.py:651-667, :679-683``); a chain's path depends on its key only (counter-based random numbers), so the
+    records equal the single-rank queue's."""
+
+    def __init__(self, local_fn, group=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.local_fn = local_fn
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def run(self, live, u0, loglstar, keys, walks):
+        import torch
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        n, ndim = u0.shape
+        star = np.ascontiguousarray(np.broadcast_to(np.asarray(loglstar, dtype=np.float64), (n,)))
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        wl = walks if np.ndim(walks) == 0 else np.ascontiguousarray(np.asarray(walks)[lo:hi])
+        if hi > lo:
+            u, v, logl, counts = self.local_fn(live, u0[lo:hi], star[lo:hi], keys[lo:hi], wl)
+        else:
+            u, v, logl, counts = np.empty((0, ndim)), np.empty((0, ndim)), np.empty(0), np.empty((0, 4), dtype=np.int32)
+        if self.world == 1:
+            return u, v, logl, counts
+        slot, width = (n + self.world - 1) // self.world, 2 * ndim + 5
+        mine = np.zeros((slot, width))
+        mine[: hi - lo, :ndim], mine[: hi - lo, ndim:2 * ndim], mine[: hi - lo, 2 * ndim] = u, v, logl
+        mine[: hi - lo, 2 * ndim + 1:] = counts                       # (counts < 2^53: exact in float64)
+        dev = self.device if self.device is not None else "cpu"
+        buf = torch.as_tensor(mine).to(dev)
+        out = torch.empty((self.world * slot, width), dtype=torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(out, buf, group=self.group)
+        full = out.cpu().numpy()
+        rows = np.concatenate([np.arange(r * slot, r * slot + (b - a)) for r, (a, b) in
+                               enumerate(shard_bounds(n, self.world, r) for r in range(self.world))]) if n else np.zeros(0, dtype=int)
+        full = full[rows]
+        return (np.ascontiguousarray(full[:, :ndim]), np.ascontiguousarray(full[:, ndim:2 * ndim]), np.ascontiguousarray(full[:, 2 * ndim]),
+                np.ascontiguousarray(full[:, 2 * ndim + 1:]).astype(np.int32))
+
+
 class MultiDeviceEvaluator:
     """ONE process driving several GPUs ("single process x 8 devices (ctypes + streams) avoids MPI").
 
@@ -64,12 +112,16 @@ class MultiDeviceEvaluator:
     lives on a GPU), launches all shards asynchronously on per-device streams -- the C ABI only enqueues, so one host thread
     keeps every device busy -- and gathers the pieces on ``devices[0]``.  No collective library is involved."""
 
-    def __init__(self, engine_factory, devices):
+    def __init__(self, engine_factory, devices, engines=None):
+        """``engines``: ready-made engines, one per entry of ``devices`` (they stay the caller's: ``close`` leaves them alone)."""
         import torch
         self.devices = [int(d) for d in devices]
         if not self.devices:
             raise ValueError("MultiDeviceEvaluator needs at least one device")
-        self.engines = [engine_factory(d) for d in self.devices]
+        self._own = engines is None
+        self.engines = [engine_factory(d) for d in self.devices] if engines is None else list(engines)
+        if len(self.engines) != len(self.devices):
+            raise ValueError("one engine per device")
         self.streams = [torch.cuda.Stream(device=d) for d in self.devices]
 
     def evaluate(self, theta):
@@ -104,6 +156,8 @@ class MultiDeviceEvaluator:
         return out
 
     def close(self):
+        if not self._own:
+            return
         for eng in self.engines:
             if hasattr(eng, "close"):
                 eng.close()

@@ -22,8 +22,16 @@ import numpy as np
 
 
 class GPUPool:
-    def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None, priors=None, device=0, device_walk=True):
+    def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None, priors=None, device=0, device_walk=True,
+                 devices=None):
+        """``devices``: several HIP devices driven from this one process (e.g. ``range(8)``) -- a queue of the device walk and a
+        batch of ``log_likelihood`` calls are then SHARDED over them, contiguous balanced shards with the live set replicated, as
+        the reference's task farm spreads a queue's chains over its MPI ranks (core/mpi_setup.py:651-667, :679-683); results come
+        back in queue order and are the single-device results bit for bit.  Default: the likelihood's own device only."""
         self.likelihood = likelihood
+        self.devices = [int(d) for d in devices] if devices is not None else None
+        self._shard_engines = None        # [(engine, constraint program)] per entry of `devices`, built on first use
+        self._evaluator = None
         self.size = int(queue_size)
         self.names = names
         self.prior_transform_many = prior_transform_many     # e.g. nmma_amd.sampler.BatchedPriorTransform
@@ -47,6 +55,11 @@ class GPUPool:
         return None
 
     def close(self):
+        if self._shard_engines:
+            for eng, _ in self._shard_engines[1:]:        # (the first one belongs to the likelihood)
+                eng.close()
+        self._shard_engines = None
+        self._evaluator = None
         return None
 
     def __enter__(self):
@@ -66,7 +79,15 @@ class GPUPool:
             theta = np.ascontiguousarray(thetas, dtype=float)          # (the lock-step walker hands over arrays)
         else:
             theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
-        out = self.likelihood.log_likelihood_batch(theta, self.names)
+        shards = self._walk_engines() if self.devices is not None and len(self.devices) > 1 else None
+        if shards and all(prog is None for _, prog in shards):
+            # several devices: row shards launched asynchronously on every device, gathered on the first (no collective library)
+            if self._evaluator is None:
+                from .parallel import MultiDeviceEvaluator
+                self._evaluator = MultiDeviceEvaluator(None, [e.device for e, _ in shards], engines=[e for e, _ in shards])
+            out = self._evaluator.evaluate(theta).cpu().numpy()
+        else:
+            out = self.likelihood.log_likelihood_batch(theta, self.names)
         self.n_batches += 1
         self.n_evals += len(theta)
         return np.asarray(out)
@@ -96,6 +117,32 @@ class GPUPool:
                 return None, None
         return eng, prog
 
+    def _walk_engines(self):
+        """One (engine, constraint program) per entry of ``devices`` (the likelihood's own engine first; further engines are copies
+        of it on the other devices -- or on the same one, which is how the sharding is tested on a single GPU); None when the
+        likelihood has no single-engine form."""
+        if self._shard_engines is not None:
+            return self._shard_engines
+        eng, prog = self._walk_engine()
+        if eng is None:
+            return None
+        lik, sub = self.likelihood, self.likelihood.sub_model
+        names = list(self.names)
+        shards = [(eng, prog)]
+        for d in (self.devices or [eng.device])[1:]:
+            model = sub.light_curve_model
+            e = sub._build_engine(names, model.gpu_filters, dict(model.engine_kwargs(), device=int(d)))
+            p = None
+            if getattr(lik, "constraints", None):
+                _, fixed = sub.sampling_layout()
+                p = lik.device_constraints(names, {k: v for k, v in fixed.items() if k not in names}, int(d))
+                if p is None:
+                    e.close()
+                    return None
+            shards.append((e, p))
+        self._shard_engines = shards
+        return shards
+
     def map(self, func, iterable, callback=None):
         from .sampler import SamplerArgumentBatch
         items = iterable if isinstance(iterable, (list, SamplerArgumentBatch)) else list(iterable)
@@ -111,6 +158,10 @@ class GPUPool:
                 kw = {}
                 if "engine" in walker.run_many_device.__code__.co_varnames:
                     kw["engine"], kw["constraints"] = self._walk_engine()
+                    if kw["engine"] is not None and self.devices is not None and len(self.devices) > 1:
+                        shards = self._walk_engines()
+                        if shards is not None:
+                            kw["engine"], kw["constraints"] = shards, None
                 res = walker.run_many_device(items, self._log_likelihood_device, self.priors, self.names, device=self.device,
                                              loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many, **kw)
                 self.n_batches += getattr(walker, "n_batches", 0)

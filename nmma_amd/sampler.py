@@ -608,7 +608,26 @@ class EnsembleWalkSampler(_LockstepWalk):
         same = len(set(walks)) == 1
         steps = walks[0] if same else np.array(walks, dtype=np.int32)
         if engine is not None:
-            u, v, logl, counts = engine.walk_queue(table, live, u0, loglstar, rseeds, steps, constraints=constraints)
+            # ``engine``: the EMEngine behind the likelihood, or a list of (engine, constraint program) pairs, one per device -- the
+            # queue is then SHARDED over them (the reference spreads a queue's chains over its MPI ranks, core/mpi_setup.py:651-667,
+            # :679-683): contiguous balanced shards, the live points replicated, every shard's call begun before the first is collected;
+            # a chain's path depends on its key only, so the result is the single-device queue's, bit for bit
+            shards = list(engine) if isinstance(engine, (list, tuple)) else [(engine, constraints)]
+            if len(shards) == 1:
+                u, v, logl, counts = shards[0][0].walk_queue(table, live, u0, loglstar, rseeds, steps, constraints=shards[0][1])
+            else:
+                from .parallel import shard_bounds
+                u0 = np.ascontiguousarray(u0, dtype=float)
+                star = np.ascontiguousarray(np.broadcast_to(np.asarray(loglstar, dtype=float), (n,)))
+                keys_all = np.ascontiguousarray(rseeds, dtype=np.uint64)
+                begun = []
+                for r, (eng_r, con_r) in enumerate(shards):
+                    lo, hi = shard_bounds(n, len(shards), r)
+                    if hi > lo:
+                        st = steps if same else np.ascontiguousarray(steps[lo:hi])
+                        begun.append((eng_r, eng_r.walk_queue_begin(table, live, u0[lo:hi], star[lo:hi], keys_all[lo:hi], st, constraints=con_r)))
+                parts = [eng_r.walk_queue_end(tok) for eng_r, tok in begun]
+                u, v, logl, counts = (np.concatenate([p[i] for p in parts]) for i in range(4))
             self.n_batches, self.n_evals = max(walks) + int(np.any(counts[:, 0] == 0)), int(counts[:, 3].sum())
         else:
             u, v, logl, counts = device_walk(table, live, u0, loglstar, rseeds, steps, loglike_device, device=device)

@@ -58,6 +58,8 @@ def test_config3_combined_kn_plus_grb_at_8192():
 
     a = _properties(fn, theta, 1000)
     assert np.all(a <= 0) and np.mean(a > FLOOR) > 0.9
+    # two sub-models on one grid: ONE launch (em_logl<.., 7>, nmma_em_loglike_stack2), the likelihood-from-curves engine never built
+    assert lik.sub_model._engine2 is not None and lik.sub_model._engine is None
     olik, _ = cases_combined.oracle_likelihood(case, use_scipy=False)
     rows = np.linspace(0, B - 1, 64).astype(int)
     want = orc.log_likelihood_batch(olik, case["names"], theta[rows])

@@ -166,6 +166,91 @@ def test_pool_map_on_the_argument_batch_returns_array_backed_records(torch_cuda,
     assert _same(slow.u, got.u) and _same(slow.logl, got.logl) and np.array_equal(slow.accept, got.accept)
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0, 0]])
+def test_queue_sharded_over_engines_is_the_single_device_queue(torch_cuda, config2, devices):
+    """``GPUPool(devices=[...])`` shards a queue over one engine per entry -- contiguous balanced shards, the live set replicated,
+    every shard's ``nmma_em_walk_queue_begin`` issued before the first ``..._end`` (core/mpi_setup.py:651-667, :679-683: the
+    reference spreads a queue's chains over its ranks).  Tested with several engines on the ONE device a test box has: ragged
+    splits, equal and per-chain walk lengths, a constrained prior set -- records identical to the single-device queue, bit for
+    bit, in queue order; ``log_likelihood`` batches take the same shards."""
+    from nmma_amd.pool import GPUPool
+    case, lik, names, pri = config2
+    pt = smp.BatchedPriorTransform(pri, names)
+    rng = np.random.default_rng(40 + len(devices))
+    for n, walks in ((1, 5), (7, 6), (701, 9), (4096, 4)):
+        live = rng.uniform(0.3, 0.7, (max(n, 50), len(names)))
+        w = smp.EnsembleWalkSampler(ndim=len(names), walks=walks, naccept=5)
+
+        class _NS:
+            live_u = live
+        seeds = rng.integers(1, 2 ** 62, n)
+        bound = float(np.quantile(lik.log_likelihood_batch(pt(live), names), 0.25))
+        batch = w.prepare_sampler(loglstar=bound, points=live[:n].copy(), axes=None, seeds=seeds, prior_transform=pt, loglikelihood=None,
+                                  nested_sampler=_NS)
+        one = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri)
+        many = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri, devices=devices)
+        ref, got = one.map(w.sample, batch), many.map(w.sample, batch)
+        assert len(many._shard_engines) == len(devices) and many._shard_engines[0][0] is lik.sub_model.engine(names)
+        assert _same(got.u, ref.u) and _same(got.v, ref.v) and _same(got.logl, ref.logl)
+        assert np.array_equal(got.ncall, ref.ncall) and np.array_equal(got.accept, ref.accept)
+        theta = pt(rng.uniform(0.2, 0.8, (n, len(names))))
+        assert np.array_equal(many.log_likelihood_many(theta), one.log_likelihood_many(theta))
+        many.close()
+    # per-chain walk lengths through the walker's own entry point, a list of (engine, program) shards
+    n = 333
+    eng = lik.sub_model.engine(names)
+    extra = [lik.sub_model._build_engine(names, lik.sub_model.light_curve_model.gpu_filters, lik.sub_model.light_curve_model.engine_kwargs())
+             for _ in devices[1:]]
+    table = smp.device_prior_table(pri, names)
+    live = rng.uniform(0.3, 0.7, (400, len(names)))
+    u0 = live[rng.integers(0, 400, n)].copy()
+    bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.3))
+    keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
+    steps = (2 + np.arange(n) % 7).astype(np.int32)
+    ref = eng.walk_queue(table, live, u0, bound, keys, steps)
+    from nmma_amd.parallel import shard_bounds
+    shards = [eng] + extra
+    toks = []
+    for r, e in enumerate(shards):
+        lo, hi = shard_bounds(n, len(shards), r)
+        toks.append(e.walk_queue_begin(table, live, u0[lo:hi], bound[lo:hi], keys[lo:hi], np.ascontiguousarray(steps[lo:hi])))
+    parts = [e.walk_queue_end(t) for e, t in zip(shards, toks)]
+    for i in range(4):
+        assert _same(np.concatenate([p[i] for p in parts]), ref[i])
+    # one queue in flight per engine: a second begin without end is refused
+    tok = eng.walk_queue_begin(table, live, u0, bound, keys, 3)
+    with pytest.raises(Exception, match="not collected"):
+        eng.walk_queue_begin(table, live, u0, bound, keys, 3)
+    eng.walk_queue_end(tok)
+    for e in extra:
+        e.close()
+
+
+def test_constrained_queue_sharded_over_engines(torch_cuda, config2):
+    """A constrained prior set: every shard gets the constraint program of its device; rows that violate it count as evaluated."""
+    from nmma_amd.pool import GPUPool
+    case, _, names, pri = config2
+    _, _, lik = plugin_from_case(case)
+    lik.constraints["log10_mej_dyn"] = Constraint(minimum=-2.6, maximum=-1.3, name="log10_mej_dyn")
+    pt = smp.BatchedPriorTransform(pri, names)
+    rng = np.random.default_rng(77)
+    n, walks = 500, 8
+    live = rng.uniform(0.3, 0.7, (n, len(names)))
+    w = smp.EnsembleWalkSampler(ndim=len(names), walks=walks, naccept=5)
+
+    class _NS:
+        live_u = live
+    seeds = rng.integers(1, 2 ** 62, n)
+    bound = float(np.quantile(lik.log_likelihood_batch(pt(live), names), 0.25))
+    batch = w.prepare_sampler(loglstar=bound, points=live.copy(), axes=None, seeds=seeds, prior_transform=pt, loglikelihood=None, nested_sampler=_NS)
+    one = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri)
+    many = GPUPool(lik, queue_size=n, names=names, prior_transform_many=pt, priors=pri, devices=[0, 0, 0])
+    ref, got = one.map(w.sample, batch), many.map(w.sample, batch)
+    assert all(prog is not None for _, prog in many._shard_engines)
+    assert _same(got.u, ref.u) and _same(got.logl, ref.logl) and np.array_equal(got.ncall, ref.ncall)
+    many.close()
+
+
 def test_new_prior_transforms_match_bilbys_formulas(torch_cuda):
     """TruncatedGaussian (priors/Sr2023.prior), LogNormal, HalfGaussian: ``rescale`` as bilby/core/prior/analytical.py defines them."""
     torch = torch_cuda
