@@ -459,10 +459,10 @@ void nmma_walk_ws_destroy(nmma_walk_ws* ws);
 /* The MCMC step as ONE launch: the likelihood kernel's workgroup owns the chains whose log L it has just summed, so the accept of
  * step `step` and the proposal of step `step + 1` (nmma_walk_step) can run in its epilogue and leave the tile's theta rows ready for
  * the next launch.  `wf_dev`: a DEVICE copy of this struct (pointers to the chains' state, as for nmma_walk_step; theta is the
- * launch's own theta_dev, which the kernel then WRITES).  last != 0: accept only (the walk's final step).  Returns 2 -- nothing
- * launched -- when the handle's task flavour has no fused instantiation, or more than 8 dimensions / 4096 chains (the caller then takes
- * nmma_em_loglike + nmma_walk_step); Constraint programs are NOT evaluated by the fused step (n_con_ops must be 0: their interpreter does
- * not fit the likelihood kernel's register budget);
+ * launch's own theta_dev, which the kernel then WRITES).  last != 0: accept only (the walk's final step).  n_con_ops: the host's copy
+ * of wf_dev->n_con_ops (> 0: the chains' Constraint program is evaluated in the step, on an fp64 stack in LDS).  Returns 2 --
+ * nothing launched -- when the handle's task flavour has no fused instantiation (for constrained sets: the general and the dense
+ * lean task), with more than 16 sampled dimensions or more than 4096 chains (the caller then takes nmma_em_loglike + nmma_walk_step);
  * the chains are bit-identical either way. */
 typedef struct nmma_walk_fuse {
     nmma_walk_prior priors[NMMA_WALK_MAX_DIM];
@@ -477,7 +477,7 @@ typedef struct nmma_walk_fuse {
     uint64_t first_step;
 } nmma_walk_fuse;
 int32_t nmma_em_loglike_walk(nmma_em_handle* h, double* theta_dev, int64_t B, int64_t ld, double* out_dev, const nmma_walk_fuse* wf_dev,
-                             uint64_t step, int32_t last, void* stream);
+                             uint64_t step, int32_t last, int32_t n_con_ops, void* stream);
 
 typedef struct nmma_walk_queue {
     const nmma_walk_prior* priors;   /* [ndim] */
@@ -515,6 +515,12 @@ int32_t nmma_logl_sum_floor(const double* const* parts_dev, int32_t n_parts, int
 /* Surrogate output only: coeff_dev[B][M][NC] fp32 (lightcurve_generation.py:198). */
 int32_t nmma_em_coefficients(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld,
                              float* coeff_dev, void* stream);
+
+/* Run-time options of a handle, for A/B measurements and tests (each also has an environment variable that is read once, at
+ * nmma_em_create): "walk_fuse" (NMMA_WALK_NO_FUSE), "walk_split" (NMMA_WALK_NO_SPLIT): 0 / 1; "lc_group" (NMMA_LC_GROUP): 0 = by batch
+ * size, 16 / 32 / 64 lanes per sample of the likelihood-from-curves kernel; "stack2_fixup" (NMMA_STACK2_NO_FIXUP): 0 skips the
+ * re-evaluation launches of nmma_em_loglike_stack2 (measurement only).  Unknown names fail. */
+int32_t nmma_em_set_option(nmma_em_handle* h, const char* name, int32_t value);
 
 /* Introspection used by bench.py / tests. */
 int32_t nmma_em_n_sample_times(const nmma_em_handle* h);

@@ -16,8 +16,9 @@ SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: translation units of the library; every other file under csrc/ and include/ is a dependency of both
 #: translation units of libnmma_hip.so, longest first (they compile concurrently; build_library caps the number in flight).  em_logl's
 #: 38 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s.
-SOURCES = ("em_logl_f5.hip", "em_kernels.hip", "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip",
-           "em_logl_f1.hip", "gw_kernels.hip", "walk_kernels.hip")
+SOURCES = ("em_logl_w3.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_w2.hip", "em_kernels.hip", "em_logl_f5.hip", "em_logl_wc2.hip",
+           "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f1.hip", "gw_kernels.hip",
+           "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
@@ -177,7 +178,8 @@ PROTOTYPES = {
     "nmma_con_create": (C.c_int32, [C.POINTER(ConOp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "nmma_con_destroy": (None, [C.c_void_p]),
     "nmma_con_floor": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    "nmma_em_loglike_walk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p]),
+    "nmma_em_loglike_walk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
+    "nmma_em_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nmma_walk_ws_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
     "nmma_walk_ws_destroy": (None, [C.c_void_p]),
     "nmma_em_walk_queue": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(WalkQueue), C.c_void_p]),
@@ -226,19 +228,33 @@ def build_library(force=False, extra_flags=()):
     objdir = os.path.join(csrc, "build")
     os.makedirs(objdir, exist_ok=True)
     deps_mtime = max(os.path.getmtime(d) for d in _dependencies())
-    objs, procs, rebuilt = [], [], False
+    objs, todo, rebuilt = [], [], False
     for name in SOURCES:
         src = os.path.join(csrc, name)
         obj = os.path.join(objdir, name.replace(".hip", ".o"))
         objs.append(obj)
         if force or extra_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps_mtime):
-            procs.append((name, subprocess.Popen(["hipcc", *HIPCC_FLAGS, *UNIT_FLAGS.get(name, []), "-c", src, "-o", obj, *extra_flags],
-                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+            todo.append((name, ["hipcc", *HIPCC_FLAGS, *UNIT_FLAGS.get(name, []), "-c", src, "-o", obj, *extra_flags]))
             rebuilt = True
-    for name, proc in procs:      # (the units compile concurrently)
-        _, err = proc.communicate()
-        if proc.returncode != 0:
-            raise NMMAHipError(f"hipcc failed on {name}:\n" + err[-4000:])
+    # the units compile concurrently, at most one per core, in SOURCES order (longest first)
+    import time
+    slots = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    running = []
+    while todo or running:
+        while todo and len(running) < slots:
+            name, cmd = todo.pop(0)
+            running.append((name, subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)))
+        for item in list(running):
+            name, proc = item
+            if proc.poll() is not None:
+                running.remove(item)
+                if proc.returncode != 0:
+                    err = proc.stderr.read()
+                    for _, other in running:
+                        other.kill()
+                    raise NMMAHipError(f"hipcc failed on {name}:\n" + err[-4000:])
+        if running:
+            time.sleep(0.05)
     if rebuilt or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs):
         proc = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH],
                               capture_output=True, text=True)

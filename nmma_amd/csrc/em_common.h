@@ -331,7 +331,7 @@ __device__ __forceinline__ double exp_neg(const double x) {
 // prologue staging of em_logl: theta columns per row and cosmology-grid nodes kept in LDS
 constexpr int STAGE_COLS = 24, STAGE_COSMO = 256;
 // (the fused MCMC step parks [tot 16 | 5 x 2 rounds x 64 | 2 x 16 doubles | 6 x 16 ints | prior table] in the staging area of a 16-sample tile)
-static_assert((16 * STAGE_COLS + 2 * STAGE_COSMO) * 8 >= (16 + 5 * 2 * 64 + 2 * 16 + 3 * 16) * 8 + 8 * 40, "parked walk state");
+static_assert((16 * STAGE_COLS + 2 * STAGE_COSMO) * 8 >= (16 + 5 * 2 * 64 + 2 * 16 + 3 * 16) * 8 + 8 * 40, "parked walk state (8 lanes per chain; 16: lds_layout_logl_try)");
 // fast mode: most (item, sample group) tasks of one tile whose index -> (item, chunk) map is kept in LDS
 constexpr int TMAP_MAX = 512;
 constexpr int DENSE_NBUF = 2, DENSE_STRIDE = 17;   // dense lean task: node-magnitude buffers of 16 samples, row stride in doubles (odd: bank spread)
@@ -608,7 +608,7 @@ constexpr int LDS_DYNAMIC_MAX = 159 * 1024;
 
 __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M,
                                          int NP, int all_fast, int n_data, int n_sys_slots, int nbuf, bool stage_dat, int ext_rows = 0,
-                                         int dat_point_bytes = 32, int dense_rows = 0, int stack_bytes = 0) {
+                                         int dat_point_bytes = 32, int dense_rows = 0, int stack_bytes = 0, int walk_lanes = 0) {
     const int TS = 16 * R;
     const bool bracket_lookup = NS < 0;        // (NS < 0: unequally spaced sample_times -- the lean tasks' lookup table sits behind the grid)
     NS = NS < 0 ? -NS : NS;
@@ -621,8 +621,13 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
     L.part = off; off = align16(off + L.nbuf * NSLICE * TS * PSTR * 4);
     L.chi = off;  off = align16(off + n_items * TS * 8);             // per item: [TS] minus-chi-square sums
     L.gp = off;   off = align16(off + n_items * TS * 8);
-    L.sync = off; off = align16(off + (3 * n_items + 4 + 4 * n_items + 1) * 4);      // (+ produced / consumed counters per (item, 16 samples): dense task)
-    L.stage = off; off = align16(off + (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8);
+    L.sync = off; off = align16(off + (3 * n_items + 4 + 4 * n_items + 2) * 4);      // (+ produced / consumed counters per (item, 16 samples): dense task; + 2: fused MCMC step)
+    // (prologue staging; afterwards the fused MCMC step parks its state there: 16 lanes per chain -- four rounds per tile -- need more)
+    {
+        const int stage = (TS * STAGE_COLS + 2 * STAGE_COSMO) * 8;
+        const int parked = walk_lanes ? (TS + 5 * (TS / (64 / walk_lanes)) * 64 + 2 * TS + 3 * TS) * 8 + walk_lanes * 40 : 0;
+        L.stage = off; off = align16(off + (stage > parked ? stage : parked));
+    }
     L.tmap = off;  off = align16(off + (all_fast ? TMAP_MAX * 4 : 0));   // fast mode: task index -> (item << 8 | chunk)
     L.dat = (all_fast && stage_dat && n_data <= DAT_MAX) ? off : -1;     // fast mode: photometry [t | m | 1/sigma | log sigma]
     if (L.dat >= 0) off = align16(off + n_data * dat_point_bytes);     // (8: the epochs only -- item-staged photometry, EmDev::dat_in_tab)
@@ -648,7 +653,7 @@ __host__ inline LdsW lds_layout_logl_try(int R, int NS, int nf_avg_max, int tab_
 //  that share the CUs, e.g. RCCL's while a collective overlaps the likelihood)
 __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_bytes, int tab_fast_bytes, int n_items, int M, int NP,
                                      int all_fast, int n_data, int n_sys_slots, int ext_rows = 0, int ring_max = 4, int dat_point_bytes = 32,
-                                     int dense_rows = 0, int stack_bytes = 0) {
+                                     int dense_rows = 0, int stack_bytes = 0, int walk_lanes = 0) {
     constexpr int LDS_MAX = LDS_DYNAMIC_MAX;
     int want = n_items < 1 ? 1 : (n_items < (all_fast ? 4 : 3) ? n_items : (all_fast ? 4 : 3));
     if (want > ring_max) want = ring_max < 1 ? 1 : ring_max;
@@ -656,7 +661,7 @@ __host__ inline LdsW lds_layout_logl(int R, int NS, int nf_avg_max, int tab_byte
     for (int pass = 0; pass < 2; ++pass)
         for (int nbuf = want; nbuf >= (pass == 0 ? (want < 3 ? want : 3) : 1); --nbuf) {
             // (all_fast == 1, the lean task, reads the photometry from LDS only: never give the staging up)
-            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes, dense_rows, stack_bytes);
+            L = lds_layout_logl_try(R, NS, nf_avg_max, tab_bytes, tab_fast_bytes, n_items, M, NP, all_fast, n_data, n_sys_slots, nbuf, pass == 0 || all_fast == 1, ext_rows, dat_point_bytes, dense_rows, stack_bytes, walk_lanes);
             if (L.total <= LDS_MAX) return L;
         }
     return L;     // does not fit: the launch fails with an explicit error

@@ -42,6 +42,12 @@ struct nmma_em_handle {
     double* gp = nullptr;
     int64_t parts_cap = 0;
     double* lc_ws = nullptr;        // [B][M][NS] model light curves (non-SVD models; the surrogate's curves of rows nmma_em_loglike_stack2 re-evaluates)
+    // run-time options (nmma_em_set_option; the environment variables of the same purpose are read ONCE, at nmma_em_create:
+    // a getenv per launch raced with the host program's own environment writes)
+    int walk_fuse = 1;              // "walk_fuse"  / NMMA_WALK_NO_FUSE : the MCMC step fused into the likelihood launch where an instantiation exists
+    int walk_split = 1;             // "walk_split" / NMMA_WALK_NO_SPLIT: small queues' fused launches split by band
+    int lc_group = 0;               // "lc_group"   / NMMA_LC_GROUP, NMMA_LC_NO_GROUPS: lanes per sample of em_lc_loglike (0: by batch size; 16 / 32 / 64)
+    int stack2_fixup = 1;           // "stack2_fixup" / NMMA_STACK2_NO_FIXUP: re-evaluation launches of nmma_em_loglike_stack2 (0: measurement only)
     int stack2_ok = 0;              // the handle has the one-launch form of the combined model (em_logl<.., 7>; nmma_em_loglike_stack2)
     unsigned char* gap_ws = nullptr;    // [B] rows em_logl<.., 7> flagged for re-evaluation
     int64_t gap_cap = 0;

@@ -56,17 +56,21 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NBUF = L.nbuf;
-    for (int j = tid; j < 7 * P.n_items + 5; j += logl_threads(NMW, NVW)) sync[j] = 0;      // (the last one: fused MCMC step, first phase done)
+    for (int j = tid; j < 7 * P.n_items + 5 + (WALKF ? 1 : 0); j += logl_threads(NMW, NVW)) sync[j] = 0;      // (the last two: fused MCMC step -- first phase done | the tile's totals parked)
     if (tid == 0) g_wd_trip = 0;
     __syncthreads();             // the only workgroup barrier: counters zeroed
     const long tile0 = (long)blockIdx.x * TS;
     const int NP = P.NP, NC = P.NC, NT = P.NT, NS = P.NS;
     const int W = P.n_items;
     gci32p items = as_global(P.items);
-    // (WALKF = 8: the fused MCMC step keeps a group of that many lanes per chain -- one per sampled dimension -- and 16-sample tiles)
-    constexpr int WT = WALKF ? WALKF : 8;             // lanes per chain (8: up to 8 sampled dimensions; the parked state below is sized for it)
+    // (WALKF = 8 / 16 [+ 64]: the fused MCMC step keeps a group of 8 / 16 lanes per chain -- one per sampled dimension -- and 16-sample
+    //  tiles; + 64: the chains' Constraint program is evaluated in the step, on an fp64 stack in LDS)
+    constexpr int WT = WALKF ? (WALKF & 31) : 8;      // lanes per chain (8: up to 8 sampled dimensions, 16: up to 16)
+    constexpr bool WCON = (WALKF & 64) != 0;
     constexpr int WCR = 64 / WT;                      // chains per round of one wave
-    constexpr int WNR = WALKF ? TS / WCR : 1;
+    constexpr int WNR = WALKF ? TS / WCR : 1;         // rounds per tile: the second phase of the step gives each to a likelihood wave of its own
+    static_assert(WALKF == 0 || ((WT == 8 || WT == 16) && WNR <= NVW), "lanes per chain of the fused MCMC step");
+    constexpr int WPH = WNR > 2 ? 2 : 1;              // likelihood waves that share the step's first phase (two rounds each)
     // (staging area after the prologue: tot[TS] | parked walk state 5 x WNR x 64 + 2 TS doubles + 6 TS ints | prior table)
     nmma_walk_prior* wspl = reinterpret_cast<nmma_walk_prior*>(reinterpret_cast<double*>(smem + L.stage) + TS + 5 * WNR * 64 + 2 * TS + 3 * TS);
 
@@ -1546,20 +1550,23 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             // parked in the prologue's staging area (free from here on), so that the epilogue finds it in LDS instead of waiting for
             // a chain of dependent L2 round trips after the tile's last task.  At priority 0: it has all of the launch to finish
             // and must not take issue slots from the MFMA stream.
-            if (!helper && vwave == NVW - 1) {
+            // (16 lanes per chain: four rounds -- the last TWO likelihood waves take two each; on one wave the first phase delayed that
+            //  wave's tasks enough to lose what the fused step gains on the dense task: config 4's shape with em_syserr)
+            if (!helper && vwave >= NVW - WPH) {
+                const int wq0 = (NVW - 1 - vwave) * (WNR / WPH);        // this wave's first round
                 __builtin_amdgcn_s_setprio(0);
                 double* wl = reinterpret_cast<double*>(smem + L.stage);
                 double* pl = wl + TS;                         // [5][WNR * 64]: live_j - live_i | u | v | proposal | theta, per (round, lane)
                 double* pcd = pl + 5 * WNR * 64;              // [2][TS]: gamma | bound, per chain
                 int* pci = reinterpret_cast<int*>(pcd + 2 * TS);      // [6][TS]: inside | active | counts[4]
-                {
+                if (vwave == NVW - 1) {
                     const uint32_t* src = reinterpret_cast<const uint32_t*>(&wf->priors[0]);
                     for (int j = lane; j < wf->ndim * 10; j += 64) reinterpret_cast<uint32_t*>(wspl)[j] = src[j];
                 }
 #ifndef NMMA_DBG_WALK_NOPRE
                 constexpr int WPR = WNR < 2 ? WNR : 2;       // rounds in flight together
 #pragma unroll
-                for (int r0 = 0; r0 < WNR; r0 += WPR) {
+                for (int r0 = wq0; r0 < wq0 + WNR / WPH; r0 += WPR) {
                     WalkPre wq[WPR];
                     WalkPreKey wkey[WPR];
                     double wr[WPR][7];
@@ -1681,11 +1688,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
     }
     // ---- sum over filters + floor (core/base.py:178-182)
-    WalkPre wpre[WNR < 2 ? WNR : 2];
+    bool own_totals = false;     // (wave-uniform; first likelihood wave)
     if (vwave == 0) {            // the first likelihood wave (helpers have vwave < 0)
         for (int k = 0; k < W; ++k) sync_wait(sync + W + 2 + k, all_fast ? itab[k].ntask[R - 1] : NVW, P.watchdog, 700 + k);
         const int nb = SPLITTABLE ? P.n_bands : 1;
-        bool own_totals = !SPLITTABLE || nb <= 1;       // (wave-uniform)
+        own_totals = !SPLITTABLE || nb <= 1;
         if constexpr (COMB) {
             if (vt < TS && tile0 + vt >= B) aux.gap_rows[tile0 + vt] = 0;      // (the flag array is padded to whole tiles)
         }
@@ -1745,40 +1752,48 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 own_totals = true;       // (split launch: the group that added the bands owns the tile's MCMC step)
             }
         }
-        if (WALKF && own_totals) {
-            // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch
-            double* totl = reinterpret_cast<double*>(smem + L.stage);
-            sync_wait(sync + 7 * W + 4, 1, P.watchdog, 900);          // (the first phase finished long ago)
-            const double* pl = totl + TS;
-            const double* pcd = pl + 5 * WNR * 64;
-            const int* pci = reinterpret_cast<const int*>(pcd + 2 * TS);
-            constexpr int WPR = WNR < 2 ? WNR : 2;           // (rounds handled together, as in the first phase)
-#pragma unroll
-            for (int r0 = 0; r0 < WNR; r0 += WPR) {
-#pragma unroll
-                for (int rr = 0; rr < WPR; ++rr) {
-                    const int r = r0 + rr;
-                    const int e = r * 64 + vt, cl = r * WCR + vt / WT;
-                    WalkPre& w = wpre[rr];
-                    w.li = 0.0; w.lj = pl[e]; w.uu = pl[WNR * 64 + e]; w.vv = pl[2 * WNR * 64 + e]; w.pp = pl[3 * WNR * 64 + e]; w.th = pl[4 * WNR * 64 + e];
-                    w.gamma = pcd[cl]; w.lstar = pcd[TS + cl];
-                    w.in0 = pci[cl]; w.active = pci[TS + cl]; w.cnt0 = pci[2 * TS + cl]; w.cnt1 = pci[3 * TS + cl]; w.cnt2 = pci[4 * TS + cl];
-                    w.cnt3 = pci[5 * TS + cl];
-                }
+    }
+    if constexpr (WALKF != 0) {
+        // ---- the MCMC step, second phase: decide, move, propose, leave the tile's theta rows ready for the next launch.  One ROUND
+        // (64 / WT chains, a group of WT lanes each) per likelihood wave, WNR waves side by side: on the one wave that sums the tile
+        // the rounds ran one after the other -- two for 8 lanes per chain; four for 16, which then cost what the separate walk launch
+        // costs (profiles/r04_fused_mcmc_step.md).  The first likelihood wave publishes "totals parked" (1: this workgroup owns the
+        // tile's step; 2: split launch, another group of bands does) through an LDS word; LDS operations of a wave execute in order,
+        // so the totals are there when the word is.
+        if (vwave >= 0 && vwave < WNR) {
+            int* const wgo = sync + 7 * W + 5;
+            int own = own_totals ? 1 : 2;
+            if (vwave == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store((lds_ip)wgo, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                sync_wait(wgo, 1, P.watchdog, 910);
+                own = __hip_atomic_load((lds_ip)wgo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (own == 1) {
+                double* totl = reinterpret_cast<double*>(smem + L.stage);
+                sync_wait(sync + 7 * W + 4, WPH, P.watchdog, 900);        // (the first phase finished long ago)
+                const double* pl = totl + TS;
+                const double* pcd = pl + 5 * WNR * 64;
+                const int* pci = reinterpret_cast<const int*>(pcd + 2 * TS);
+                const int r = vwave;
+                const int e = r * 64 + lane, cl = r * WCR + lane / WT;
+                WalkPre w;
+                w.li = 0.0; w.lj = pl[e]; w.uu = pl[WNR * 64 + e]; w.vv = pl[2 * WNR * 64 + e]; w.pp = pl[3 * WNR * 64 + e]; w.th = pl[4 * WNR * 64 + e];
+                w.gamma = pcd[cl]; w.lstar = pcd[TS + cl];
+                w.in0 = pci[cl]; w.active = pci[TS + cl]; w.cnt0 = pci[2 * TS + cl]; w.cnt1 = pci[3 * TS + cl]; w.cnt2 = pci[4 * TS + cl];
+                w.cnt3 = pci[5 * TS + cl];
 #ifndef NMMA_DBG_WALK_NOPOST
-#pragma unroll
-                for (int rr = 0; rr < WPR; ++rr) {
-                    const int cl = (r0 + rr) * WCR + vt / WT;
-                    const long c = tile0 + cl;
-                    if (c < B)
-                        walk_step_post<false>(wspl, wf->ndim, WT, c, vt & (WT - 1), totl[cl], wpre[rr], wf->u, wf->v, wf->logl, wf->counts, wf->prop,
-                                              const_cast<double*>(theta), wf->inside, wf->con_ops, wf->n_con_ops, !wlast);
-                }
+                const long c = tile0 + cl;
+                // (WCON: the Constraint program's evaluation stack, one per chain of the round, in the partial-sum ring -- every task is done)
+                double* const cstack = reinterpret_cast<double*>(smem + L.part) + (size_t)vwave * (NMMA_CON_MAX_STACK * WCR);
+                if (c < B)
+                    walk_step_post<WCON>(wspl, wf->ndim, WT, c, lane & (WT - 1), totl[cl], w, wf->u, wf->v, wf->logl, wf->counts, wf->prop,
+                                         const_cast<double*>(theta), wf->inside, wf->con_ops, wf->n_con_ops, !wlast, cstack + lane / WT, WCR);
+#else
+                if (lane == 0 && vwave == 0) wf->counts[0] = w.cnt0 + (int)w.gamma;      // (keep the first phase alive)
 #endif
             }
-#ifdef NMMA_DBG_WALK_NOPOST
-            if (vt == 0) wf->counts[0] = wpre[0].cnt0 + (int)wpre[0].gamma;      // (keep the first phase alive)
-#endif
         }
     }
 }
@@ -1790,7 +1805,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
                                    (P.all_fast == 1 && (P.lean_x || FAST == 7)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0, FAST == 7 ? STACK2_LDS_BYTES : 0);
+                                   P.dense ? ((P.NT + 15) & ~15) : 0, FAST == 7 ? STACK2_LDS_BYTES : 0, (WALKF & 31) == 16 ? 16 : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
     if (L.total > LDS_DYNAMIC_MAX) {
@@ -1806,7 +1821,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     // keep every workgroup resident at once up to 256 / 2 tiles (measured: profiles/r03_small_batch.log).
     const int n_bands = h->lvl_n[0];
     const long tiles = (long)((B + TS - 1) / TS);
-    const int lvl = (WALKF && getenv("NMMA_WALK_NO_SPLIT") != nullptr) ? -1 : split_level(h, R, FAST, B, chi != nullptr);
+    const int lvl = (WALKF && !h->walk_split) ? -1 : split_level(h, R, FAST, B, chi != nullptr);
     const bool split = lvl >= 0;
     const int n_groups = split ? h->lvl_n[lvl] : 1;
     if (split) {
@@ -1858,8 +1873,16 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     NMMA_LOGL_INSTANCE(1, 2, NMW, FASTM, 0);   \
     NMMA_LOGL_INSTANCE(2, 1, NMW, FASTM, 0);   \
     NMMA_LOGL_INSTANCE(2, 2, NMW, FASTM, 0)
+// (the fused MCMC step: 8 / 16 lanes per chain -- up to 8 / 16 sampled dimensions; + 64: with the chains' Constraint program)
 #define NMMA_LOGL_WALK(FASTM)                  \
     NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 8);     \
-    NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 8)
+    NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 8);     \
+    NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 16);    \
+    NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 16)
+#define NMMA_LOGL_WALK_CON(FASTM)              \
+    NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 72);    \
+    NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 72);    \
+    NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 80);    \
+    NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 80)
 
 }  // namespace nmma

@@ -1,4 +1,4 @@
-// em_logl_f1.hip -- instantiations of em_logl (em_logl.h): the plain lean task (FASTM 1: BASELINE config 2) and its fused MCMC step.
+// em_logl_f1.hip -- instantiations of em_logl (em_logl.h): the plain lean task (FASTM 1: BASELINE config 2).
 #include "em_logl.h"
 
 namespace nmma {
@@ -13,7 +13,6 @@ NMMA_LOGL_INSTANCE(1, 1, 8, 1, 8);
 #endif
 #else
 NMMA_LOGL_FLAVOUR(8, 1);
-NMMA_LOGL_WALK(1);
 #endif
 
 }  // namespace nmma

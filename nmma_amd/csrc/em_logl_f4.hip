@@ -5,7 +5,6 @@ namespace nmma {
 
 #ifndef NMMA_DEV_HEADLINE_ONLY
 NMMA_LOGL_FLAVOUR(8, 4);
-NMMA_LOGL_WALK(4);
 #endif
 
 }  // namespace nmma

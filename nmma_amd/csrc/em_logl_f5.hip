@@ -5,7 +5,6 @@ namespace nmma {
 
 #ifndef NMMA_DEV_HEADLINE_ONLY
 NMMA_LOGL_FLAVOUR(8, 5);
-NMMA_LOGL_WALK(5);
 #endif
 
 }  // namespace nmma

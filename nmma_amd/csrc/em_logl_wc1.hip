@@ -1,0 +1,11 @@
+// em_logl_wc1.hip -- instantiations of em_logl (em_logl.h): the fused MCMC step WITH the chains' Constraint program (FASTM 1, 3).
+#include "em_logl.h"
+
+namespace nmma {
+
+#ifndef NMMA_DEV_HEADLINE_ONLY
+NMMA_LOGL_WALK_CON(1);
+NMMA_LOGL_WALK_CON(3);
+#endif
+
+}  // namespace nmma

@@ -100,6 +100,46 @@ __device__ inline bool con_row_ok(const nmma_con_op* __restrict__ ops, const int
     return ok;
 }
 
+// con_row_ok with its evaluation stack in LDS: st[level * stride] (one stack per chain of a round, the chains' stacks interleaved).
+// For the likelihood kernel's fused MCMC step: as a private array the 16-deep fp64 stack and its dynamic indexing cost 270 VGPRs, which
+// the kernel's budget of 128 cannot hold.  Same operations in the same order as con_row_ok: the same verdict, bit for bit.
+__device__ inline bool con_row_ok_lds(const nmma_con_op* __restrict__ ops, const int n_ops, const double* __restrict__ row, double* st_generic,
+                                      const int stride) {
+    typedef __attribute__((address_space(3))) double* lds_dp;
+    const lds_dp st = (lds_dp)st_generic;
+    int sp = 0;
+    bool ok = true;
+    for (int i = 0; i < n_ops; ++i) {
+        const nmma_con_op o = ops[i];
+        const int t1 = (sp - 1) * stride, t2 = (sp - 2) * stride;
+        switch (o.op) {
+            case NMMA_CON_PUSH_COL: st[sp * stride] = row[o.col]; ++sp; break;
+            case NMMA_CON_PUSH_CONST: st[sp * stride] = o.value; ++sp; break;
+            case NMMA_CON_ADD: st[t2] = st[t2] + st[t1]; --sp; break;
+            case NMMA_CON_SUB: st[t2] = st[t2] - st[t1]; --sp; break;
+            case NMMA_CON_MUL: st[t2] = st[t2] * st[t1]; --sp; break;
+            case NMMA_CON_DIV: st[t2] = st[t2] / st[t1]; --sp; break;
+            case NMMA_CON_POW: st[t2] = pow(st[t2], st[t1]); --sp; break;
+            case NMMA_CON_MIN: st[t2] = fmin(st[t2], st[t1]); --sp; break;
+            case NMMA_CON_MAX: st[t2] = fmax(st[t2], st[t1]); --sp; break;
+            case NMMA_CON_NEG: st[t1] = -st[t1]; break;
+            case NMMA_CON_ABS: st[t1] = fabs(st[t1]); break;
+            case NMMA_CON_SQRT: st[t1] = sqrt(st[t1]); break;
+            case NMMA_CON_LOG10: st[t1] = log10(st[t1]); break;
+            case NMMA_CON_LOG: st[t1] = log(st[t1]); break;
+            case NMMA_CON_EXP: st[t1] = exp(st[t1]); break;
+            case NMMA_CON_SIN: st[t1] = sin(st[t1]); break;
+            case NMMA_CON_COS: st[t1] = cos(st[t1]); break;
+            case NMMA_CON_ACOS: st[t1] = acos(st[t1]); break;
+            case NMMA_CON_ASIN: st[t1] = asin(st[t1]); break;
+            case NMMA_CON_SIGN: { const double x = st[t1]; st[t1] = x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); } break;
+            case NMMA_CON_CHECK_GT: ok = ok && (st[t1] > o.value); break;
+            default: ok = ok && (st[t1] < o.value); --sp; break;          // NMMA_CON_CHECK_LT
+        }
+    }
+    return ok;
+}
+
 // proposal in the unit cube (differential evolution between two other live points), boundary conditions, inside-the-cube flag, prior
 // transform.  A proposal outside the cube keeps the chain's current point in `theta` (the lock-step likelihood launch evaluates every
 // chain; the accept kernel ignores that row).
@@ -219,13 +259,20 @@ template <bool CON = true>
 __device__ __forceinline__ void walk_step_post(const nmma_walk_prior* sp, const int D, const int T, const long c, const int lane, const double lp_in,
                                                const WalkPre& w, double* u, double* v, double* __restrict__ logl, int32_t* __restrict__ counts,
                                                double* prop, double* theta, int32_t* inside, const nmma_con_op* __restrict__ con_ops,
-                                               const int n_con_ops, const bool propose) {
+                                               const int n_con_ops, const bool propose, double* cstack = nullptr, const int cstride = 1) {
     bool acc = false;
+    // a Constraint prior the proposal violates: the reference's likelihood returns the floor for it (core/base.py:77-82).  The first
+    // lane of the chain's group runs the program (its stack in LDS: cstack, cstride) and hands the verdict to the group.
+    int con_ok = 1;
+    if constexpr (CON) {
+        if (n_con_ops > 0) {
+            if (w.active && w.in0 && lane == 0) con_ok = con_row_ok_lds(con_ops, n_con_ops, theta + c * D, cstack, cstride) ? 1 : 0;
+            con_ok = __shfl(con_ok, (int)(threadIdx.x & 63) & ~(T - 1), 64);
+        }
+    }
     if (w.active) {
         double lp = lp_in;
-        // a Constraint prior the proposal violates: the reference's likelihood returns the floor for it (core/base.py:77-82)
-        if constexpr (CON)
-            if (n_con_ops > 0 && w.in0 && !con_row_ok(con_ops, n_con_ops, theta + c * D)) lp = NMMA_LOGL_FLOOR;
+        if (!con_ok) lp = NMMA_LOGL_FLOOR;
         acc = w.in0 && lp > w.lstar;
         if (acc && lane < D) { u[c * D + lane] = w.pp; v[c * D + lane] = w.th; }
         if (lane == 0) {

@@ -511,11 +511,14 @@ int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma
     // One launch per MCMC step where the handle's task flavour carries the fused step (accept + next proposal in the likelihood
     // kernel's epilogue, nmma_em_loglike_walk); else the likelihood launch followed by walk_step_kernel.  Same device functions,
     // same bits.
-    bool fused = q->constraints == nullptr;      // (the constraint interpreter's register needs do not fit the likelihood kernel's budget)
+    // (queues beyond 4096 chains keep two launches per step: the fused step exists for 16-sample tiles -- one round of workgroups --
+    //  and walking a longer queue in chunks of 4096 chains loses to the likelihood's 32-sample tiles + walk_step_kernel:
+    //  8192 chains x 100 steps 6.15 against 5.37 ms for config 2, profiles/r05_fused_mcmc_step.md)
+    bool fused = true;
     const nmma_walk_fuse* wf_d = reinterpret_cast<const nmma_walk_fuse*>(d + o_wf);
     for (int k = 1; k <= max_walks; ++k) {
         if (fused) {
-            const int rc = nmma_em_loglike_walk(h, theta_d, n, D, lp_d, wf_d, (uint64_t)k, k == max_walks ? 1 : 0, stream);
+            const int rc = nmma_em_loglike_walk(h, theta_d, n, D, lp_d, wf_d, (uint64_t)k, k == max_walks ? 1 : 0, n_con, stream);
             if (rc == 1) return 1;
             if (rc == 0) continue;
             fused = false;

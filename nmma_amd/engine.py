@@ -572,6 +572,11 @@ class EMEngine:
                 "nmma_em_profile_end")
         return dict(fused_ms_total=f.value, combine_ms_total=c.value, n_launches=n.value)
 
+    def set_option(self, name, value):
+        """Run-time option of the handle (``nmma_em_set_option``): "walk_fuse", "walk_split" (0 / 1), "lc_group" (0, 16, 32, 64),
+        "stack2_fixup" (0 / 1) -- for A/B measurements and tests."""
+        L.check(self._lib.nmma_em_set_option(self._handle, str(name).encode(), int(value)), "nmma_em_set_option")
+
     def check(self):
         """Synchronise and raise if an earlier asynchronous launch failed (kernel watchdog)."""
         L.check(self._lib.nmma_em_check(self._handle), "nmma_em_check")

@@ -122,12 +122,11 @@ def test_lc_tail_against_the_oracle(shape):
             th = torch.as_tensor(theta, device="cuda:0")
             dev_sets = [torch.as_tensor(s, device="cuda:0") for s in sets]
             for grp in (None, "16", "32"):
-                if grp is not None:
-                    os.environ["NMMA_LC_GROUP"] = grp
+                eng.set_option("lc_group", int(grp or 0))
                 try:
                     got = (eng.loglike_lc_sets(th, dev_sets) if n_sets > 1 else eng.loglike_lc(th, dev_sets[0])).cpu().numpy()
                 finally:
-                    os.environ.pop("NMMA_LC_GROUP", None)
+                    eng.set_option("lc_group", 0)
                 floor = ~np.isfinite(want) | (want <= FLOOR)
                 assert np.array_equal(got == FLOOR, floor), (shape, B, n_sets, grp)
                 ok = ~floor

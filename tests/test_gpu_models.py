@@ -108,12 +108,11 @@ def test_likelihood_from_curves_on_every_golden_case(name):
     floor = gold == FLOOR
     atol_rows = int(case.get("logl_atol_rows", 0))
     for grp in (None, "16", "32"):
-        if grp is not None:
-            os.environ["NMMA_LC_GROUP"] = grp
+        eng.set_option("lc_group", int(grp or 0))
         try:
             got = eng.loglike_lc(th, lc).cpu().numpy()
         finally:
-            os.environ.pop("NMMA_LC_GROUP", None)
+            eng.set_option("lc_group", 0)
         assert np.array_equal(got == FLOOR, floor), (name, grp)
         err = rel_err(got[~floor], gold[~floor])
         if atol_rows:            # (a documented near-cancelling row: absolute tolerance, see tests/cases.py)
@@ -156,7 +155,7 @@ def test_combined_union_grids_and_filter_fallbacks():
 def test_stack_fused_into_the_likelihood_gives_the_materialised_result():
     """``nmma_em_loglike_lc_sets`` (flux sum formed while a sample's curves are staged on chip; four samples per wave) against
     ``nmma_lc_stack`` + ``nmma_em_loglike_lc``: the same bits for one, two, three sets -- non-finite nodes, dark models, ragged
-    batch sizes, a row flagged as "no light curve" -- and the other group sizes (NMMA_LC_GROUP=16 / 32), all with the same bits."""
+    batch sizes, a row flagged as "no light curve" -- and the other group sizes (option lc_group = 16 / 32), all with the same bits."""
     import os
     import torch
     case = cases_combined.case_combined()
@@ -187,12 +186,12 @@ def test_stack_fused_into_the_likelihood_gives_the_materialised_result():
             flagged = tail.loglike_lc_sets(th, sets, bad)
             assert flagged[B // 2].item() == FLOOR and torch.equal(flagged[~bad], want[~bad])
             for grp, tile in (("16", 16), ("32", 8)):           # the other group sizes: the same bits (one summation order: group_total_canon)
-                os.environ["NMMA_LC_GROUP"] = grp
+                tail.set_option("lc_group", int(grp))
                 try:
                     other = tail.loglike_lc_sets(th, sets)
                     assert tail.last_launch_geometry()["tile_samples"] == tile
                 finally:
-                    del os.environ["NMMA_LC_GROUP"]
+                    tail.set_option("lc_group", 0)
                 assert torch.equal(other, want), (B, n_sets, grp)
     tail.close()
 

@@ -84,7 +84,7 @@ def _per_filter_syserr_case():
 @pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape", "c4_syserr", "syserr_per_filter"])
 def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     """The queue's one-launch MCMC step (accept + next proposal in the likelihood kernel's epilogue: ``nmma_em_loglike_walk``,
-    ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (``NMMA_WALK_NO_FUSE=1``) and against the
+    ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (option ``walk_fuse`` = 0) and against the
     Python-driven step loop: the same bits -- for the constant-systematics flavour (config 2), the sampled ``em_syserr`` flavour
     (7 sampled dimensions) and a six-input surrogate (KP = 2) -- with periodic / reflective dimensions and ragged queue sizes."""
     import os
@@ -110,24 +110,72 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
         keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
         steps = 7 if n != 37 else (2 + np.arange(n) % 6).astype(np.int32)
         fused = eng.walk_queue(table, live, u0, bound, keys, steps)      # (small queues: the launch is split by band AND carries the step)
-        os.environ["NMMA_WALK_NO_SPLIT"] = "1"          # every workgroup walks all bands and steps its own tile
+        eng.set_option("walk_split", 0)          # every workgroup walks all bands and steps its own tile
         try:
             unsplit = eng.walk_queue(table, live, u0, bound, keys, steps)
         finally:
-            del os.environ["NMMA_WALK_NO_SPLIT"]
+            eng.set_option("walk_split", 1)
         for a, b in zip(fused, unsplit):
             assert _same(a, b), (name, n, "split / unsplit")
-        os.environ["NMMA_WALK_NO_FUSE"] = "1"
+        eng.set_option("walk_fuse", 0)
         try:
             two = eng.walk_queue(table, live, u0, bound, keys, steps)
         finally:
-            del os.environ["NMMA_WALK_NO_FUSE"]
+            eng.set_option("walk_fuse", 1)
         for a, b in zip(fused, two):
             assert _same(a, b), (name, n)
         buf = torch.empty(n, dtype=torch.float64, device="cuda:0")
         u, v, logl, counts = smp.device_walk(table, live, u0, bound, keys, steps, lambda t: eng.loglike(t, out=buf))
         w._device_fresh_draws(np.nonzero(counts[:, 0] == 0)[0], table, keys, u, v, logl, counts, lambda t: eng.loglike(t), 0)
         assert _same(fused[0], u) and _same(fused[2], logl) and np.array_equal(fused[3], counts)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "log_grid", "syserr_per_filter"])
+def test_fused_mcmc_step_with_constraints_and_long_queues(torch_cuda, name):
+    """The one-launch MCMC step with the chains' Constraint program evaluated in it (``em_logl<..., WALKF | 64>``: the interpreter's
+    stack in LDS) and for queues of more than 4096 chains (walked in chunks of 4096: each chunk one full round of workgroups):
+    the same bits as the likelihood launch + ``walk_step_kernel`` -- 6, 7 and 15 sampled dimensions (8 / 16 lanes per chain)."""
+    from nmma_amd.core.constraints import ConstraintProgram
+    from nmma_amd import _lib as L
+    from tests import cases
+    from tests.helpers import engine_from_case
+    case = _per_filter_syserr_case() if name == "syserr_per_filter" else (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    eng = engine_from_case(case)
+    names = case["names"]
+    th = case["theta"]
+    lo, hi = th.min(axis=0) - 1e-3, th.max(axis=0) + 1e-3
+    pri = {k: UniformPrior(float(a), float(b)) for k, a, b in zip(names, lo, hi)}
+    pt = smp.BatchedPriorTransform(pri, names)
+    w = smp.EnsembleWalkSampler(ndim=len(names), periodic=[1], reflective=[2], walks=6)
+    table = smp.device_prior_table(pri, names, w.periodic, w.reflective)
+    # a program with arithmetic, a transcendental and both kinds of check: 10 ** col4 + 10 ** col5 < bound, col3 > lower bound
+    c4, c5 = names.index("log10_mej_dyn"), names.index("log10_mej_wind")
+    mid = float(np.median(10 ** th[:, c4] + 10 ** th[:, c5]))
+    ops = [(L.CON_PUSH_CONST, 0, 10.0), (L.CON_PUSH_COL, c4, 0.0), (L.CON_POW, 0, 0.0), (L.CON_PUSH_CONST, 0, 10.0), (L.CON_PUSH_COL, c5, 0.0),
+           (L.CON_POW, 0, 0.0), (L.CON_ADD, 0, 0.0), (L.CON_CHECK_LT, 0, 1.3 * mid),
+           (L.CON_PUSH_COL, 3, 0.0), (L.CON_CHECK_GT, 0, float(np.quantile(th[:, 3], 0.05))), (L.CON_CHECK_LT, 0, 1e300)]
+    prog = ConstraintProgram(ops, len(names), 0)
+    rng = np.random.default_rng(72)
+    for n, con in ((37, prog), (4096, prog), (5000, None), (8192 + 77, prog)):
+        n_live = 300
+        live = rng.uniform(0.2, 0.8, (n_live, len(names)))
+        u0 = live[rng.integers(0, n_live, n)].copy()
+        bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.3))
+        keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
+        steps = 6 if n != 37 else (2 + np.arange(n) % 5).astype(np.int32)
+        fused = eng.walk_queue(table, live, u0, bound, keys, steps, constraints=con)
+        eng.set_option("walk_fuse", 0)
+        try:
+            two = eng.walk_queue(table, live, u0, bound, keys, steps, constraints=con)
+        finally:
+            eng.set_option("walk_fuse", 1)
+        for a, b in zip(fused, two):
+            assert _same(a, b), (name, n)
+        if con is not None:          # the constraint bites: some proposals were floored, i.e. evaluated and rejected
+            free = eng.walk_queue(table, live, u0, bound, keys, steps)
+            assert not _same(free[0], fused[0])
+    prog.close()
     eng.close()
 
 

@@ -484,7 +484,7 @@ def test_kernel_register_budget():
             if m and name:
                 kernels[name][key] = int(m.group(1))
     logl = {k: v for k, v in kernels.items() if "7em_loglI" in k}
-    assert len(logl) >= 38, sorted(kernels)
+    assert len(logl) >= 64, sorted(kernels)
     seen = set()
     for k, v in logl.items():
         # template arguments <R, KP, NMW, NVW, FASTM, WALKF>
@@ -492,10 +492,12 @@ def test_kernel_register_budget():
         assert len(targs) == 6, k
         fastm = targs[4]
         seen.add(fastm)
-        if fastm in (1, 3, 4, 6):      # (the fused MCMC step's instantiations keep a few words of scratch for the walk's state, no spills)
-            assert v["vgpr_spill_count"] == 0 and (v["private_segment_fixed_size"] == 0 or targs[5] != 0), (k, v)
-        if fastm == 5:      # (the general lean task with its detection-limit call: two registers)
-            assert v["vgpr_spill_count"] <= 4, (k, v)
-        assert v["private_segment_fixed_size"] <= 64, (k, v)
+        if fastm in (1, 3, 4, 6):      # (the fused MCMC step's instantiations keep a few words of scratch for the walk's state, no spills --
+            # except the ones that carry the Constraint interpreter, WALKF & 64: two dozen registers around its libm calls, in the epilogue)
+            con = (targs[5] & 64) != 0
+            assert v["vgpr_spill_count"] <= (32 if con else 0) and (v["private_segment_fixed_size"] == 0 or targs[5] != 0), (k, v)
+        if fastm == 5:      # (the general lean task with its detection-limit call: two registers; with the fused MCMC step a handful)
+            assert v["vgpr_spill_count"] <= (8 if targs[5] else 4), (k, v)
+        assert v["private_segment_fixed_size"] <= (160 if (targs[5] & 64) else 64), (k, v)
         assert v["vgpr_count"] <= (128 if fastm else 160), (k, v)
-    assert seen >= {0, 1, 2, 3, 4, 5, 6}, seen
+    assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, seen

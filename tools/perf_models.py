@@ -76,7 +76,8 @@ got = one.loglike_stack2(t, ext)
 rel = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
 print(f"config 3 shape B={B}: ONE launch (em_logl<.., 7> + two restricted re-evaluation launches) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call; "
       f"max rel diff to the materialising path {rel:.2e}")
-os.environ["NMMA_STACK2_NO_FIXUP"] = "1"      # (read once per process by the library: measured in a child process below)
+one.set_option("stack2_fixup", 0)             # (measurement only: the kernel alone, without the two restricted re-evaluation launches)
+print(f"   em_logl<.., 7> alone (no re-evaluation launches) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call")
 one.close()
 
 lc_fixed = kn.model_lightcurves(t)
@@ -86,10 +87,10 @@ print(f"config 3 shape B={B}: SVD curves + fused stack / likelihood {timeit(comb
 print(f"   tail alone: fused stack + likelihood {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
       f"lc_stack {timeit(lambda: tail.stack([lc_fixed, ext])):8.1f} us + likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
 for grp in ("16", "32", "64"):                 # every group size of the same kernels, like for like (default: 32 lanes per sample)
-    os.environ["NMMA_LC_GROUP"] = grp
-    print(f"   NMMA_LC_GROUP={grp}: fused {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
+    tail.set_option("lc_group", int(grp))
+    print(f"   lc_group={grp}: fused {timeit(lambda: tail.loglike_lc_sets(t, [lc_fixed, ext])):8.1f} us; "
           f"likelihood from curves {timeit(lambda: tail.loglike_lc(t, stacked)):8.1f} us")
-del os.environ["NMMA_LC_GROUP"]
+tail.set_option("lc_group", 0)
 assert torch.equal(tail.loglike_lc_sets(t, [lc_fixed, ext]), tail.loglike_lc(t, stacked))
 kn.close(); tail.close()
 

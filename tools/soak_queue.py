@@ -37,11 +37,11 @@ for name in names_cases:
         walks = int(rng.integers(1, 40))
         steps = walks if rng.uniform() < 0.5 else rng.integers(1, walks + 1, n).astype(np.int32)
         fused = eng.walk_queue(table, live, u0, bound, keys, steps)
-        os.environ["NMMA_WALK_NO_FUSE"] = "1"
+        eng.set_option("walk_fuse", 0)
         try:
             two = eng.walk_queue(table, live, u0, bound, keys, steps)
         finally:
-            del os.environ["NMMA_WALK_NO_FUSE"]
+            eng.set_option("walk_fuse", 1)
         same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(fused, two))
         steps_total += n * walks
         if not same:
