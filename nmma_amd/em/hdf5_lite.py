@@ -8,7 +8,9 @@ Supported subset of the HDF5 file format (what h5py's default ``libver='earliest
 headers with continuation blocks, simple dataspaces (version 1 / 2), fixed-point and IEEE floating-point datatypes (little endian),
 contiguous (layout class 1) and compact (class 0) storage.  Chunked / filtered datasets, new-style groups and variable-length
 attributes are not read -- attributes are skipped altogether (the layer order is recovered from the kernel shapes, see ``em/io.py``).
-Anything outside the subset raises ``Hdf5LiteError``.
+A STRUCTURE outside the subset (superblock, groups, object headers), a truncated file or a cyclic group link raises
+``Hdf5LiteError``; a single DATASET outside it (chunked, compressed, a string datatype ...) is skipped and listed in
+``File.skipped`` -- a Keras file carries such datasets next to the Dense weights, and they must not abort the read.
 """
 from __future__ import annotations
 
@@ -51,9 +53,16 @@ class File:
         # then the root group's symbol-table entry
         root = 24 + 4 * 8
         self.datasets = {}
-        link_off, header, cache, _ = struct.unpack_from("<QQII", b, root)
-        scratch = b[root + 24: root + 40]
-        self._walk_object(header, "", cache, scratch)
+        self.skipped = {}                 # name -> reason, for datasets outside the supported subset
+        self._seen = set()                # object-header addresses already visited (hard links may form cycles)
+        try:
+            link_off, header, cache, _ = struct.unpack_from("<QQII", b, root)
+            scratch = b[root + 24: root + 40]
+            self._walk_object(header, "", cache, scratch)
+        except (struct.error, IndexError) as exc:             # an offset beyond the end of the buffer: a truncated or damaged file
+            raise Hdf5LiteError(f"truncated or damaged HDF5 file: {exc}") from exc
+        except RecursionError as exc:
+            raise Hdf5LiteError("group nesting too deep") from exc
 
     # ---- object headers -------------------------------------------------------------------------------------------------------
     def _messages(self, addr):
@@ -79,6 +88,9 @@ class File:
         return out
 
     def _walk_object(self, header, name, cache=0, scratch=b""):
+        if header in self._seen:              # a second link to an object already read (or a cycle): nothing new below it
+            return
+        self._seen.add(header)
         msgs = self._messages(header)
         types = {m[0] for m in msgs}
         if 0x0011 in types or cache == 1:                 # a group: symbol-table message (B-tree address, local-heap address)
@@ -92,8 +104,10 @@ class File:
                 self._walk_object(lheader, f"{name}/{lname}" if name else lname, lcache, lscratch)
             return
         if 0x0008 in types and 0x0001 in types and 0x0003 in types:          # a dataset
-            ds = self._dataset(msgs)
-            self.datasets[name] = self._read(ds)
+            try:
+                self.datasets[name] = self._read(self._dataset(msgs))
+            except Hdf5LiteError as exc:      # this dataset only: the others stay readable
+                self.skipped[name] = str(exc)
             return
         if 0x0002 in types or 0x0006 in types:
             raise Hdf5LiteError(f"{name}: new-style group (link messages) -- not read")
@@ -123,8 +137,10 @@ class File:
             for i in range(n):
                 e = addr + 8 + i * 40
                 link_off, header, cache, _ = struct.unpack_from("<QQII", b, e)
-                end = heap.index(b"\x00", link_off)
-                yield heap[link_off:end].decode("utf-8"), header, cache, b[e + 24: e + 40]
+                end = heap.find(b"\x00", link_off)
+                if link_off >= len(heap) or end < 0:
+                    raise Hdf5LiteError(f"link name at heap offset {link_off} is not terminated")
+                yield heap[link_off:end].decode("utf-8", "replace"), header, cache, b[e + 24: e + 40]
         else:
             raise Hdf5LiteError(f"neither a B-tree nor a symbol-table node at {addr}")
 

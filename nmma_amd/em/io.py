@@ -80,11 +80,13 @@ def _dense_weights_from_h5(path):
     layers = {}
     for name, arr in _h5_datasets(path).items():
         parts = name.split("/")
-        if parts[0] != "model_weights" or len(parts) < 3:
-            continue
+        if parts[0] == "model_weights":          # a full model file (keras model.save): model_weights/<layer>/<layer>/{kernel,bias}:0
+            parts = parts[1:]
+        if len(parts) < 2 or parts[0] == "optimizer_weights":
+            continue                             # (a weights-only file, model.save_weights, has the layer groups at the root)
         leaf = parts[-1].split(":")[0]
         if leaf in ("kernel", "bias"):
-            layers.setdefault(parts[1], {})[leaf] = np.asarray(arr)
+            layers.setdefault(parts[0], {})[leaf] = np.asarray(arr)
     dense = [(v["kernel"], v["bias"]) for v in layers.values() if "kernel" in v and "bias" in v]
     if len(dense) != 2:
         raise ValueError(f"{path}: expected two Dense layers, found {len(dense)}")

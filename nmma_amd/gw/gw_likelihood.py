@@ -401,8 +401,12 @@ class GravitationalWaveTransient:
                     # when the prior is flat over its support (bilby evaluates prior.prob(times + jitter) per sample)
                     inside = self._time_logw[np.isfinite(self._time_logw)]
                     if inside.size and np.ptp(inside) > 1e-9:
-                        raise L.NMMAHipError("jitter_time with a non-uniform geocent_time prior is not supported on the device path "
-                                             "(the time prior would have to be evaluated per sample): pass jitter_time=False")
+                        # (bilby's default is jitter_time=True: a reference-shaped set-up with, say, a Gaussian time prior must
+                        #  keep running -- without the jitter the time grid is fixed, which is bilby's own jitter_time=False)
+                        import warnings
+                        warnings.warn("jitter_time with a non-uniform geocent_time prior: the device path cannot evaluate the time prior per "
+                                      "sample; continuing with jitter_time=False (a fixed time grid)", RuntimeWarning, stacklevel=2)
+                        self.jitter_time, self._time_bounds = False, None
                 if self.jitter_time and "time_jitter" not in priors:
                     # bilby/gw/likelihood/base.py: priors['time_jitter'] = Uniform(-delta_tc / 2, delta_tc / 2)
                     half = 0.5 * float(ifo.strain_data.duration) / (len(ifo.frequency_array) - 1)

@@ -46,6 +46,51 @@ def test_reader_refuses_what_it_does_not_parse(tmp_path):
         hdf5_lite.read_datasets(str(v2))
 
 
+def test_reader_survives_damage_cycles_and_foreign_datasets():
+    """A truncated file and a link cycle raise ``Hdf5LiteError`` (not struct.error / RecursionError); ONE dataset outside the
+    subset is skipped and named in ``skipped`` while the Dense weights stay readable."""
+    import struct
+    raw = open(H5, "rb").read()
+    with pytest.raises(hdf5_lite.Hdf5LiteError):
+        hdf5_lite.read_datasets(data=raw[: len(raw) // 3])                      # cut in the middle of the object headers / heaps
+    # make one bias dataset's datatype a string class (class 3): that dataset is skipped, everything else is read
+    f = hdf5_lite.File(data=raw)
+    assert f.skipped == {} and len(f.datasets) == 13
+    target = raw.find(np.float32(f.datasets["model_weights/dense_51/dense_51/bias:0"]).tobytes())
+    assert target > 0
+    # (find the datatype message of some float32 dataset: class 1, 4 bytes -- patch the FIRST one's class nibble to 3)
+    sig = bytes([0x11, 0x20, 0x1F, 0x00]) + struct.pack("<I", 4)
+    pos = raw.find(sig)
+    assert pos > 0
+    patched = bytearray(raw)
+    patched[pos] = 0x13
+    g = hdf5_lite.File(data=bytes(patched))
+    assert len(g.skipped) == 1 and len(g.datasets) == 12
+    assert "datatype class 3" in next(iter(g.skipped.values()))
+    # a cycle: the root group's first symbol-table entry made to point back at the root object header
+    root_header = struct.unpack_from("<Q", raw, 24 + 32 + 8)[0]
+    snod = raw.find(b"SNOD")
+    cyc = bytearray(raw)
+    struct.pack_into("<Q", cyc, snod + 8 + 8, root_header)
+    h = hdf5_lite.File(data=bytes(cyc))                                          # terminates; the revisited object adds nothing
+    assert len(h.datasets) <= 13
+
+
+def test_weights_only_file_layout_is_accepted(tmp_path):
+    """``model.save_weights`` writes the layer groups at the ROOT (no ``model_weights/`` prefix): same reader, same weights."""
+    d = hdf5_lite.read_datasets(H5)
+    flat = {k[len("model_weights/"):]: v for k, v in d.items() if k.startswith("model_weights/")}
+    import nmma_amd.em.io as io_mod
+    orig = io_mod._h5_datasets
+    io_mod._h5_datasets = lambda path: flat
+    try:
+        w1, b1, w2, b2 = io_mod._dense_weights_from_h5("weights_only.h5")
+    finally:
+        io_mod._h5_datasets = orig
+    w = _weights()
+    assert np.array_equal(w1, w["W1"]) and np.array_equal(b2, w["b2"])
+
+
 def test_reference_layout_joblib_plus_h5_end_to_end(tmp_path):
     """``{svd_path}/Bu2019nsbh.joblib`` (the metadata dict of training.py:generate_svd_model, keys with ``_`` for ``:`` as the reference
     stores sncosmo names) + ``{svd_path}/Bu2019nsbh_tf/{filter}.h5``: ``SVDLightCurveModel(svd_path=...)`` converts on the fly, writes
