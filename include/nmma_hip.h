@@ -230,8 +230,8 @@ int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int6
  * meet an interior gap of lc2 (rare) are re-evaluated in the same call by the kernels behind nmma_em_model_lightcurves +
  * nmma_em_loglike_lc_sets, restricted to those rows.  bad_rows_dev (or NULL): [B] bytes, non-zero = a sub-model delivered no light
  * curve for this row (model.py:1423-1426) -> floor.  Returns 2 -- nothing launched -- when the handle has no one-launch form (not
- * created with stack_operands = 1; a task flavour other than the lean one; sample_times reaching beyond the surrogate's grid;
- * unequally spaced sample_times): the caller then takes nmma_em_model_lightcurves + nmma_em_loglike_lc_sets.  Asynchronous. */
+ * created with stack_operands = 1; a task flavour other than the lean one; sample_times reaching beyond the surrogate's grid):
+ * the caller then takes nmma_em_model_lightcurves + nmma_em_loglike_lc_sets.  Asynchronous. */
 int32_t nmma_em_loglike_stack2(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* lc2_dev,
                                const uint8_t* bad_rows_dev, double* out_dev, void* stream);
 

@@ -17,7 +17,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: translation units of libnmma_hip.so, longest first (they compile concurrently; build_library caps the number in flight).  em_logl's
 #: 38 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s.
 SOURCES = ("em_logl_w3.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_w2.hip", "em_kernels.hip", "em_logl_f5.hip", "em_logl_wc2.hip",
-           "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f1.hip", "gw_kernels.hip",
+           "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f8.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f1.hip", "gw_kernels.hip",
            "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference

@@ -600,6 +600,7 @@ struct EmAux { const double* lc2; const unsigned char* bad_rows; unsigned char* 
 struct EmNoAux {};      // (what every other flavour takes in that place: their kernel arguments stay as they were)
 template <int FASTM> struct em_aux_of { typedef EmNoAux type; };
 template <> struct em_aux_of<7> { typedef EmAux type; };
+template <> struct em_aux_of<8> { typedef EmAux type; };
 
 // One candidate layout: `nbuf` ring slots, photometry staged or not.
 // Dynamic LDS a launch may ask for: the 160 KiB of a CU minus the kernel's static words (g_wd_trip), rounded down to the

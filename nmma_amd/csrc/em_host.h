@@ -112,7 +112,7 @@ static int split_level(const nmma_em_handle* h, int R, int FAST, int64_t B, bool
     const int n_bands = h->lvl_n[0];
     const long tiles = (long)((B + 16 * R - 1) / (16 * R));
     int lvl = -1;
-    if (R == 1 && FAST != 0 && FAST != 2 && FAST != 7 && !per_filter_parts && h->band_dev_d != nullptr && n_bands >= 2 && h->split_mode != 0 &&
+    if (R == 1 && FAST != 0 && FAST != 2 && FAST != 7 && FAST != 8 && !per_filter_parts && h->band_dev_d != nullptr && n_bands >= 2 && h->split_mode != 0 &&
         tiles * (long)sizeof(unsigned) <= SPLIT_COUNTER_BYTES) {
         if (h->split_mode == 1) lvl = 0;
         else {

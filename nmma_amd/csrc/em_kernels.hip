@@ -251,29 +251,11 @@ __device__ __forceinline__ void em_fused_body(
     }
 }
 
-// ONLY: the launch is restricted to the tiles that hold a row with only_rows[b] != 0 (the combined-model call re-evaluates the rows its
-// one-launch kernel flagged: nmma_em_loglike_stack2) -- a SMALL grid whose workgroups each look at every gridDim.x-th tile's flags
-// (64 tiles per load round) and run the kernel for the flagged ones: with nothing flagged the launch costs little more than an
-// empty kernel (as one workgroup per tile leaving after a load it cost 5 us at config 3's shape).
-template <int MODE, int R, int WPB, int KP, bool ONLY = false>
+template <int MODE, int R, int WPB, int KP>
 __global__ __launch_bounds__(64 * WPB, 2) void em_fused(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff L,
-    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out, const unsigned char* __restrict__ only_rows) {
-    if constexpr (!ONLY) {
-        em_fused_body<MODE, R, WPB, KP>(Pp, theta, B, ld, L, coeff_out, tobs_out, mag_out, blockIdx.x, (int)blockIdx.y);
-    } else {
-        constexpr int TS = 16 * R;
-        const long n_tiles = (B + TS - 1) / TS;
-        for (long first = blockIdx.x; first < n_tiles; first += 64L * gridDim.x) {
-            unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_tiles, TS);
-            while (mask != 0) {
-                const int i = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                em_fused_body<MODE, R, WPB, KP>(Pp, theta, B, ld, L, coeff_out, tobs_out, mag_out, (unsigned)(first + (long)i * gridDim.x), (int)blockIdx.y);
-                __syncthreads();
-            }
-        }
-    }
+    float* __restrict__ coeff_out, double* __restrict__ tobs_out, double* __restrict__ mag_out) {
+    em_fused_body<MODE, R, WPB, KP>(Pp, theta, B, ld, L, coeff_out, tobs_out, mag_out, blockIdx.x, (int)blockIdx.y);
 }
 
 // =======================================================================================
@@ -810,28 +792,48 @@ __device__ __forceinline__ void em_lc_loglike_body(
     }
 }
 
-// em_lc_loglike<G, NM, SD, SA, ONLY>: one workgroup per row block; ONLY (the re-evaluation of the rows the combined model's one-launch
-// kernel flagged): a small grid whose workgroups each look at every gridDim.x-th row block's flags and run the kernel for the
-// flagged ones (see em_fused).
-template <int G, int NM, bool SD, bool SA, bool ONLY = false>
+// em_lc_loglike<G, NM, SD, SA>: one workgroup per row block.
+template <int G, int NM, bool SD, bool SA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void em_lc_loglike(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld,
     const LcSets sets, const int n_sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample,
-    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts,
-    const unsigned char* __restrict__ only_rows) {
-    if constexpr (!ONLY) {
-        em_lc_loglike_body<G, NM, SD, SA, false>(Pp, theta, B, ld, sets, n_sets, bad_rows, lds_per_sample, always_floor, out, chi_parts, gp_parts,
-                                                 only_rows, blockIdx.x);
-    } else {
-        constexpr int SPB = 4 * (64 / G);
-        const long n_blocks = (B + SPB - 1) / SPB;
-        for (long first = blockIdx.x; first < n_blocks; first += 64L * gridDim.x) {
-            unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_blocks, SPB);
-            while (mask != 0) {
-                const int i = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                em_lc_loglike_body<G, NM, SD, SA, true>(Pp, theta, B, ld, sets, n_sets, bad_rows, lds_per_sample, always_floor, out, chi_parts,
-                                                        gp_parts, only_rows, (unsigned)(first + (long)i * gridDim.x));
+    const int always_floor, double* __restrict__ out, double* __restrict__ chi_parts, double* __restrict__ gp_parts) {
+    em_lc_loglike_body<G, NM, SD, SA, false>(Pp, theta, B, ld, sets, n_sets, bad_rows, lds_per_sample, always_floor, out, chi_parts, gp_parts,
+                                             nullptr, blockIdx.x);
+}
+
+// stack2_redo<KP, G, SD>: ONE launch that re-evaluates the rows the combined model's one-launch kernel flagged (em_logl<.., 7 | 8>,
+// nmma_em_loglike_stack2: rows that met an interior gap of the second transient's curve) with the kernels of the materialising path
+// -- per flagged tile of 32 rows a workgroup runs em_fused<MODE_LC_ABS> for every model filter (the surrogate's curves, into kn_ws),
+// then em_lc_loglike on {kn_ws, lc2} for the tile's row blocks, storing the flagged rows only: their values are the materialising
+// path's, bit for bit.  A small grid: every workgroup looks at each gridDim.x-th tile's flags (64 tiles per load round), so that
+// with nothing flagged -- the usual case -- the launch is little more than an empty kernel.  (Two restricted launches, one per
+// kernel, cost 5 us EACH at config 3's shape whatever their grid: dependent launches pay the inter-kernel latency.)
+template <int KP, int G, bool SD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void stack2_redo(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff Lf, double* __restrict__ kn_ws,
+    const LcSets sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int always_floor,
+    double* __restrict__ out, const unsigned char* __restrict__ only_rows) {
+    constexpr int TS = 32, SPB = 4 * (64 / G);
+    const long n_tiles = (B + TS - 1) / TS;
+    const int M = Pp->M;
+    for (long first = blockIdx.x; first < n_tiles; first += 64L * gridDim.x) {
+        unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_tiles, TS);
+        while (mask != 0) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long tile = first + (long)i * gridDim.x;
+            for (int m = 0; m < M; ++m) {
+                em_fused_body<MODE_LC_ABS, 2, 4, KP>(Pp, theta, B, ld, Lf, nullptr, nullptr, kn_ws, (unsigned)tile, m);
+                __syncthreads();
+            }
+            __threadfence();          // the curves this workgroup just wrote are what it reads next
+            __syncthreads();
+            for (int q = 0; q < TS / SPB; ++q) {
+                const long blk = tile * (TS / SPB) + q;
+                if (blk * SPB < B)
+                    em_lc_loglike_body<G, 2, SD, true, true>(Pp, theta, B, ld, sets, 2, bad_rows, lds_per_sample, always_floor, out, nullptr, nullptr,
+                                                             only_rows, (unsigned)blk);
                 __syncthreads();
             }
         }

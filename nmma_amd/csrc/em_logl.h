@@ -24,7 +24,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
-    constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2 && FASTM != 7;    // small batches: one band per workgroup (launch_logl_one)
+    constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2 && FASTM != 7 && FASTM != 8;    // small batches: one band per workgroup (launch_logl_one)
     constexpr bool DENSE = FASTM == 6;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     // FASTM == 7: the lean task with extras (as 3) for a COMBINED model of two transients that share sample_times and filters
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // source-frame curves aux.lc2[B][M][NS] are an operand; every datum loads its two bracket nodes of them and the flux sum
     // (stack_magnitudes, :1486-1510) is formed on those two nodes only, next to the kilonova's two reconstructed nodes -- the
     // kilonova's curves are never written out (em_fused<MODE_LC_ABS> + em_lc_loglike: two launches and 24 + 48 MB of traffic at config 3's shape)
-    constexpr bool COMB = FASTM == 7;
+    constexpr bool COMB = FASTM == 7 || FASTM == 8;      // (8: the same on unequally spaced sample_times, as FASTM 4)
     constexpr int NV = 64 * NVW;      // VALU-role threads
 
     // (blockIdx.y > 0 only in the split launch of small batches: one copy of the configuration per observed band)
@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || (FASTM == 5 && itab[k].kind == NMMA_SYS_NODES));
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
-                    if constexpr (FASTM == 4) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
+                    if constexpr (FASTM == 4 || FASTM == 8) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
                         if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
                     } else if constexpr (FASTM == 5) {
                         if (!P.st_uniform) { if (sysp) lean_gen_task(tb, T{}, T{}, T{}, k, t); else lean_gen_task(tb, T{}, F{}, T{}, k, t); }
@@ -1804,8 +1804,8 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     constexpr int LOGL_THREADS = logl_threads(NMW, NVW);
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
-                                   (P.all_fast == 1 && (P.lean_x || FAST == 7)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0, FAST == 7 ? STACK2_LDS_BYTES : 0, (WALKF & 31) == 16 ? 16 : 0);
+                                   (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
+                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : 0, (WALKF & 31) == 16 ? 16 : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
     if (L.total > LDS_DYNAMIC_MAX) {
@@ -1838,7 +1838,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
         }
     }
     typename em_aux_of<FAST>::type kaux{};
-    if constexpr (FAST == 7) kaux = aux;
+    if constexpr (FAST == 7 || FAST == 8) kaux = aux;
     const dim3 grid((unsigned)tiles, (unsigned)n_groups);
     h->g_x = grid.x; h->g_y = grid.y; h->g_block = LOGL_THREADS; h->g_tile = TS; h->g_lds = L.total;
     if (L.total > 64 * 1024) {

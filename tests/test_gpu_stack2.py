@@ -158,7 +158,7 @@ def test_one_launch_properties_and_batch_independence():
 def test_handles_without_a_one_launch_form_say_so():
     """``loglike_stack2`` returns None (the library: 2, nothing launched) for a handle not created for it, for sample_times that
     reach beyond the surrogate's grid (the flux sum is then finite where the kilonova is not: the task's window test would be
-    wrong), and for unequally spaced sample_times; the plugin then takes the materialising path and says so once."""
+    wrong); the plugin then takes the materialising path and says so once."""
     import torch
     case = cases_combined.case_combined()
     M = len(case["filters"])
@@ -173,9 +173,31 @@ def test_handles_without_a_one_launch_form_say_so():
     assert one.loglike_stack2(th, torch.zeros((8, M, len(beyond)), dtype=torch.float64, device="cuda:0")) is None
     for e in (one, kn, tail):
         e.close()
+
+
+def test_one_launch_on_a_log_spaced_grid():
+    """Unequally spaced sample_times (the CLI's log-spaced grid): ``em_logl<.., 8>`` -- the combined flavour with the lean task's
+    bracket search for such grids -- against the materialising path, with edges and gaps in the second transient's curves."""
+    import torch
+    case = cases_combined.case_combined()
+    M = len(case["filters"])
     logt = np.geomspace(0.1, 20.0, 40)
     one, kn, tail = _engines(case, sample_times=logt)
-    assert one.loglike_stack2(th, torch.zeros((8, M, len(logt)), dtype=torch.float64, device="cuda:0")) is None
+    rng = np.random.default_rng(88)
+    for B in (7, 500, 8192):
+        theta = _theta(880 + B, B)
+        th = torch.as_tensor(theta, device="cuda:0")
+        lc2 = rng.uniform(-17.0, -12.0, (B, M, len(logt)))
+        lc2[::5, :, 0] = np.inf
+        lc2[3::9, 2, 11] = np.nan
+        lc2_t = torch.as_tensor(lc2, device="cuda:0")
+        got = one.loglike_stack2(th, lc2_t)
+        assert got is not None
+        want = tail.loglike_lc_sets(th, [kn.model_lightcurves(th), lc2_t]).cpu().numpy()
+        got = got.cpu().numpy()
+        assert np.array_equal(got == FLOOR, want == FLOOR)
+        fin = want > FLOOR
+        assert fin.mean() > 0.5 and rel_err(got[fin], want[fin]).max() <= FUSED_VS_MATERIALISED_RTOL
     for e in (one, kn, tail):
         e.close()
 

@@ -74,10 +74,10 @@ assert one.loglike_stack2(t, ext) is not None
 ref = combined()
 got = one.loglike_stack2(t, ext)
 rel = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
-print(f"config 3 shape B={B}: ONE launch (em_logl<.., 7> + two restricted re-evaluation launches) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call; "
+print(f"config 3 shape B={B}: em_logl<.., 7> + the re-evaluation launch (stack2_redo, nothing flagged) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call; "
       f"max rel diff to the materialising path {rel:.2e}")
-one.set_option("stack2_fixup", 0)             # (measurement only: the kernel alone, without the two restricted re-evaluation launches)
-print(f"   em_logl<.., 7> alone (no re-evaluation launches) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call")
+one.set_option("stack2_fixup", 0)             # (measurement only: the kernel alone, without the re-evaluation launch)
+print(f"   em_logl<.., 7> alone (no re-evaluation launch) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call")
 one.close()
 
 lc_fixed = kn.model_lightcurves(t)
