@@ -25,6 +25,7 @@ SOURCES = ("em_logl_w3.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_w2.hi
 UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 
 ABI_VERSION = 6
+STACK2_GAP_FREE = 1
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -155,7 +156,7 @@ PROTOTYPES = {
                                        C.c_void_p]),
     "nmma_em_loglike_lc_sets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
-    "nmma_em_loglike_stack2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nmma_em_loglike_stack2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "nmma_lc_stack": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "nmma_lc_regrid": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _pd, _pi, _pi, C.c_int64, C.c_void_p,
                                    C.c_void_p]),

@@ -809,33 +809,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
 // path's, bit for bit.  A small grid: every workgroup looks at each gridDim.x-th tile's flags (64 tiles per load round), so that
 // with nothing flagged -- the usual case -- the launch is little more than an empty kernel.  (Two restricted launches, one per
 // kernel, cost 5 us EACH at config 3's shape whatever their grid: dependent launches pay the inter-kernel latency.)
+// (the work on one flagged tile, out of line: inlined, its register spills were hoisted to the kernel's entry -- every workgroup of the
+//  "nothing flagged" launch wrote its registers to scratch, 14.8 MB per call at config 3's shape, before looking at a single flag)
+template <int KP, int G, bool SD>
+__device__ __noinline__ void stack2_redo_tile(
+    const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff Lf, double* __restrict__ kn_ws,
+    const LcSets sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int always_floor,
+    double* __restrict__ out, const unsigned char* __restrict__ only_rows, const long tile) {
+    constexpr int TS = 32, SPB = 4 * (64 / G);
+    const int M = Pp->M;
+    for (int m = 0; m < M; ++m) {
+        em_fused_body<MODE_LC_ABS, 2, 4, KP>(Pp, theta, B, ld, Lf, nullptr, nullptr, kn_ws, (unsigned)tile, m);
+        __syncthreads();
+    }
+    __threadfence();          // the curves this workgroup just wrote are what it reads next
+    __syncthreads();
+    for (int q = 0; q < TS / SPB; ++q) {
+        const long blk = tile * (TS / SPB) + q;
+        if (blk * SPB < B)
+            em_lc_loglike_body<G, 2, SD, true, true>(Pp, theta, B, ld, sets, 2, bad_rows, lds_per_sample, always_floor, out, nullptr, nullptr,
+                                                     only_rows, (unsigned)blk);
+        __syncthreads();
+    }
+}
+
 template <int KP, int G, bool SD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void stack2_redo(
     const EmDev* __restrict__ Pp, const double* __restrict__ theta, const long B, const long ld, const LdsOff Lf, double* __restrict__ kn_ws,
     const LcSets sets, const unsigned char* __restrict__ bad_rows, const int lds_per_sample, const int always_floor,
     double* __restrict__ out, const unsigned char* __restrict__ only_rows) {
-    constexpr int TS = 32, SPB = 4 * (64 / G);
+    constexpr int TS = 32;
     const long n_tiles = (B + TS - 1) / TS;
-    const int M = Pp->M;
     for (long first = blockIdx.x; first < n_tiles; first += 64L * gridDim.x) {
         unsigned long long mask = flagged_units(only_rows, first, (long)gridDim.x, n_tiles, TS);
         while (mask != 0) {
             const int i = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const long tile = first + (long)i * gridDim.x;
-            for (int m = 0; m < M; ++m) {
-                em_fused_body<MODE_LC_ABS, 2, 4, KP>(Pp, theta, B, ld, Lf, nullptr, nullptr, kn_ws, (unsigned)tile, m);
-                __syncthreads();
-            }
-            __threadfence();          // the curves this workgroup just wrote are what it reads next
-            __syncthreads();
-            for (int q = 0; q < TS / SPB; ++q) {
-                const long blk = tile * (TS / SPB) + q;
-                if (blk * SPB < B)
-                    em_lc_loglike_body<G, 2, SD, true, true>(Pp, theta, B, ld, sets, 2, bad_rows, lds_per_sample, always_floor, out, nullptr, nullptr,
-                                                             only_rows, (unsigned)blk);
-                __syncthreads();
-            }
+            stack2_redo_tile<KP, G, SD>(Pp, theta, B, ld, Lf, kn_ws, sets, bad_rows, lds_per_sample, always_floor, out, only_rows,
+                                        first + (long)i * gridDim.x);
         }
     }
 }

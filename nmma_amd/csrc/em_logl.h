@@ -1694,7 +1694,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const int nb = SPLITTABLE ? P.n_bands : 1;
         own_totals = !SPLITTABLE || nb <= 1;
         if constexpr (COMB) {
-            if (vt < TS && tile0 + vt >= B) aux.gap_rows[tile0 + vt] = 0;      // (the flag array is padded to whole tiles)
+            if (aux.gap_rows != nullptr && vt < TS && tile0 + vt >= B) aux.gap_rows[tile0 + vt] = 0;      // (the flag array is padded to whole tiles)
         }
         if (vt < TS && tile0 + vt < B) {
             bool isbad = always_floor != 0 || bad[vt] != 0 || sample_bad(vt) || g_wd_trip != 0;
@@ -1702,7 +1702,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (aux.bad_rows != nullptr && aux.bad_rows[tile0 + vt] != 0) isbad = true;
                 // (a flagged row's value -- NaN terms from the nodes without a value, hence the floor -- is replaced by the materialising
                 //  kernels that follow this launch; they floor the row themselves where that is the answer)
-                aux.gap_rows[tile0 + vt] = bad[5 * TS + vt] != 0 ? 1 : 0;
+                if (aux.gap_rows != nullptr) aux.gap_rows[tile0 + vt] = bad[5 * TS + vt] != 0 ? 1 : 0;
+                else if (bad[5 * TS + vt] != 0 && always_floor == 0 && !sample_bad(vt) && !(aux.bad_rows != nullptr && aux.bad_rows[tile0 + vt] != 0)) {
+                    // the caller promised curves without interior gaps (NMMA_STACK2_GAP_FREE: no re-evaluation launch follows) and this
+                    // row met one: the handle is poisoned -- every later call fails with a message -- instead of a silent floor
+                    g_ip wd = (g_ip)(uintptr_t)P.watchdog;
+                    wd[0] = 1; wd[1] = 950; wd[2] = (int)blockIdx.x; wd[3] = vt;
+                }
             }
             if (!SPLITTABLE || nb <= 1) {
                 double c = 0.0, g = 0.0;             // running sums in item (= observed-filter) order

@@ -384,8 +384,12 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
 
     gpu_model_kind = "external"
 
-    def __init__(self, model, filters, sample_times, model_parameters=(), cosmo_grid=None, device=0):
+    def __init__(self, model, filters, sample_times, model_parameters=(), cosmo_grid=None, device=0, gap_free=False):
+        """``gap_free``: the supplied curves never hold a non-finite node strictly inside the time grid (afterglowpy's are finite, or
+        the row is reported as failed: lightcurve_generation.py:259-283) -- a combined model's one-launch likelihood then skips its
+        re-evaluation launch; a curve that breaks the promise makes the next likelihood call raise."""
         super().__init__(model, filters, list(model_parameters), sample_times)
+        self.gap_free = bool(gap_free)
         self.cosmo_grid, self.device = cosmo_grid, device
         self._lc_engine, self._lc_names = None, None
 

@@ -475,12 +475,14 @@ class EMEngine:
                                                   self._stream()), "nmma_em_loglike_lc_sets")
         return out
 
-    def loglike_stack2(self, theta, lc2, bad_rows=None, out=None, stream=None):
+    def loglike_stack2(self, theta, lc2, bad_rows=None, out=None, stream=None, gap_free=False):
         """logL of the COMBINED model {this engine's surrogate + a second transient} in one launch: ``lc2[B, M, NS]`` are the second
         transient's source-frame curves on this engine's sample_times and model filters; the flux sum is formed on the two nodes
         every datum interpolates between (``nmma_em_loglike_stack2``).  Returns None when the handle has no one-launch form (not
         created with ``stack_operands=1``, or a configuration outside it): the caller then materialises the surrogate's curves
-        (``model_lightcurves``) and takes ``loglike_lc_sets`` on a likelihood-from-curves engine."""
+        (``model_lightcurves``) and takes ``loglike_lc_sets`` on a likelihood-from-curves engine.  ``gap_free=True``: the caller guarantees
+        that ``lc2`` has no non-finite node strictly inside the grid (e.g. afterglowpy curves: finite, or the row is in ``bad_rows``) --
+        the re-evaluation launch is skipped; a row that breaks the promise poisons the engine (the next call raises)."""
         import torch
         t = self._dev_theta(theta)
         shape = (t.shape[0], len(self.model_filters), self.n_sample_times)
@@ -498,7 +500,7 @@ class EMEngine:
             self._check_out(out, t.shape[0])
         status = self._lib.nmma_em_loglike_stack2(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0), C.c_void_p(lc2.data_ptr()),
                                                   C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
-                                                  self._stream(stream))
+                                                  L.STACK2_GAP_FREE if gap_free else 0, self._stream(stream))
         if status == 2:
             return None
         L.check(status, "nmma_em_loglike_stack2")

@@ -155,6 +155,36 @@ def test_one_launch_properties_and_batch_independence():
         e.close()
 
 
+def test_gap_free_promise_skips_the_re_evaluation_and_fails_loudly_when_broken():
+    """``gap_free=True`` (NMMA_STACK2_GAP_FREE): same values for curves that keep the promise (finite, or non-finite at the first /
+    last node only); a curve with an interior gap poisons the engine -- the next call raises and names the cause."""
+    import torch
+    from nmma_amd import _lib as L
+    case = cases_combined.case_combined()
+    one, kn, tail = _engines(case)
+    M, NS = len(case["filters"]), len(case["sample_times"])
+    rng = np.random.default_rng(3)
+    B = 700
+    th = torch.as_tensor(_theta(31, B), device="cuda:0")
+    lc2 = rng.uniform(-17.0, -12.0, (B, M, NS))
+    lc2[::3, :, 0] = np.inf
+    lc2[1::5, 4, NS - 1] = np.nan
+    lc2_t = torch.as_tensor(lc2, device="cuda:0")
+    safe = one.loglike_stack2(th, lc2_t)
+    fast = one.loglike_stack2(th, lc2_t, gap_free=True)
+    one.check()
+    assert torch.equal(safe, fast)
+    lc2[17, :, 4:30] = np.nan                               # gaps strictly inside the grid, where the data are: the promise is broken
+    one.loglike_stack2(th, torch.as_tensor(lc2, device="cuda:0"), gap_free=True)
+    with pytest.raises(L.NMMAHipError, match="NMMA_STACK2_GAP_FREE"):
+        one.check()
+    with pytest.raises(L.NMMAHipError, match="NMMA_STACK2_GAP_FREE"):
+        one.loglike_stack2(th, lc2_t)
+    for e in (kn, tail):
+        e.close()
+    one.close()
+
+
 def test_handles_without_a_one_launch_form_say_so():
     """``loglike_stack2`` returns None (the library: 2, nothing launched) for a handle not created for it, for sample_times that
     reach beyond the surrogate's grid (the flux sum is then finite where the kilonova is not: the task's window test would be

@@ -450,6 +450,31 @@ def test_multimessenger_conversion_chain_and_joint_setup():
     assert plain.multi_conversion is None and plain.parameter_conversion({"a": 1.0}) == {"a": 1.0}
 
 
+def test_combined_model_one_launch_plan_is_host_logic():
+    """``CombinedLightCurveModelContainer.stack2_plan``: two sub-models on ONE grid and filter list, one of them an SVD surrogate ->
+    (surrogate, other) and engine arguments that carry the COMBINATION's grid / cosmology / extinction with ``stack_operands=1``;
+    anything else (own grids or filter lists, three sub-models, no surrogate) -> None.  No GPU involved."""
+    from nmma_amd import synthetic as syn
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    filters = ["ps1::g", "ps1::r", "2massj"]
+    mp, svd = syn.make_svd_model(11, filters, model="Bu2019lm")
+    st = np.arange(0.1, 20.5, 0.5)
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    kn = SVDLightCurveModel("Bu2019lm", svd_mag_model=svd, filters=filters, model_parameters=mp, sample_times=st, cosmo_grid=grid)
+    grb = ExternalLightCurveModel("GRB", filters, st)
+    comb = CombinedLightCurveModelContainer([grb, kn], cosmo_grid=grid)          # (order does not matter: the flux sum is symmetric)
+    assert comb.stack2_plan() == (kn, grb)
+    kw = comb.stack2_engine_kwargs()
+    assert kw["stack_operands"] == 1 and kw["svd_model"] is kn.svd_mag_model and np.array_equal(kw["sample_times"], st)
+    assert kw["cosmo_grid"] is grid and "extinction_law" not in kw
+    other_grid = ExternalLightCurveModel("GRB", filters, np.geomspace(0.2, 30.0, 30))
+    assert CombinedLightCurveModelContainer([kn, other_grid], cosmo_grid=grid).stack2_plan() is None
+    other_filters = ExternalLightCurveModel("GRB", filters[:2], st)
+    assert CombinedLightCurveModelContainer([kn, other_filters], cosmo_grid=grid).stack2_plan() is None
+    assert CombinedLightCurveModelContainer([kn, grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
+    assert CombinedLightCurveModelContainer([grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
+
+
 def test_kernel_register_budget():
     """Code-object metadata of the built library: the lean kernels (em_logl<.., 1>, <.., 3>, <.., 4>, <.., 5>, <.., 6>) must not spill -- a change
     that made hipcc spill 2 600 registers in one of them went unnoticed by the parity tests and cost 50 % of its speed --
