@@ -15,14 +15,17 @@ LIB_PATH = os.environ.get("NMMA_HIP_LIB") or os.path.join(_HERE, "libnmma_hip.so
 SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: translation units of the library; every other file under csrc/ and include/ is a dependency of both
 #: translation units of libnmma_hip.so, longest first (they compile concurrently; build_library caps the number in flight).  em_logl's
-#: 38 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s.
-SOURCES = ("em_logl_w3.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_w2.hip", "em_kernels.hip", "em_logl_f5.hip", "em_logl_wc2.hip",
-           "em_logl_f02.hip", "em_logl_f7.hip", "em_logl_f8.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f1.hip", "gw_kernels.hip",
-           "walk_kernels.hip")
+#: 100 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s.
+SOURCES = ("em_kernels.hip", "em_logl_w5.hip", "em_logl_wc3.hip", "em_logl_w4.hip", "em_logl_w3.hip", "em_logl_wc1.hip", "em_logl_f5.hip",
+           "em_logl_w1.hip", "em_logl_w2.hip", "em_logl_f02.hip", "em_logl_wc2.hip", "em_logl_f7.hip", "em_logl_f3.hip", "em_logl_f8.hip",
+           "em_logl_f4.hip", "em_logl_f6.hip", "gw_kernels.hip", "em_logl_f1.hip", "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.
 UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
+
+#: seconds each unit took in this process's last build_library call (tools: order SOURCES longest first)
+UNIT_SECONDS = {}
 
 ABI_VERSION = 6
 STACK2_GAP_FREE = 1
@@ -244,14 +247,15 @@ def build_library(force=False, extra_flags=()):
     while todo or running:
         while todo and len(running) < slots:
             name, cmd = todo.pop(0)
-            running.append((name, subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)))
+            running.append((name, subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True), time.time()))
         for item in list(running):
-            name, proc = item
+            name, proc, t0 = item
             if proc.poll() is not None:
                 running.remove(item)
+                UNIT_SECONDS[name] = round(time.time() - t0, 1)
                 if proc.returncode != 0:
                     err = proc.stderr.read()
-                    for _, other in running:
+                    for _, other, _ in running:
                         other.kill()
                     raise NMMAHipError(f"hipcc failed on {name}:\n" + err[-4000:])
         if running:

@@ -1811,7 +1811,8 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
                                    (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : 0, (WALKF & 31) == 16 ? 16 : 0);
+                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : 0,
+                                   ((WALKF & 31) == 16 || (WALKF != 0 && R == 2)) ? (WALKF & 31) : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
     if (L.total > LDS_DYNAMIC_MAX) {
@@ -1890,5 +1891,16 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 72);    \
     NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 80);    \
     NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 80)
+// (the same on 32-sample tiles: queues beyond one round of 16-sample tiles -- 4096 chains)
+#define NMMA_LOGL_WALK2(FASTM)                 \
+    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 8);     \
+    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 8);     \
+    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 16);    \
+    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 16)
+#define NMMA_LOGL_WALK2_CON(FASTM)             \
+    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 72);    \
+    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 72);    \
+    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 80);    \
+    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 80)
 
 }  // namespace nmma

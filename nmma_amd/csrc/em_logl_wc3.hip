@@ -1,0 +1,12 @@
+// em_logl_wc3.hip -- em_logl instantiations: the fused MCMC step with a Constraint program on 32-sample tiles
+#include "em_logl.h"
+
+namespace nmma {
+
+#ifndef NMMA_DEV_HEADLINE_ONLY
+NMMA_LOGL_WALK2_CON(1);
+NMMA_LOGL_WALK2_CON(3);
+NMMA_LOGL_WALK2_CON(4);
+#endif
+
+}  // namespace nmma

@@ -511,9 +511,9 @@ int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma
     // One launch per MCMC step where the handle's task flavour carries the fused step (accept + next proposal in the likelihood
     // kernel's epilogue, nmma_em_loglike_walk); else the likelihood launch followed by walk_step_kernel.  Same device functions,
     // same bits.
-    // (queues beyond 4096 chains keep two launches per step: the fused step exists for 16-sample tiles -- one round of workgroups --
-    //  and walking a longer queue in chunks of 4096 chains loses to the likelihood's 32-sample tiles + walk_step_kernel:
-    //  8192 chains x 100 steps 6.15 against 5.37 ms for config 2, profiles/r05_fused_mcmc_step.md)
+    // (queues beyond 4096 chains -- one round of 16-sample tiles -- run the fused step on the likelihood's 32-sample tiles; walking them
+    //  in chunks of 4096 chains lost to two launches per step: 8192 chains x 100 steps 6.15 against 5.37 ms for config 2,
+    //  profiles/r05_fused_mcmc_step.md)
     bool fused = true;
     const nmma_walk_fuse* wf_d = reinterpret_cast<const nmma_walk_fuse*>(d + o_wf);
     for (int k = 1; k <= max_walks; ++k) {

@@ -102,7 +102,7 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     w = smp.EnsembleWalkSampler(ndim=len(names), periodic=[1], reflective=[2], walks=7)
     table = smp.device_prior_table(pri, names, w.periodic, w.reflective)
     rng = np.random.default_rng(71)
-    for n in (1, 37, 1000, 4096):
+    for n in (1, 37, 1000, 4096, 4500):          # (beyond 4096 chains: the step on 32-sample tiles)
         n_live = 300
         live = rng.uniform(0.2, 0.8, (n_live, len(names)))
         u0 = live[rng.integers(0, n_live, n)].copy()
@@ -134,7 +134,7 @@ def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
 @pytest.mark.parametrize("name", ["c2_default", "syserr_param", "log_grid", "syserr_per_filter"])
 def test_fused_mcmc_step_with_constraints_and_long_queues(torch_cuda, name):
     """The one-launch MCMC step with the chains' Constraint program evaluated in it (``em_logl<..., WALKF | 64>``: the interpreter's
-    stack in LDS) and for queues of more than 4096 chains (walked in chunks of 4096: each chunk one full round of workgroups):
+    stack in LDS) and for queues of more than 4096 chains (the step in the 32-sample-tile kernels, four / eight rounds of chains per tile):
     the same bits as the likelihood launch + ``walk_step_kernel`` -- 6, 7 and 15 sampled dimensions (8 / 16 lanes per chain)."""
     from nmma_amd.core.constraints import ConstraintProgram
     from nmma_amd import _lib as L

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Engine-level queue (nmma_em_walk_queue) of 1024 / 4096 / 8192 chains x 100 steps for golden-case configurations: the fused MCMC step
+"""Engine-level queue (nmma_em_walk_queue) of 1024 / 4096 / 8192 / 16384 chains (NMMA_PERF_CHAINS) x 100 steps for golden-case configurations: the fused MCMC step
 against two launches per step; with ``+con`` after a case name also under a Constraint program (its interpreter in the fused step).
 Usage: perf_walk_queue_cases.py case[,case...]"""
 import os
@@ -48,14 +48,14 @@ for spec in (sys.argv[1].split(",") if len(sys.argv) > 1 else DEFAULT):
                                  (L.CON_PUSH_COL, c5, 0.0), (L.CON_POW, 0, 0.0), (L.CON_ADD, 0, 0.0), (L.CON_CHECK_LT, 0, 1.5 * mid),
                                  (L.CON_PUSH_COL, 3, 0.0), (L.CON_CHECK_GT, 0, float(np.quantile(th[:, 3], 0.02))), (L.CON_CHECK_LT, 0, 1e300)],
                                 len(names), 0)
-    for n in (1024, 4096, 8192):
+    for n in [int(x) for x in os.environ.get("NMMA_PERF_CHAINS", "1024,4096,8192,16384").split(",")]:
         live = rng.uniform(0.2, 0.8, (n, len(names)))
         u0 = live.copy()
         bound = np.full(n, np.quantile(eng.loglike(np.ascontiguousarray(pt(live))), 0.2))
         keys = rng.integers(1, 2 ** 62, n).astype(np.uint64)
         out = []
-        for nofuse in (False, True):
-            eng.set_option("walk_fuse", 0 if nofuse else 1)
+        for fuse in (2, 0):          # (2: the fused step wherever an instantiation exists, also where the library prefers two launches)
+            eng.set_option("walk_fuse", fuse)
             eng.walk_queue(table, live, u0, bound, keys, 100, constraints=con)
             ts = []
             for _ in range(5):
