@@ -231,11 +231,13 @@ int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int6
  * nmma_em_loglike_lc_sets, restricted to those rows.  bad_rows_dev (or NULL): [B] bytes, non-zero = a sub-model delivered no light
  * curve for this row (model.py:1423-1426) -> floor.  flags: NMMA_STACK2_GAP_FREE = the caller guarantees that lc2 has no non-finite
  * node strictly inside the grid (an afterglowpy curve is finite or the row fails altogether, lightcurve_generation.py:259-283; +inf /
- * NaN at the first / last node are fine) -- the re-evaluation launch is then not enqueued (6 us of 91 at BASELINE config 3's shape);
+ * NaN at the first / last node are fine) -- the re-evaluation launch is then not enqueued (4 us of 89 at BASELINE config 3's shape);
  * a row that breaks the promise is floored AND poisons the handle: every later call fails with a message saying so.
- * Returns 2 -- nothing launched -- when the handle has no one-launch form (not
- * created with stack_operands = 1; a task flavour other than the lean one; sample_times reaching beyond the surrogate's grid):
- * the caller then takes nmma_em_model_lightcurves + nmma_em_loglike_lc_sets.  Asynchronous. */
+ * Returns 2 -- nothing launched, nmma_last_error() says why -- when the handle has no one-launch form (not created with
+ * stack_operands = 1; a configuration that needs the general task: finite detection limits, averaged bands, time-node systematics,
+ * other than 10 coefficients; sample_times reaching beyond the surrogate's grid; more curve nodes per sample than the
+ * re-evaluation kernel stages -- 4 x M x NS x 8 bytes within 159 KiB of LDS): the caller then takes nmma_em_model_lightcurves +
+ * nmma_em_loglike_lc_sets.  Asynchronous. */
 #define NMMA_STACK2_GAP_FREE 1
 int32_t nmma_em_loglike_stack2(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* lc2_dev,
                                const uint8_t* bad_rows_dev, double* out_dev, int32_t flags, void* stream);

@@ -331,8 +331,9 @@ class EMEngine:
         return kind, _f64(const), nn, off, slots, _f64(node_t if node_t else [0.0])
 
     @classmethod
-    def from_case(cls, case, device=0):
-        """Engine for a case dict of ``nmma_amd.synthetic.make_case`` (what bench.py, smoke() and the parity tests build)."""
+    def from_case(cls, case, device=0, **extra):
+        """Engine for a case dict of ``nmma_amd.synthetic.make_case`` (what bench.py, smoke() and the parity tests build);
+        ``extra``: further constructor arguments (e.g. ``stack_operands=1``)."""
         from .em.utils import FILTER_AVERAGES, resolve_sources
         obs = list(case["observed_filters"])
         lim = case["detection_limit"]
@@ -346,7 +347,7 @@ class EMEngine:
                    detection_limit=lim, systematics=case["systematics"], ebv_coeff=case.get("ebv_coeff"),
                    filter_nu0=case.get("filter_nu0"),
                    extinction_law="P92_SMC_host" if case.get("filter_nu0") is not None else None,
-                   hubble_reference=case.get("hubble_reference"), device=device)
+                   hubble_reference=case.get("hubble_reference"), device=device, **extra)
 
     # ------------------------------------------------------------------ calls
     def _dev_theta(self, theta):
@@ -482,7 +483,8 @@ class EMEngine:
         created with ``stack_operands=1``, or a configuration outside it): the caller then materialises the surrogate's curves
         (``model_lightcurves``) and takes ``loglike_lc_sets`` on a likelihood-from-curves engine.  ``gap_free=True``: the caller guarantees
         that ``lc2`` has no non-finite node strictly inside the grid (e.g. afterglowpy curves: finite, or the row is in ``bad_rows``) --
-        the re-evaluation launch is skipped; a row that breaks the promise poisons the engine (the next call raises)."""
+        the re-evaluation launch is skipped; a row that breaks the promise poisons the engine (the next call raises).
+        After a None, ``stack2_reason`` says why the handle has no one-launch form."""
         import torch
         t = self._dev_theta(theta)
         shape = (t.shape[0], len(self.model_filters), self.n_sample_times)
@@ -502,6 +504,7 @@ class EMEngine:
                                                   C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
                                                   L.STACK2_GAP_FREE if gap_free else 0, self._stream(stream))
         if status == 2:
+            self.stack2_reason = L.last_error()       # why the handle has no one-launch form
             return None
         L.check(status, "nmma_em_loglike_stack2")
         return out

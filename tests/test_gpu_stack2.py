@@ -232,6 +232,68 @@ def test_one_launch_on_a_log_spaced_grid():
         e.close()
 
 
+MIX_CASES = ["c2_default", "c2_dt05", "grid_subset", "syserr_param", "fast_np6", "ncoeff7", "fast_many_filters", "fast_single_filter",
+             "fixed_distance", "conversions", "conversions_cos", "real_nets", "bulla_svd", "log_grid", "nonuniform_tt", "extinction_linear",
+             "hubble_sampled", "edges", "unobserved_filter_overflow", "c2_dt05_limit", "averaging", "c4_shape"]
+
+
+@pytest.mark.parametrize("name", MIX_CASES)
+def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
+    """The flavour with the operand (FASTM 7 / 8) under the features of the single-model cases -- sampled systematics, extinction,
+    six-parameter surrogates, two-stage grids, unequally spaced grids, conversions, a fixed distance, real networks, samples pushed
+    off the model window.  With a second transient 60 mag fainter than anything the surrogate emits the flux sum IS the kilonova's
+    magnitude (min(kn, m2) - g(|kn - m2|), g < 1e-20), so log L must be the single-model likelihood of the same handle's plain
+    flavour -- which the golden vectors of these cases pin to the reference.  Cases whose handle has no one-launch form (the general
+    task: limits, averaged bands, other than 10 coefficients) must say so (status 2 -> None, with the reason); config 4's shape
+    takes the row-form lean task under the operand (the plain handle: the dense task -- agreement to 1e-12)."""
+    import torch
+    from nmma_amd.engine import EMEngine
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    plain = EMEngine.from_case(case)
+    one = EMEngine.from_case(case, stack_operands=1)
+    th = torch.as_tensor(np.ascontiguousarray(case["theta"]), device="cuda:0")
+    B, M, NS = th.shape[0], len(case["model_filters"]), one.n_sample_times
+    faint = torch.full((B, M, NS), 45.0, dtype=torch.float64, device="cuda:0")
+    want = plain.loglike(th).cpu().numpy()
+    got = one.loglike_stack2(th, faint)
+    # no one-launch form: the general task (limits / averaged bands; surrogates with other than 10 coefficients -- ncoeff7, bulla_svd;
+    # a model filter nobody observed)
+    no_form = {"c2_dt05_limit": "general task", "averaging": "general task", "ncoeff7": "general task", "bulla_svd": "general task",
+               "unobserved_filter_overflow": "general task"}
+    if name in no_form:
+        assert got is None, name
+        assert no_form[name] in one.stack2_reason, (name, one.stack2_reason)
+        # ... and the handle still evaluates the single model
+        assert np.array_equal(one.loglike(th).cpu().numpy(), want)
+    else:
+        assert got is not None, (name, getattr(one, "stack2_reason", None))
+        one.check()
+        got = got.cpu().numpy()
+        assert np.array_equal(got == FLOOR, want == FLOOR), name
+        fin = want > FLOOR
+        err = rel_err(got[fin], want[fin]).max() if fin.any() else 0.0
+        print(f"{name}: one-launch flavour with a dark second transient vs the plain flavour: max rel {err:.2e} over {int(fin.sum())} rows")
+        assert err <= 1e-12, name
+        # the promise form takes the same rows through the kernel alone
+        again = one.loglike_stack2(th, faint, gap_free=True).cpu().numpy()
+        assert np.array_equal(again, got)
+        one.check()
+        # a hole in every third row's dark curves: autocomplete_data fills it from the (equally dark) neighbours, so nothing changes
+        # -- but those rows now come from the re-evaluation kernel (the surrogate's curves + likelihood from curves, under the same
+        # features: sampled systematics, extinction, two-stage / unequally spaced grids, six-parameter surrogates)
+        holes = faint.clone()
+        holes[::3, :, 1:NS - 1:4] = float("nan")
+        redo = one.loglike_stack2(th, holes).cpu().numpy()
+        one.check()
+        assert np.array_equal(redo == FLOOR, want == FLOOR), name
+        err_r = rel_err(redo[fin], want[fin]).max() if fin.any() else 0.0
+        print(f"   re-evaluated rows: max rel {err_r:.2e}; {int((redo != got).sum())} of {B} rows changed bits")
+        assert err_r <= FUSED_VS_MATERIALISED_RTOL, name
+        keep = np.ones(B, dtype=bool); keep[::3] = False
+        assert np.array_equal(redo[keep], got[keep])
+    plain.close(); one.close()
+
+
 def test_union_grid_combination_keeps_the_materialising_path():
     """Sub-models with different grids / filter lists (golden ``combined_union``) have no one-launch plan."""
     from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
