@@ -818,8 +818,15 @@ __device__ __noinline__ void stack2_redo_tile(
     double* __restrict__ out, const unsigned char* __restrict__ only_rows, const long tile) {
     constexpr int TS = 32, SPB = 4 * (64 / G);
     const int M = Pp->M;
+    // (the surrogate's curves of this tile go to THIS WORKGROUP's 32 rows of the workspace, whatever the tile's position in the batch:
+    //  both bodies index by batch row, so the base is moved back by the tile's offset -- the workspace then holds gridDim.x x 32
+    //  rows instead of B)
+    const long shift = ((long)blockIdx.x - tile) * TS * M * Pp->NS;
+    double* const ws = kn_ws + shift;
+    LcSets own = sets;
+    own.p[0] = ws;
     for (int m = 0; m < M; ++m) {
-        em_fused_body<MODE_LC_ABS, 2, 4, KP>(Pp, theta, B, ld, Lf, nullptr, nullptr, kn_ws, (unsigned)tile, m);
+        em_fused_body<MODE_LC_ABS, 2, 4, KP>(Pp, theta, B, ld, Lf, nullptr, nullptr, ws, (unsigned)tile, m);
         __syncthreads();
     }
     __threadfence();          // the curves this workgroup just wrote are what it reads next
@@ -827,7 +834,7 @@ __device__ __noinline__ void stack2_redo_tile(
     for (int q = 0; q < TS / SPB; ++q) {
         const long blk = tile * (TS / SPB) + q;
         if (blk * SPB < B)
-            em_lc_loglike_body<G, 2, SD, true, true>(Pp, theta, B, ld, sets, 2, bad_rows, lds_per_sample, always_floor, out, nullptr, nullptr,
+            em_lc_loglike_body<G, 2, SD, true, true>(Pp, theta, B, ld, own, 2, bad_rows, lds_per_sample, always_floor, out, nullptr, nullptr,
                                                      only_rows, (unsigned)blk);
         __syncthreads();
     }

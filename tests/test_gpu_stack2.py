@@ -79,7 +79,7 @@ def test_golden_combined_goes_through_the_one_launch_form():
     assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
 
 
-@pytest.mark.parametrize("B", [1, 5, 16, 17, 333, 4100])
+@pytest.mark.parametrize("B", [1, 5, 16, 17, 333, 4100, 20011])      # (20011: more tiles than workgroups in the re-evaluation launch)
 def test_one_launch_against_materialised_with_gaps_and_edges(B):
     """Second-transient curves with everything the operand contract allows: finite, +inf at the first / last nodes (the edge of its
     time range: handled in the task), +inf over the first three nodes, NaN / inf holes in the middle (gaps autocomplete_data fills),
