@@ -589,13 +589,16 @@ class OracleCombinedModel:
 
 class OraclePowerLawModel:
     """Synthetic stand-in for a GRB afterglow (the real one is third-party afterglowpy):
-    abs mag = grb_mag0 + 2.5 * grb_slope * log10(t / 1 day), defined for t >= t_start."""
+    abs mag = grb_mag0 + 2.5 * grb_slope * log10(t / 1 day), defined for t >= t_start.
+    ``hole = (first, last, slope_threshold)``: parameter vectors with ``grb_slope`` above the threshold leave the nodes
+    first..last (indices of the requested times) without a value (NaN) -- what the combined model's
+    ``autocomplete_data`` (nmma/em/model.py:1440-1448) fills from the finite neighbours."""
 
     model_parameters = ["grb_mag0", "grb_slope"]
 
-    def __init__(self, filters, sample_times, cosmo_grid=None, t_start=0.3, colour=0.15):
+    def __init__(self, filters, sample_times, cosmo_grid=None, t_start=0.3, colour=0.15, hole=None):
         self.filters, self.model_times = list(filters), np.asarray(sample_times, float)
-        self.cosmo_grid, self.t_start, self.colour = cosmo_grid, t_start, colour
+        self.cosmo_grid, self.t_start, self.colour, self.hole = cosmo_grid, t_start, colour, hole
         self.good_parameters = True
 
     def parameter_conversion(self, parameters):
@@ -607,7 +610,11 @@ class OraclePowerLawModel:
         lc = {}
         for k, f in enumerate(self.filters):
             v = base + self.colour * k
-            lc[f] = np.where(sample_times >= self.t_start, v, np.inf)
+            v = np.where(sample_times >= self.t_start, v, np.inf)
+            if self.hole is not None and parameters["grb_slope"] > self.hole[2]:
+                v = v.copy()
+                v[self.hole[0] + (k % 2): self.hole[1] + 1] = np.nan        # (the hole starts one node later in every other filter)
+            lc[f] = v
         return lc
 
     def gen_detector_lc(self, parameters, sample_times=None):

@@ -24,13 +24,37 @@ def case_combined(seed=9123, batch=48):
                 cosmo_grid=grid, data=data, names=NAMES, theta=theta)
 
 
+def case_combined_syserr(seed=9323, batch=40):
+    """The shared-grid combination with a SAMPLED systematic (``em_syserr``, FilterSystematicsHandler.from_param) and a second
+    transient whose curves have an interior hole for the steeper half of its slope prior -- the reference fills it from the
+    finite neighbours (autocomplete_data, model.py:1440-1448); in the one-launch form those rows take the re-evaluation launch."""
+    c = case_combined(seed=seed, batch=batch)
+    rng = np.random.default_rng(seed + 5)
+    c["names"] = NAMES + ["em_syserr"]
+    c["theta"] = np.concatenate([c["theta"], rng.uniform(0.1, 1.5, (batch, 1))], axis=1)
+    c["systematics"] = dict(mode="param", name="em_syserr")
+    c["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    c["grb_hole"] = (9, 12, 1.2)
+    return c
+
+
+def case_combined_loggrid(seed=9423, batch=40):
+    """The shared-grid combination on the CLI's log-spaced grid (unequally spaced sample_times: bracket search instead of the index
+    guess), with the same interior holes."""
+    c = case_combined(seed=seed, batch=batch)
+    c["sample_times"] = np.geomspace(0.1, 20.0, 36)
+    c["grb_hole"] = (14, 16, 1.2)
+    return c
+
+
 def oracle_likelihood(case, use_scipy=True):
     from oracle import nmma_oracle as orc
     kn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=case["filters"],
                             sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
-    grb = orc.OraclePowerLawModel(case["filters"], case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = orc.OraclePowerLawModel(case["filters"], case["sample_times"], cosmo_grid=case["cosmo_grid"], hole=case.get("grb_hole"))
     comb = orc.OracleCombinedModel([kn, grb])
-    return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in case["filters"]}),
+    systematics = case.get("systematics") or dict(mode="budget", values={f: 1.0 for f in case["filters"]})
+    return orc.OracleLikelihood(comb, case["data"], systematics,
                                 case["filters"], detection_limit=np.inf, known_filters=case["filters"],
                                 use_scipy=use_scipy), grb
 

@@ -44,7 +44,9 @@ def _plugin(case):
     grb = ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"])
     comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
     times, mags, sigmas = case["data"]
-    handler = FilterSystematicsHandler(case["filters"], error_budget=1.0, light_curve_times=times)
+    sys_ref = case.get("systematics_ref") or dict(error_budget=1.0, systematics_file=None)
+    handler = FilterSystematicsHandler(case["filters"], systematics_file=sys_ref["systematics_file"], error_budget=sys_ref["error_budget"],
+                                       light_curve_times=times)
     priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
     return EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors, filters=case["filters"])
 
@@ -77,6 +79,40 @@ def test_golden_combined_goes_through_the_one_launch_form():
     ok[[3, 17]] = False
     got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
     assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+@pytest.mark.parametrize("name", ["combined_syserr", "combined_loggrid"])
+def test_golden_combinations_with_extras_and_holes(name):
+    """Reference-made goldens of the shared-grid combination with a SAMPLED systematic (the task's sigma_tot per datum) and on the CLI's
+    log-spaced grid (em_logl<.., 8>: bracket search), the second transient's curves with an interior hole in 18 of 40 rows (the
+    reference fills it: autocomplete_data, model.py:1440-1448 -- here those rows take the re-evaluation launch): through the plugin,
+    which picks the one-launch engine, at 1e-6 against the reference; the materialising path agrees to 1e-10."""
+    import torch
+    case = getattr(cases_combined, "case_" + name)()
+    gold = cases.load_golden(name)
+    _, grb_oracle = cases_combined.oracle_likelihood(case)
+    lik = _plugin(case)
+    st = case["sample_times"]
+    ext = np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), st)[f] for f in case["filters"]])
+                    for row in case["theta"]])
+    holes = np.isnan(ext).any(axis=(1, 2))
+    assert 10 <= holes.sum() <= 30
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    err = rel_err(got, gold["logl"])
+    print(f"{name} through the one-launch form: max rel err vs the reference {err.max():.3e} (rows with holes: {err[holes].max():.3e})")
+    assert np.array_equal(got == FLOOR, gold["logl"] == FLOOR) and err.max() <= 1e-6
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    assert rel_err(got, mat).max() <= FUSED_VS_MATERIALISED_RTOL
+    # re-evaluated rows carry the materialising kernels' own bits (a row is re-evaluated when one of its data brackets a hole node:
+    # always for combined_syserr's hole at 4.6-6.1 days; on the log grid the hole spans 0.8-1.1 days, which few epochs reach)
+    same = got[holes] == mat[holes]
+    print(f"   {int(same.sum())} of {int(holes.sum())} rows with a hole were re-evaluated")
+    if name == "combined_syserr":
+        assert same.all()
+    sub._stack2_off = False
 
 
 @pytest.mark.parametrize("B", [1, 5, 16, 17, 333, 4100, 20011])      # (20011: more tiles than workgroups in the re-evaluation launch)

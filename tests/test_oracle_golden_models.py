@@ -1,6 +1,7 @@
 """CPU: the Me2017 (config 1) and combined-model (config 3 shape) oracles against the golden
 vectors produced by the reference's own source."""
 import numpy as np
+import pytest
 
 from oracle import nmma_oracle as orc
 from tests import cases, cases_combined, cases_me2017
@@ -27,6 +28,27 @@ def test_combined_oracle_matches_golden():
     lik, _ = cases_combined.oracle_likelihood(case)
     got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
     np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["combined_syserr", "combined_loggrid"])
+def test_combined_extras_oracle_matches_golden(name):
+    """Shared-grid combinations with a sampled systematic / on the log-spaced grid, the second transient's curves with an interior hole
+    for part of the rows (filled by the reference's autocomplete_data): the oracle against the reference-made golden, stage by stage."""
+    case = getattr(cases_combined, "case_" + name)()
+    gold = cases.load_golden(name)
+    lik, _ = cases_combined.oracle_likelihood(case)
+    rows = np.r_[0:10, np.nonzero(case["theta"][:, 7] > case["grb_hole"][2])[0][:6]]      # (some rows without, some with holes)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][rows])
+    np.testing.assert_allclose(got, gold["logl"][rows], rtol=1e-12)
+    for i in range(3):
+        p = lik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in case["theta"][i]))))
+        tobs, lc = lik.model.gen_detector_lc(p)
+        np.testing.assert_allclose(tobs, gold[f"s{i}_obs_times"], rtol=1e-15)
+        for f in case["filters"]:
+            want = gold[f"s{i}_app_{f}"]
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isfinite(lc[f]), fin)
+            np.testing.assert_allclose(lc[f][fin], want[fin], rtol=1e-13)
 
 
 def test_combined_union_oracle_matches_golden():

@@ -45,6 +45,16 @@ def test_reference_reproduces_combined_golden():
     np.testing.assert_allclose(got, cases.load_golden("combined")["logl"], rtol=1e-13)
 
 
+@pytest.mark.parametrize("name", ["combined_syserr", "combined_loggrid"])
+def test_reference_reproduces_combined_extras_golden(name):
+    from tests import cases_combined
+    from tools.make_golden_combined import build_reference
+    case = getattr(cases_combined, "case_" + name)()
+    lik, _ = build_reference(case)
+    got = _rows(lik, case["names"], case["theta"])
+    np.testing.assert_allclose(got, cases.load_golden(name)["logl"], rtol=1e-13)
+
+
 def test_reference_reproduces_combined_union_golden():
     from tests import cases_combined
     from tools.make_golden_combined import build_reference

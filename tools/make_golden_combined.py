@@ -2,7 +2,7 @@
 """Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
 CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
 sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
-is third-party and absent).  Output: tests/golden/combined.npz."""
+is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz."""
 import os
 import sys
 
@@ -42,7 +42,7 @@ def build_reference(case):
     kn.model_times, kn.redshift_func = case["sample_times"], zfun
     kn.check_vs_priors = lambda priors: None
 
-    helper = orc.OraclePowerLawModel(grb_filters, grb_times)
+    helper = orc.OraclePowerLawModel(grb_filters, grb_times, hole=case.get("grb_hole"))
 
     class PowerLawGRB(ref.model.LightCurveModelContainer):
         def __init__(self):
@@ -61,7 +61,9 @@ def build_reference(case):
     comb = ref.model.CombinedLightCurveModelContainer([kn, PowerLawGRB()])
     times, mags, sigmas = case["data"]
     priors = ref.base.PriorDict({n: object() for n in case["names"]})
-    handler = ref.systematics.FilterSystematicsHandler(obs_filters, error_budget=1.0, light_curve_times=times)
+    sys_ref = case.get("systematics_ref") or dict(error_budget=1.0, systematics_file=None)
+    handler = ref.systematics.FilterSystematicsHandler(obs_filters, systematics_file=sys_ref["systematics_file"],
+                                                       error_budget=sys_ref["error_budget"], light_curve_times=times)
     lik = ref.em_likelihood.EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors,
                                                   filters=obs_filters, detection_limit=np.inf)
     return lik, comb
@@ -109,6 +111,8 @@ def main():
             out[f"s{i}_app_{k}"] = np.asarray(lc[f], float)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "combined.npz"), **out)
     run(cases_combined.case_combined_union(), cases_combined.oracle_likelihood_union, "combined_union")
+    run(cases_combined.case_combined_syserr(), cases_combined.oracle_likelihood, "combined_syserr")
+    run(cases_combined.case_combined_loggrid(), cases_combined.oracle_likelihood, "combined_loggrid")
 
 
 if __name__ == "__main__":

@@ -77,6 +77,7 @@ rel = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
 print(f"config 3 shape B={B}: em_logl<.., 7> + the re-evaluation launch (stack2_redo, nothing flagged) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call; "
       f"max rel diff to the materialising path {rel:.2e}")
 print(f"   with the gap-free promise (NMMA_STACK2_GAP_FREE: no re-evaluation launch) {timeit(lambda: one.loglike_stack2(t, ext, gap_free=True)):8.1f} us per call")
+print(f"   the same handle's single-model likelihood (the kilonova alone, no operand: what the flux sum adds) {timeit(lambda: one.loglike(t)):8.1f} us per call")
 one.set_option("stack2_fixup", 0)             # (measurement only: the kernel alone, without the re-evaluation launch)
 print(f"   em_logl<.., 7> alone (no re-evaluation launch) {timeit(lambda: one.loglike_stack2(t, ext)):8.1f} us per call")
 one.close()
