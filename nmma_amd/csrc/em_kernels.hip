@@ -871,13 +871,28 @@ constexpr double sigSB = 5.6703744191844314e-05, D10pc = 10 * 3.085677581491367e
 constexpr int MPREC = 300, NL = MPREC - 1, LPL = 5;   // layers per lane (5 * 64 >= 299)
 }  // namespace me17
 
+// (value, index) of the wave's smallest value, the lowest index among equals (np.argmin), in every lane.  The same DPP steps as
+// group_sum -- lexicographic min is idempotent, so the overlapping mirror steps are as good as a butterfly -- instead of 18 dependent
+// ds_bpermute round trips per call: the explicit-Euler loop of me2017_lc calls this once per time step with nothing to hide behind.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_step(double& v, int& idx) {
+    const double ov = dpp_mov_f64<CTRL, ROW_MASK>(v);
+    const int oi = __builtin_amdgcn_mov_dpp(idx, CTRL, ROW_MASK, 0xf, false);
+    // (rows a row_mask leaves out read undefined values: they never hold the wave's result, which is taken from lane 63)
+    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
+
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    argmin_step<0xB1, 0xf>(v, idx);     // quad_perm [1,0,3,2]
+    argmin_step<0x4E, 0xf>(v, idx);     // quad_perm [2,3,0,1]
+    argmin_step<0x141, 0xf>(v, idx);    // row_half_mirror
+    argmin_step<0x140, 0xf>(v, idx);    // row_mirror: every lane holds its row's result
+    argmin_step<0x142, 0xA>(v, idx);    // row_bcast15 into rows 1 and 3
+    argmin_step<0x143, 0xC>(v, idx);    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    v = __hiloint2double(hi, lo);
+    idx = __builtin_amdgcn_readlane(idx, 63);
 }
 
 __global__ __launch_bounds__(256) void me2017_lc(const EmDev* __restrict__ Pp, const double* __restrict__ theta,
