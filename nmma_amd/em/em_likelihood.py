@@ -118,6 +118,9 @@ class MultiFilterTransient:
         """One parameter dict -> float (em_likelihood.py:186-204)."""
         names = self._names or self.sampling_layout()[0]
         names = [n for n in names if n in parameters] if self._names is None else names
+        if hasattr(self.light_curve_model, "stacked_lightcurves_abs"):      # a combined model: the batched path with one row
+            val = float(self.log_likelihood_batch(np.array([[float(parameters[n]) for n in names]]), names)[0])
+            return -np.inf if val == LOGL_FLOOR else val
         eng = self.engine(names)
         theta = np.array([[float(parameters[n]) for n in eng.parameter_names]])
         val = float(eng.loglike(theta)[0])
@@ -134,6 +137,10 @@ class MultiFilterTransient:
             import torch
             th = torch.as_tensor(np.asarray(theta)) if not isinstance(theta, torch.Tensor) else theta
             out = None
+            if hasattr(model, "host_operands"):             # sub-models whose curves a host callable computes (e.g. afterglowpy)
+                lay_names, fixed = self.sampling_layout()
+                use = list(names) if names is not None else (self._names2 or self._names or lay_names)
+                external_lc = model.host_operands(th, use, {k: v for k, v in fixed.items() if k not in use}, external_lc)
             if not self._stack2_off and model.stack2_plan() is not None:
                 # two sub-models on one grid (the reference drivers' case): ONE launch, the surrogate's curves never leave the chip
                 eng2 = self.stack2_engine(names)

@@ -384,17 +384,54 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
 
     gpu_model_kind = "external"
 
-    def __init__(self, model, filters, sample_times, model_parameters=(), cosmo_grid=None, device=0, gap_free=False):
+    def __init__(self, model, filters, sample_times, model_parameters=(), cosmo_grid=None, device=0, gap_free=False,
+                 generate_lightcurve=None):
         """``gap_free``: the supplied curves never hold a non-finite node strictly inside the time grid (afterglowpy's are finite, or
         the row is reported as failed: lightcurve_generation.py:259-283) -- a combined model's one-launch likelihood then skips its
-        re-evaluation launch; a curve that breaks the promise makes the next likelihood call raise."""
+        re-evaluation launch; a curve that breaks the promise makes the next likelihood call raise.
+        ``generate_lightcurve``: a host callable with the reference's model signature, ``(sample_times, parameters: dict) ->
+        {filter: abs_mag[NS]}`` or something falsy when the model has no light curve for these parameters (model.py:378-379, :1423-1426)
+        -- e.g. the bound ``generate_lightcurve`` of the reference's own ``GRBLightCurveModel``.  With it the likelihood needs no
+        ``external_lc``: ``log_likelihood(parameters)``, ``log_likelihood_batch(theta)`` and a ``GPUPool`` call it once per row on the
+        host, then evaluate the whole batch in one launch."""
         super().__init__(model, filters, list(model_parameters), sample_times)
         self.gap_free = bool(gap_free)
         self.cosmo_grid, self.device = cosmo_grid, device
         self._lc_engine, self._lc_names = None, None
+        self.generator = generate_lightcurve
+
+    def generate_lightcurve(self, sample_times, parameters):
+        """model.py:405-408: the model's source-frame light curve for one parameter dict (the supplied callable's)."""
+        if self.generator is None:
+            raise RuntimeError(f"external model {self.model!r} has no `generate_lightcurve` callable")
+        return self.generator(sample_times, parameters)
+
+    def generate_batch(self, theta, names, fixed=None, conversion=None):
+        """``(lc[B, M, NS] float64, ok[B] bool)`` from one host call of the generator per row: every row's dict holds the sampled
+        columns, the fixed parameters and what ``conversion`` (the likelihood's parameter conversion chain) derives from them; a
+        falsy result marks the row as failed (the combined model then returns no light curve: model.py:1423-1426 -> floor); a filter
+        the generator does not return stays +inf (no flux)."""
+        theta = np.asarray(theta, dtype=float)
+        st = np.asarray(self.model_times, float)
+        lc = np.full((len(theta), len(self.filters), len(st)), np.inf)
+        ok = np.ones(len(theta), dtype=bool)
+        for i, row in enumerate(theta):
+            p = dict(fixed or {})
+            p.update(zip(names, (float(v) for v in row)))
+            if conversion is not None:
+                p = conversion(p)
+            res = self.generate_lightcurve(st, p)
+            if not res:
+                ok[i] = False
+                continue
+            for k, f in enumerate(self.filters):
+                if f in res:
+                    lc[i, k] = np.asarray(res[f], dtype=float)
+        return lc, ok
 
     def lightcurves_abs(self, theta, names):
-        raise RuntimeError(f"light curves of external model {self.model!r} must be passed in `external_lc`")
+        raise RuntimeError(f"light curves of external model {self.model!r} must be passed in `external_lc` "
+                           "(or give the model a `generate_lightcurve` callable)")
 
 
 class CombinedLightCurveModelContainer(_TensorModelMixin):
@@ -471,6 +508,17 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         for m in self.lc_models:
             parameters = m.parameter_conversion(parameters)
         return parameters
+
+    def host_operands(self, theta, names, fixed=None, have=None):
+        """``external_lc`` entries -- ``{model name: (lc[B, M_k, NS_k], ok[B])}`` -- of every external sub-model that brings its own
+        ``generate_lightcurve`` callable and is not in ``have`` already: one host call per row, with the combination's parameter
+        conversion chain applied first (model.py:1405-1408)."""
+        out = dict(have or {})
+        for m in self.lc_models:
+            if isinstance(m, ExternalLightCurveModel) and m.model not in out and m.generator is not None:
+                th = theta.detach().cpu().numpy() if hasattr(theta, "detach") else np.asarray(theta)
+                out[m.model] = m.generate_batch(th, names, fixed, self.parameter_conversion)
+        return out
 
     def stack2_plan(self):
         """``(surrogate_model, other_model)`` when the combination can be evaluated in ONE launch (``EMEngine.loglike_stack2``): two

@@ -35,13 +35,14 @@ def _theta(seed, B):
                            rng.uniform(0.8, 1.6, (B, 1))], axis=1)
 
 
-def _plugin(case):
+def _plugin(case, generate_lightcurve=None):
     from nmma_amd.em.em_likelihood import EMTransientLikelihood
     from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
     from nmma_amd.em.systematics import FilterSystematicsHandler
     kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"], model_parameters=case["model_parameters"],
                             sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
-    grb = ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"])
+    grb = ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"], model_parameters=["grb_mag0", "grb_slope"],
+                                  generate_lightcurve=generate_lightcurve)
     comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
     times, mags, sigmas = case["data"]
     sys_ref = case.get("systematics_ref") or dict(error_budget=1.0, systematics_file=None)
@@ -79,6 +80,41 @@ def test_golden_combined_goes_through_the_one_launch_form():
     ok[[3, 17]] = False
     got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
     assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+def test_combined_model_is_a_drop_in_with_a_host_generator():
+    """Config 3 as a user of the reference runs it: the second transient is a HOST model with the reference's signature
+    ``generate_lightcurve(sample_times, parameters) -> {filter: mag}`` (their GRBLightCurveModel; here the power-law stand-in the
+    goldens were made with).  No ``external_lc`` anywhere: ``log_likelihood(parameters)``, ``log_likelihood_batch(theta)`` and
+    ``GPUPool.map`` call the generator once per row and evaluate each batch in one launch -- golden log L at 1e-6; a row for which
+    the generator returns an empty dict is floored (model.py:1423-1426)."""
+    from nmma_amd.pool import GPUPool
+    case = cases_combined.case_combined_syserr()
+    gold = cases.load_golden("combined_syserr")
+    _, grb_oracle = cases_combined.oracle_likelihood(case)
+    calls = []
+
+    def generate(sample_times, parameters):
+        calls.append(1)
+        if parameters["grb_mag0"] < -17.6:            # (outside the case's prior box: see the failure check below)
+            return {}
+        return grb_oracle.abs_lightcurves(parameters, np.asarray(sample_times))
+
+    lik = _plugin(case, generate)
+    names, theta = case["names"], case["theta"]
+    got = lik.log_likelihood_batch(theta, names)
+    assert len(calls) == len(theta) and lik.sub_model._engine2 is not None and lik.sub_model._engine is None
+    assert rel_err(got, gold["logl"]).max() <= 1e-6
+    one = lik.log_likelihood(dict(zip(names, (float(v) for v in theta[5]))))
+    assert abs(one - gold["logl"][5]) <= 1e-6 * abs(gold["logl"][5])
+    pool = GPUPool(lik, queue_size=16, names=names)
+    mapped = np.array(pool.map(pool.log_likelihood, [row for row in theta[:16]]))
+    assert np.array_equal(mapped, got[:16]) and pool.n_batches == 1
+    failing = theta[:4].copy()
+    failing[2, names.index("grb_mag0")] = -17.7
+    out = lik.log_likelihood_batch(failing, names)
+    assert out[2] == FLOOR and np.array_equal(out[[0, 1, 3]], got[[0, 1, 3]])
+    assert lik.log_likelihood(dict(zip(names, (float(v) for v in failing[2])))) == FLOOR          # (core/base.py:77-82)
 
 
 @pytest.mark.parametrize("name", ["combined_syserr", "combined_loggrid"])

@@ -526,3 +526,38 @@ def test_kernel_register_budget():
         assert v["private_segment_fixed_size"] <= (160 if (targs[5] & 64) else 64), (k, v)
         assert v["vgpr_count"] <= (128 if fastm else 160), (k, v)
     assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, seen
+
+
+def test_external_model_generator_builds_the_operand_row_by_row():
+    """``ExternalLightCurveModel(generate_lightcurve=...)``: the reference-shaped host callable (model.py:405-408) is called once per
+    row with sampled + fixed + converted parameters; a falsy answer marks the row as failed (model.py:1423-1426), a filter the callable
+    does not return carries no flux; entries the caller supplies in ``external_lc`` are left alone."""
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel
+    st = np.linspace(0.5, 10.0, 7)
+    seen = []
+
+    def gen(sample_times, p):
+        seen.append(dict(p))
+        if p["grb_mag0"] > -14.5:
+            return {}
+        return {"g": p["grb_mag0"] + p["grb_slope"] * np.log10(sample_times), "r": np.full(len(sample_times), p["offset"])}
+
+    ext = ExternalLightCurveModel("PLGRB", ["g", "r", "i"], st, model_parameters=["grb_mag0", "grb_slope"], generate_lightcurve=gen)
+    other = ExternalLightCurveModel("OTHER", ["g", "r", "i"], st)
+    comb = CombinedLightCurveModelContainer([other, ext])
+    theta = np.array([[40.0, 0.3, -16.0, 1.0], [40.0, 0.3, -14.0, 1.2], [80.0, 0.1, -15.0, 0.9]])
+    names = ["luminosity_distance", "inclination_EM", "grb_mag0", "grb_slope"]
+    given = {"OTHER": np.zeros((3, 3, 7))}
+    ops = comb.host_operands(theta, names, {"offset": -12.5}, given)
+    assert ops["OTHER"] is given["OTHER"] and set(ops) == {"OTHER", "PLGRB"}
+    lc, ok = ops["PLGRB"]
+    assert lc.shape == (3, 3, 7) and ok.tolist() == [True, False, True]
+    np.testing.assert_array_equal(lc[0, 0], -16.0 + 1.0 * np.log10(st))
+    np.testing.assert_array_equal(lc[2, 1], np.full(7, -12.5))
+    assert np.all(np.isinf(lc[:, 2])) and np.all(np.isinf(lc[1]))          # a filter not returned / a failed row: no flux
+    # the conversion chain ran first: KNtheta from inclination_EM (conversion.py:119-126), the fixed parameter is there
+    assert len(seen) == 3 and abs(seen[0]["KNtheta"] - 0.3 * 180 / np.pi) < 1e-12 and seen[2]["offset"] == -12.5
+    # nothing to do when every external sub-model is supplied or has no callable
+    assert set(comb.host_operands(theta, names, {}, {"OTHER": given["OTHER"], "PLGRB": (lc, ok)})) == {"OTHER", "PLGRB"}
+    with pytest.raises(RuntimeError):
+        other.generate_lightcurve(st, {})
