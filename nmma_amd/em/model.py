@@ -285,13 +285,39 @@ def _is_number(v):
         return False
 
 
-def create_light_curve_model_from_args(model_name, args, filters=None, sample_times=None):
-    """Factory with the reference's shape (model.py:1591-1614) for SVD models."""
-    return SVDLightCurveModel(
-        model_name, svd_path=getattr(args, "svd_path", None),
-        svd_mag_ncoeff=getattr(args, "svd_mag_ncoeff", None),
-        interpolation_type=getattr(args, "interpolation_type", "keras"),
-        filters=filters, sample_times=sample_times, local_only=True)
+def create_light_curve_model_from_args(em_transient, args, filters=None, sample_times=None, host_models=None):
+    """Factory with the reference's shape (model.py:1617-1668, :1591-1614): ``em_transient`` is a model name or a comma-separated
+    list / list of names; EVERY sub-model gets the same ``filters`` and ``sample_times = setup_sample_times(args)`` (which is what
+    makes a two-model combination eligible for the one-launch likelihood); more than one name gives a
+    :class:`CombinedLightCurveModelContainer`.  Names: ``Me2017`` -> the analytic kilonova on the device; a key of ``host_models``
+    -> an :class:`ExternalLightCurveModel` around that object's ``generate_lightcurve`` (a model whose arithmetic is third-party
+    code and stays on the host: the reference's ``GRBLightCurveModel`` for ``TrPi2018``, its supernova / shock-cooling / host-galaxy
+    models); anything else is an SVD surrogate, as in the reference's own fall-through (model.py:1585-1587)."""
+    from . import utils
+    names = em_transient.split(",") if isinstance(em_transient, str) else list(em_transient)
+    names = [n.strip() for n in names]
+    if sample_times is None:
+        sample_times = utils.setup_sample_times(args)
+    host_models = host_models or {}
+    law = getattr(args, "em_extinction_law", None)
+    models = []
+    for name in names:
+        if name in host_models:
+            host = host_models[name]
+            if sample_times is None:
+                raise ValueError(f"host model {name!r}: sample_times are needed (--em-tmin / --em-tmax)")
+            m = ExternalLightCurveModel(name, filters, sample_times, model_parameters=getattr(host, "model_parameters", ()),
+                                        generate_lightcurve=host.generate_lightcurve, gap_free=bool(getattr(host, "gap_free", False)))
+        elif name == "Me2017":
+            m = SimpleKilonovaLightCurveModel(name, filters=filters, sample_times=sample_times)
+        else:
+            m = SVDLightCurveModel(name, svd_path=getattr(args, "svd_path", None), svd_mag_ncoeff=getattr(args, "svd_mag_ncoeff", None),
+                                   interpolation_type=getattr(args, "interpolation_type", "keras"), filters=filters,
+                                   sample_times=sample_times, local_only=True)
+        if law:
+            m.extinction_law = law
+        models.append(m)
+    return models[0] if len(models) == 1 else CombinedLightCurveModelContainer(models)
 
 
 #: effective wavelengths (m) of the built-in filter names (nmma/em/utils.py:680-721)

@@ -180,3 +180,22 @@ def resolve_sources(observed_filters, model_filters, known_filters=()):
                 raise KeyError(f"model provides no light curve for filter {n!r} (needed by {f!r})")
         sources[f] = names
     return sources
+
+
+def setup_sample_times(args):
+    """The model's sample times from the drivers' arguments (em/utils.py:72-93): None when neither ``em_tmin`` nor ``em_tmax`` is
+    given (the model then decides), ``arange`` with a fixed ``em_tstep`` (the legacy form), else ``em_nsteps`` linearly or
+    geometrically spaced nodes (``em_timescale``)."""
+    tmin, tmax = getattr(args, "em_tmin", None), getattr(args, "em_tmax", None)
+    if tmin is None and tmax is None:
+        return None
+    tstep = getattr(args, "em_tstep", None)
+    if tstep:
+        return np.arange(tmin, tmax + tstep, tstep)
+    scale = getattr(args, "em_timescale", "linear") or "linear"
+    nsteps = getattr(args, "em_nsteps", None)
+    if "lin" in scale or tmin <= 0.0:
+        return np.linspace(tmin, tmax, nsteps)
+    if any(k in scale for k in ("log", "geo")):
+        return np.geomspace(tmin, tmax, nsteps)
+    raise ValueError(f"Unknown time scale {scale}. Please use 'lin(ear)' or 'log(arithmic)' / 'geo(metric)'.")

@@ -161,3 +161,66 @@ def test_keras_archive_branch_runs_without_keras(tmp_path):
         z.writestr("config.json", "{}")
     with pytest.raises(ValueError):
         em_io._dense_weights_from_keras_archive(str(bad))
+
+
+def test_factory_builds_what_the_reference_drivers_build(tmp_path):
+    """``create_light_curve_model_from_args`` (model.py:1617-1668 with :1591-1614): names -> models, every sub-model on the same
+    filters and ``setup_sample_times(args)`` -- compared with the reference's own ``setup_sample_times`` for its three argument forms --
+    a host model (the GRB afterglow, third-party arithmetic) wrapped around its ``generate_lightcurve``; a surrogate + host-model
+    combination built this way is eligible for the one-launch likelihood."""
+    import joblib
+    import shutil
+    import types
+    from nmma_amd.em import utils as amd_utils
+    from nmma_amd.em.model import (CombinedLightCurveModelContainer, ExternalLightCurveModel, SimpleKilonovaLightCurveModel,
+                                   SVDLightCurveModel, create_light_curve_model_from_args)
+    forms = [dict(em_tmin=0.1, em_tmax=20.0, em_tstep=0.5, em_timescale="linear", em_nsteps=100),
+             dict(em_tmin=0.05, em_tmax=14.0, em_tstep=None, em_timescale="geometric", em_nsteps=36),
+             dict(em_tmin=0.0, em_tmax=10.0, em_tstep=None, em_timescale="log", em_nsteps=21),
+             dict(em_tmin=None, em_tmax=None, em_tstep=None, em_timescale="linear", em_nsteps=50)]
+    if os.path.isdir("/root/reference/nmma"):
+        from oracle import ref_harness
+        ref = ref_harness.reference_modules()
+        for f in forms:
+            want, got = ref.utils.setup_sample_times(types.SimpleNamespace(**f)), amd_utils.setup_sample_times(types.SimpleNamespace(**f))
+            assert (want is None and got is None) or np.array_equal(want, got)
+    assert np.array_equal(amd_utils.setup_sample_times(types.SimpleNamespace(**forms[0])), np.arange(0.1, 20.5, 0.5))
+    with pytest.raises(ValueError):
+        amd_utils.setup_sample_times(types.SimpleNamespace(em_tmin=1.0, em_tmax=2.0, em_tstep=None, em_timescale="cubic", em_nsteps=5))
+
+    rng = np.random.default_rng(4)
+    nt, nc = 60, 10
+    meta = {}
+    for name in ("ztfr", "ztfg"):
+        q, _ = np.linalg.qr(rng.standard_normal((nt, nt)))
+        meta[name] = dict(param_array_postprocess=rng.uniform(size=(28, 3)), param_mins=np.array([-3.0, -3.0, 0.0]),
+                          param_maxs=np.array([-1.0, -0.5, 90.0]), mins=-18.0 + rng.random(nt), maxs=-8.0 + rng.random(nt),
+                          tt=np.linspace(0.0, 21.0, nt), n_coeff=nc, cAmat=rng.standard_normal((nc, 28)), cAstd=np.ones((nc, 28)), VA=q)
+    svd_path = tmp_path / "svdmodels"
+    (svd_path / "Bu2019nsbh_tf").mkdir(parents=True)
+    joblib.dump(meta, str(svd_path / "Bu2019nsbh.joblib"), compress=9)
+    for name in meta:
+        shutil.copy(H5, str(svd_path / "Bu2019nsbh_tf" / f"{name}.h5"))
+
+    class HostGRB:                       # stands for the reference's GRBLightCurveModel (afterglowpy behind generate_lightcurve)
+        model_parameters = ["log10_E0", "thetaCore"]
+        gap_free = True
+
+        def generate_lightcurve(self, sample_times, parameters):
+            return {f: np.full(len(sample_times), -15.0) for f in ("ztfr", "ztfg")}
+
+    args = types.SimpleNamespace(svd_path=str(svd_path), svd_mag_ncoeff=None, interpolation_type="tensorflow", em_extinction_law=None, **forms[0])
+    comb = create_light_curve_model_from_args("Bu2019nsbh_tf, TrPi2018", args, filters=["ztfr", "ztfg"], host_models={"TrPi2018": HostGRB()})
+    assert isinstance(comb, CombinedLightCurveModelContainer) and comb.model == ["Bu2019nsbh", "TrPi2018"]        # (the "_tf" suffix is stripped as in model.py:596-599)
+    kn, grb = comb.lc_models
+    assert isinstance(kn, SVDLightCurveModel) and isinstance(grb, ExternalLightCurveModel) and grb.gap_free
+    assert np.array_equal(kn.model_times, np.arange(0.1, 20.5, 0.5)) and np.array_equal(grb.model_times, kn.model_times)
+    assert grb.model_parameters == ["log10_E0", "thetaCore"] and list(grb.filters) == ["ztfr", "ztfg"]
+    plan = comb.stack2_plan()
+    assert plan is not None and plan[0] is kn and plan[1] is grb                 # one launch per batch (nmma_em_loglike_stack2)
+    lc, ok = grb.generate_batch(np.zeros((3, 2)), ["log10_E0", "thetaCore"])
+    assert lc.shape == (3, 2, 41) and ok.all() and np.all(lc == -15.0)
+    single = create_light_curve_model_from_args("Me2017", args, filters=["g", "r", "i"])
+    assert isinstance(single, SimpleKilonovaLightCurveModel) and len(single.model_times) == 41
+    one = create_light_curve_model_from_args(["Bu2019nsbh_tf"], args, filters=["ztfr"])
+    assert isinstance(one, SVDLightCurveModel) and list(one.filters) == ["ztfr"]
