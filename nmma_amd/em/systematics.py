@@ -209,3 +209,210 @@ class FilterSystematicsHandler:
             out[f] = (np.full_like(t[f], vals[0]) if entry.nodes is None
                       else np.interp(t[f], entry.nodes, vals, left=vals[0], right=vals[-1]))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The legacy systematics file (``config: {withTime, withoutTime}``) as a source of PRIOR STRINGS: validation and the
+# ``name = Prior(...)`` lines the reference writes into a prior file for it (nmma/em/systematics.py:340-513; its tests:
+# nmma/tests/systematics.py, restated in tests/test_systematics_yaml.py).  The distribution classes are bilby's analytical
+# priors (third-party: bilby.core.prior.analytical); with bilby importable the strings are ``repr`` of its objects, as in the
+# reference -- without it the same text is composed from the classes' published constructor signatures below (pinned for
+# ``Uniform`` by the string the reference's own test expects; the other rows are restated from bilby 2.x, unpinned here).
+# ---------------------------------------------------------------------------------------------------------------
+class ValidationError(ValueError):
+    """``Validation error for '<key>': <message>`` (reference :9-11)."""
+
+    def __init__(self, key, message):
+        super().__init__(f"Validation error for '{key}': {message}")
+
+
+#: sncosmo bandpass names a legacy systematics file may address (reference :342-369)
+ALLOWED_FILTERS = ["2massh", "2massj", "2massks", "atlasc", "atlaso", "bessellb", "besselli", "bessellr", "bessellux", "bessellv",
+                   "ps1::g", "ps1::i", "ps1::r", "ps1::y", "ps1::z", "sdssu", "uvot::b", "uvot::u", "uvot::uvm2", "uvot::uvw1",
+                   "uvot::uvw2", "uvot::v", "uvot::white", "ztfg", "ztfi", "ztfr"]
+
+_TAIL = (("name", None), ("latex_label", None), ("unit", None), ("boundary", None))
+_REQ = object()
+#: constructor signatures of bilby's analytical priors, in order: (argument, default) with _REQ for a required one
+_SIGNATURES = {
+    "DeltaFunction": (("peak", _REQ),) + _TAIL[:3],
+    "PowerLaw": (("alpha", _REQ), ("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+    "Uniform": (("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+    "LogUniform": (("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+    "SymmetricLogUniform": (("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+    "Cosine": (("minimum", -np.pi / 2), ("maximum", np.pi / 2)) + _TAIL,
+    "Sine": (("minimum", 0), ("maximum", np.pi)) + _TAIL,
+    "Gaussian": (("mu", _REQ), ("sigma", _REQ)) + _TAIL,
+    "TruncatedGaussian": (("mu", _REQ), ("sigma", _REQ), ("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+    "HalfGaussian": (("sigma", _REQ),) + _TAIL,
+    "LogNormal": (("mu", _REQ), ("sigma", _REQ)) + _TAIL,
+    "Exponential": (("mu", _REQ),) + _TAIL,
+    "StudentT": (("df", _REQ), ("mu", 0.0), ("scale", 1.0)) + _TAIL,
+    "Beta": (("alpha", _REQ), ("beta", _REQ), ("minimum", 0), ("maximum", 1)) + _TAIL,
+    "Logistic": (("mu", _REQ), ("scale", _REQ)) + _TAIL,
+    "Cauchy": (("alpha", _REQ), ("beta", _REQ)) + _TAIL,
+    "Gamma": (("k", _REQ), ("theta", 1.0)) + _TAIL,
+    "ChiSquared": (("nu", _REQ),) + _TAIL,
+    "FermiDirac": (("sigma", _REQ), ("mu", None), ("r", None)) + _TAIL[:3],
+    "Categorical": (("ncategories", _REQ),) + _TAIL,
+    "Triangular": (("mode", _REQ), ("minimum", _REQ), ("maximum", _REQ)) + _TAIL,
+}
+for _alias, _of in (("Normal", "Gaussian"), ("TruncatedNormal", "TruncatedGaussian"), ("HalfNormal", "HalfGaussian"),
+                    ("LogGaussian", "LogNormal"), ("Lorentzian", "Cauchy")):
+    _SIGNATURES[_alias] = _SIGNATURES[_of]
+
+
+def _spec_class(dist_name, signature):
+    """Stand-in for one bilby prior class: keeps the constructor arguments and prints them as bilby's ``Prior.__repr__`` does
+    (every constructor argument in signature order; ``latex_label`` falls back to the name)."""
+
+    class _Spec:
+        def __init__(self, *args, **kwargs):
+            values = dict(zip((k for k, _ in signature), args))
+            values.update(kwargs)
+            unknown = set(values) - {k for k, _ in signature}
+            missing = [k for k, d in signature if d is _REQ and k not in values]
+            if unknown or missing:
+                raise TypeError(f"{dist_name}: unexpected arguments {sorted(unknown)}, missing {missing}")
+            self._values = {k: values.get(k, d) for k, d in signature}
+            if self._values.get("latex_label") is None:
+                self._values["latex_label"] = self._values.get("name")
+
+        def __repr__(self):
+            return dist_name + "(" + ", ".join(f"{k}={v!r}" for k, v in self._values.items()) + ")"
+
+    _Spec.__name__ = _Spec.__qualname__ = dist_name
+    return _Spec
+
+
+def _allowed_distributions():
+    try:  # pragma: no cover - bilby is not installed in the build image
+        import inspect
+        from bilby.core import prior as bprior
+        classes = dict(inspect.getmembers(bprior.analytical, inspect.isclass))
+
+        def positional(cls):
+            sig = inspect.signature(cls.__init__)
+            return [p.name for p in sig.parameters.values() if p.name != "self" and p.default is inspect.Parameter.empty]
+        return classes, {k: positional(v) for k, v in classes.items()}
+    except Exception:
+        classes = {k: _spec_class(k, sig) for k, sig in _SIGNATURES.items()}
+        return classes, {k: [a for a, d in sig if d is _REQ] for k, sig in _SIGNATURES.items()}
+
+
+#: distribution name -> prior class (bilby's when importable), and the constructor arguments each one requires (reference :371-390)
+ALLOWED_DISTRIBUTIONS, DISTRIBUTION_PARAMETERS = _allowed_distributions()
+
+
+def load_yaml(file_path):
+    """core/utils.py:46-47: environment variables in the text are expanded before parsing."""
+    import os
+    from pathlib import Path
+    import yaml
+    return yaml.safe_load(os.path.expandvars(Path(file_path).read_text()))
+
+
+def validate_only_one_true(yaml_dict):
+    """Exactly one entry of ``config`` is switched on, and every entry says so with a boolean (reference :393-401)."""
+    entries = yaml_dict["config"]
+    for key, values in entries.items():
+        if not isinstance(values.get("value") if isinstance(values, dict) else None, bool):
+            raise ValidationError(key, "'value' key must be present and be a boolean")
+    switched_on = sum(1 for values in entries.values() if values["value"])
+    if switched_on > 1:
+        raise ValidationError("config", "Only one configuration key can be set to True at a time")
+    if switched_on == 0:
+        raise ValidationError("config", "At least one configuration key must be set to True")
+
+
+def validate_filters(filter_groups):
+    """Every filter of a ``withTime`` entry is a known bandpass and is addressed once: not twice inside a group, not in two
+    groups; ``None`` stands for "all filters" (reference :404-439)."""
+    allowed = ", ".join(str(f) for f in ALLOWED_FILTERS)
+    claimed = set()
+
+    def known(filt):
+        if filt not in ALLOWED_FILTERS:
+            raise ValidationError("filters", f"Invalid filter value '{filt}'. Allowed values are {allowed}")
+
+    def free(filt):
+        if filt in claimed:
+            raise ValidationError("filters", f"Duplicate filter value '{filt}'. A filter can only be used in one group.")
+
+    for group in filter_groups:
+        if isinstance(group, list):
+            inside = set()
+            for filt in group:
+                known(filt)
+                if filt in inside:
+                    raise ValidationError("filters", f"Duplicate filter value '{filt}' within the same group.")
+                free(filt)
+                inside.add(filt)
+                claimed.add(filt)
+        else:
+            if group is not None:
+                known(group)
+            free(group)
+            claimed.add(group)
+
+
+def validate_distribution(distribution):
+    """The entry names a known distribution and carries its required constructor arguments (reference :442-456)."""
+    dist_type = distribution.get("type")
+    if dist_type not in ALLOWED_DISTRIBUTIONS:
+        raise ValidationError("distribution type", f"Invalid distribution '{dist_type}'. Allowed values are "
+                                                   f"{', '.join(str(f) for f in ALLOWED_DISTRIBUTIONS)}")
+    missing = set(DISTRIBUTION_PARAMETERS[dist_type]) - set(distribution.keys())
+    if missing:
+        raise ValidationError("distribution", f"Missing required parameters for {dist_type} distribution: {', '.join(missing)}")
+
+
+def create_prior_string(name, distribution):
+    """``name = Prior(...)``: the prior-file line of one systematics parameter (reference :459-472).  Only the distribution's
+    required arguments are passed on; anything else in the entry (beyond the entry's own keys) is reported and ignored."""
+    import warnings
+    dist_type = distribution["type"]
+    required = DISTRIBUTION_PARAMETERS[dist_type]
+    given = {k: v for k, v in distribution.items() if k not in ("type", "value", "time_nodes", "filters")}
+    extra = set(given) - set(required)
+    if extra:
+        warnings.warn(f"Distribution parameters {extra} are not used by {dist_type} distribution and will be ignored")
+    args = {k: given[k] for k in required if k in given}
+    return f"{name} = {ALLOWED_DISTRIBUTIONS[dist_type](**args, name=name)!r}"
+
+
+def handle_withTime(values):
+    """One prior line per (filter group, time node): ``em_syserr_<group>_<n>``, a group's filters joined by ``___``, ``all`` for
+    ``None`` (reference :475-492; the names ``lower_legacy`` above evaluates)."""
+    validate_distribution(values)
+    groups = values.get("filters", [])
+    validate_filters(groups)
+    lines = []
+    for group in groups:
+        label = "___".join(group) if isinstance(group, list) else ("all" if group is None else group)
+        lines += [create_prior_string(f"em_syserr_{label}_{n}", dict(values)) for n in range(values["time_nodes"])]
+    return lines
+
+
+def handle_withoutTime(values):
+    """One prior line: ``em_syserr`` (reference :495-497)."""
+    validate_distribution(values)
+    return [create_prior_string("em_syserr", values)]
+
+
+config_handlers = {"withTime": handle_withTime, "withoutTime": handle_withoutTime}
+
+
+def get_prior_strings(yaml_dict):
+    """The prior lines of the entry that is switched on (reference :504-510)."""
+    validate_only_one_true(yaml_dict)
+    lines = []
+    for key, values in yaml_dict["config"].items():
+        if values["value"] and key in config_handlers:
+            lines.extend(config_handlers[key](values))
+    return lines
+
+
+def main(yaml_file_path):
+    """File -> prior lines (reference :512-513)."""
+    return get_prior_strings(load_yaml(yaml_file_path))
