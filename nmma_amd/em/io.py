@@ -6,8 +6,8 @@
   (``{model}.joblib`` + ``{model}[_tf]/{filter}.keras|.h5``, nmma/em/model.py:593-696)
   and writes the flat file: ``.joblib`` through joblib, legacy ``.h5`` networks through h5py or,
   without it, the built-in reader ``em/hdf5_lite.py``; ``.keras`` archives need keras.
-* ``load_em_observations``: the ``time filter mag mag_error`` text photometry format
-  (nmma/em/io.py:116-144; ISO-T times or MJD floats).
+* ``load_em_observations`` / ``write_em_observations``: light-curve data files in the reference's formats (nmma/em/io.py:16-184):
+  ``time filter mag mag_error`` rows, the forced-photometry CSV, model tables, ``.json`` in standard or model form.
 """
 from __future__ import annotations
 
@@ -186,29 +186,163 @@ def convert_reference_model(svd_path, model, out_path, filters=None, interpolati
     return svd
 
 
-def _to_mjd(token):
+def _to_mjd(token, time_format=None):
+    """One time token -> MJD: an ISO / ISOT date (UTC), else a number in ``time_format`` (``mjd`` -- the default -- ``jd``, ``unix``:
+    the leap-second-free ones of the astropy ``Time`` formats the reference's ``--time-format`` takes, io.py:130-136)."""
     try:
-        return float(token)
+        value = float(token)
     except ValueError:
-        dt = datetime.fromisoformat(token).replace(tzinfo=timezone.utc)
+        dt = datetime.fromisoformat(str(token).strip().replace("Z", "+00:00"))
+        if dt.tzinfo is None:
+            dt = dt.replace(tzinfo=timezone.utc)
         return dt.timestamp() / 86400.0 + 40587.0
+    fmt = (time_format or "mjd").lower()
+    if fmt == "mjd":
+        return value
+    if fmt == "jd":
+        return value - 2400000.5
+    if fmt == "unix":
+        return value / 86400.0 + 40587.0
+    raise ValueError(f"time format {time_format!r} is not one of mjd, jd, unix")
 
 
-def load_em_observations(path, filters=None):
-    """``{filter: {"time": mjd[], "mag": [], "mag_error": []}}`` sorted by time
-    (rows: ``time filter mag mag_error``; ``inf`` error marks an upper limit)."""
+def _read_observation_rows(path, time_format):
+    """``time filter mag mag_error`` rows (io.py:116-144): comment lines and a ``time`` / ``mjd`` header are skipped."""
     rows = {}
     with open(path) as fh:
         for line in fh:
             parts = line.split()
-            if len(parts) < 4 or parts[0].startswith("#"):
+            if not parts or line.startswith(("#", "time", "mjd")):
                 continue
-            t, filt, mag, err = _to_mjd(parts[0]), parts[1], float(parts[2]), float(parts[3])
-            if filters is not None and filt not in filters:
-                continue
+            t, filt, mag, err = _to_mjd(parts[0], time_format), parts[1], float(parts[2]), float(parts[3])
             rows.setdefault(filt, []).append((t, mag, err))
-    out = {}
-    for filt, r in rows.items():
-        a = np.array(sorted(r))
-        out[filt] = {"time": a[:, 0], "mag": a[:, 1], "mag_error": a[:, 2]}
-    return out
+    if not rows:
+        raise ValueError(f"no photometry rows in {path}")
+    return rows
+
+
+def _read_survey_csv(path):
+    """The forced-photometry CSV the reference falls back to (io.py:101-114): columns ``mjd, filter, mag_corr, magerr,
+    limiting_mag``; rows without a magnitude are upper limits at ``limiting_mag`` (infinite error)."""
+    import csv
+    rows = {}
+    with open(path, newline="") as fh:
+        for rec in csv.DictReader(fh):
+            mag = float(rec["mag_corr"]) if rec["mag_corr"].strip() not in ("", "nan", "NaN") else np.nan
+            err = float(rec["magerr"]) if rec["magerr"].strip() else np.nan
+            if np.isnan(mag):
+                mag, err = float(rec["limiting_mag"]), np.inf
+            rows.setdefault(rec["filter"], []).append((float(rec["mjd"]), mag, err))
+    return rows
+
+
+def _read_model_table(path):
+    """A model light curve as text (io.py:85-97): header ``time f1 f2 ... [f1_error ...]``, one row per epoch."""
+    with open(path) as fh:
+        lines = [ln for ln in (raw.strip() for raw in fh) if ln]
+    header = lines[0].lstrip("#").split()
+    table = np.array([[float(v) for v in ln.split()] for ln in lines[1:] if not ln.startswith("#")])
+    cols = dict(zip(header, table.T))
+    time = cols.pop("time")
+    return {f: {"time": time, "mag": v, "mag_error": cols.get(f + "_error", np.zeros_like(time))}
+            for f, v in cols.items() if not f.endswith("_error")}
+
+
+def _decode_json(obj):
+    """bilby's JSON encoding of arrays and complex numbers (``{"__array__": true, "content": [...]}``), as the reference's reader
+    decodes it (io.py:60-61)."""
+    if isinstance(obj, dict):
+        if obj.get("__array__"):
+            return np.asarray(obj["content"])
+        if obj.get("__complex__"):
+            return complex(obj["real"], obj["imag"])
+    return obj
+
+
+def _read_json(path):
+    import json
+    with open(path) as fh:
+        data = json.load(fh, object_hook=_decode_json)
+    if "time" in data:          # a model light curve: one time axis, one column per filter (io.py:64-73)
+        time = data["time"]
+        data = {k: {"time": time, "mag": v, "mag_error": data.get(f"{k}_error", np.zeros_like(np.asarray(time, float)))}
+                for k, v in data.items() if k != "time" and not k.endswith("_error")}
+    return data
+
+
+def load_em_observations(filename, args=None, format="observations", filters=None):
+    """Light-curve data in the reference's standard form ``{filter: {"time": mjd[], "mag": [], "mag_error": []}}`` (io.py:16-55) from
+
+    * a dict (returned as it is) or a Namespace (its ``light_curve_data``),
+    * a ``.json`` file in the standard form or in the model form (``time`` + one column per filter [+ ``<filter>_error``]),
+    * a text file of ``time filter mag mag_error`` rows (``format="observations"``; ISO times or numbers in ``args.time_format``;
+      an infinite error marks an upper limit), or -- when that does not parse -- the forced-photometry CSV
+      (``mjd, filter, mag_corr, magerr, limiting_mag``),
+    * a text table ``time f1 f2 ...`` (``format="model"``).
+
+    Text observations come back sorted by time within each filter; ``filters`` keeps only the named ones."""
+    import argparse
+    if isinstance(filename, dict):
+        return filename
+    if isinstance(filename, argparse.Namespace) or (args is None and hasattr(filename, "light_curve_data")):
+        args, filename = filename, filename.light_curve_data
+        if isinstance(filename, dict):
+            return filename
+    if filename is None:
+        raise ValueError("No filename provided for lightcurve data.")
+    filename = os.fspath(filename)
+    if filename.endswith(".json"):
+        data = _read_json(filename)
+    elif "obs" in format:
+        try:
+            rows = _read_observation_rows(filename, getattr(args, "time_format", None))
+        except Exception:
+            rows = _read_survey_csv(filename)
+        data = {}
+        for filt, r in rows.items():
+            a = np.array(sorted(r))
+            data[filt] = {"time": a[:, 0], "mag": a[:, 1], "mag_error": a[:, 2]}
+    elif "model" in format:
+        data = _read_model_table(filename)
+    else:
+        raise ValueError("Standard format is not supported for reading from csv files. Please use json files instead.")
+    return {filt: {k: np.array(v) for k, v in sub.items()} for filt, sub in data.items() if filters is None or filt in filters}
+
+
+def _isot(mjd):
+    dt = datetime.fromtimestamp(round((float(mjd) - 40587.0) * 86400.0 * 1000.0) / 1000.0, tz=timezone.utc)
+    return dt.strftime("%Y-%m-%dT%H:%M:%S.") + f"{dt.microsecond // 1000:03d}"
+
+
+def write_em_observations(filename, data, format="observations"):
+    """The reverse (io.py:146-184): ``.json`` in the standard form; ``.txt`` / ``.dat`` as observation rows (ISOT time, filter,
+    magnitude and error with three decimals, sorted by time) or as a model table."""
+    import json
+    directory = os.path.dirname(os.fspath(filename))
+    if directory:
+        os.makedirs(directory, exist_ok=True)
+    filename = os.fspath(filename)
+    if filename.endswith(".json"):
+        with open(filename, "w") as fh:
+            json.dump({f: {k: np.asarray(v).tolist() for k, v in sub.items()} for f, sub in data.items()}, fh, indent=2)
+        return
+    if not filename.endswith((".txt", ".dat")):
+        return
+    if format == "observations":
+        rows = sorted((float(t), f, float(m), float(e)) for f, sub in data.items()
+                      for t, m, e in zip(sub["time"], sub["mag"], sub["mag_error"]))
+        with open(filename, "w") as fh:
+            fh.write("#time filter mag mag_error\n")
+            for t, f, m, e in rows:
+                fh.write(f"{_isot(t)} {f} {m:.3f} {e:.3f}\n")
+    elif format == "model":
+        names = list(data)
+        with_err = [f for f in names if not np.all(np.isnan(np.asarray(data[f]["mag_error"], float)))]
+        time = np.asarray(data[names[-1]]["time"], float)
+        cols = [np.asarray(data[f]["mag"], float) for f in names] + [np.asarray(data[f]["mag_error"], float) for f in with_err]
+        with open(filename, "w") as fh:
+            fh.write("#time " + " ".join(names + [f + "_error" for f in with_err]) + "\n")
+            for i, t in enumerate(time):
+                fh.write(f"{t:.5f} " + " ".join(f"{c[i]:.3f}" for c in cols) + "\n")
+    else:
+        raise ValueError(f"unknown light-curve file format {format!r}")
