@@ -199,3 +199,76 @@ def setup_sample_times(args):
     if any(k in scale for k in ("log", "geo")):
         return np.geomspace(tmin, tmax, nsteps)
     raise ValueError(f"Unknown time scale {scale}. Please use 'lin(ear)' or 'log(arithmic)' / 'geo(metric)'.")
+
+
+#: filters of the survey names ``--em-detectors`` takes, the Rubin target-of-opportunity strategies, and the surveys' single-visit
+#: depths (em/utils.py:96-196; arXiv:2108.01683 and the Rubin key numbers for LSST / Rubin, the ZTF survey depths)
+DETECTOR_FILTERS = {"ztf": ["ztfg", "ztfr", "ztfi"], "lsst": ["lsstg", "lsstr", "lssti", "lsstz", "lssty"],
+                    "rubin": ["ps1::g", "ps1::r", "ps1::i", "ps1::z", "ps1::y"]}
+RUBIN_TOO_FILTERS = {"platinum": ["ps1::g", "ps1::r", "ps1::i", "ps1::z", "ps1::y"], "gold": ["ps1::g", "ps1::r", "ps1::i"],
+                     "gold_z": ["ps1::g", "ps1::r", "ps1::z"], "silver": ["ps1::g", "ps1::i"], "silver_z": ["ps1::g", "ps1::z"]}
+DETECTOR_LIMITS = {"lsst": {"lsstu": 23.9, "lsstg": 25.0, "lsstr": 24.7, "lssti": 24.0, "lsstz": 23.3, "lssty": 22.1},
+                   "ztf": {"ztfg": 21.7, "ztfr": 21.4, "ztfi": 20.9},
+                   "rubin": {"ps1::g": 25.8, "ps1::r": 25.5, "ps1::i": 24.8, "ps1::z": 24.1, "ps1::y": 22.9}}
+
+
+def _detector_list(args):
+    dets = getattr(args, "em_detectors", None) or []
+    dets = dets.split(",") if isinstance(dets, str) else list(dets)
+    return dets
+
+
+def set_filters(args):
+    """The analysis' filter list from the drivers' arguments (em/utils.py:96-139): ``--filters`` (comma-separated, blanks and empty
+    items dropped) wins; else the filters of the ``--em-detectors`` surveys, where LSST takes precedence over a Rubin ToO strategy
+    and that over plain ``rubin``; None when nothing is given (the likelihood then takes the filters of the data)."""
+    if getattr(args, "filters", None):
+        filters = args.filters.split(",") if isinstance(args.filters, str) else args.filters
+        filters = [f for item in filters for f in item.replace(" ", "").split(",") if f]
+        if not filters:
+            raise ValueError("Need at least one valid filter.")
+        return filters
+    too = getattr(args, "rubin_ToO_type", False)
+    if not (getattr(args, "em_detectors", None) or too):
+        return None
+    dets = [d.strip().lower() for d in _detector_list(args)]
+    filters = []
+    if "ztf" in dets:
+        dets.remove("ztf")
+        filters += DETECTOR_FILTERS["ztf"]
+    if "lsst" in dets:
+        dets.remove("lsst")
+        filters += DETECTOR_FILTERS["lsst"]
+    elif too:
+        filters += RUBIN_TOO_FILTERS.get(too, [])
+        if "rubin" in dets:
+            dets.remove("rubin")
+    elif "rubin" in dets:
+        dets.remove("rubin")
+        filters += DETECTOR_FILTERS["rubin"]
+    if dets:
+        raise NotImplementedError(f"{dets} not implemented yet.")
+    return filters
+
+
+def create_detection_limit(args, filters, default_limit=np.inf):
+    """The likelihood's ``detection_limit`` dict from the drivers' arguments (em/utils.py:142-196): an explicit
+    ``--detection-limit`` (number, list or dict) for the given filters, else ``default_limit`` per filter updated with the depths of
+    the ``--em-detectors`` surveys / a Rubin ToO strategy.  (A limit read from an m4opt FITS sky map -- ``--detection-limit-fits-file``
+    -- needs astropy and healpy: read it with those and pass the number as ``detection_limit``.)"""
+    if getattr(args, "detection_limit", None):
+        return set_filter_associated_dict(args.detection_limit, filters, default_limit)
+    if getattr(args, "detection_limit_fits_file", None):
+        raise NotImplementedError("detection limits from an m4opt FITS sky map need astropy + healpy: pass the limit as detection_limit")
+    limits = {f: default_limit for f in filters}
+    if getattr(args, "em_detectors", None):
+        dets = _detector_list(args)
+        for name in ("lsst", "ztf", "rubin"):
+            if name in dets:
+                dets.remove(name)
+                limits.update(DETECTOR_LIMITS[name])
+        if dets:
+            raise NotImplementedError(f"{dets} not implemented yet.")
+    if getattr(args, "rubin_ToO_type", None):
+        limits.update(DETECTOR_LIMITS["rubin"])
+    return limits
