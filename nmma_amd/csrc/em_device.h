@@ -129,7 +129,7 @@ struct EmDev {
     const int32_t* bguess;
     double bg_inv_h;
     int32_t bg_nbis, pad_bg;
-    int32_t lean_gen, pad_gen;        // general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
+    int32_t lean_gen, mass_tab;       // (mass_tab: a band has a finite detection limit -- the general lean task reads log Phi from the table it keeps in LDS at LdsW::nodes, logphi_tab.h)  general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
 };
 
 }  // namespace nmma

@@ -293,6 +293,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             double* dst = reinterpret_cast<double*>(smem + L.nodes);
             for (int j = cvt; j < STACK2_NINT * STACK2_ROW; j += cnv) dst[j] = kStack2Tab[j];
         }
+        if constexpr (FASTM == 5) {       // log Phi for detections under a finite limit (logphi_tab.h): a band of this handle has one
+            if (P.mass_tab) {
+                double* dst = reinterpret_cast<double*>(smem + L.nodes);
+                for (int j = cvt; j < LOGPHI_NINT * LOGPHI_ROW; j += cnv) dst[j] = kLogPhiTab[j];
+            }
+        }
         }
 
         // Static tables of a model filter (basis rows, span, mins, stage-1 lerp tables) are
@@ -1483,10 +1489,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             isig_[u] = isig; lsig_[u] = lsig; sbad_[u] = sig_bad;
         }
         if (lim_fin) {
+            // truncnorm.logpdf(m, a = -inf, b = (lim - est) / sigma, loc = est, scale = sigma) (em_math.h: detection_term) with the
+            // scaled residuals as products with 1 / sigma, like the untruncated term above, and log Phi(b) from the table in LDS
+            // (logphi_tab.h; 48.0 -> 37 us per 4096 rows of the CLI-grid case with finite limits: profiles/r05_limits.md)
 #pragma unroll
             for (int u = 0; u < NSL; ++u)
-                if (valid_[u] & !ul_[u])
-                    v_[u] = sbad_[u] ? dnan() : detection_term(m_[u], inside_[u] ? est_[u] : dinf(), 1.0 / isig_[u], lsig_[u], it.lim);
+                if (valid_[u] & !ul_[u]) {
+                    const double b = (it.lim - est_[u]) * isig_[u];
+                    const double x = (m_[u] - est_[u]) * isig_[u];
+                    double v = ((-(x * x) / 2.0 - kNormPdfLogC) - log_gauss_mass_tab(b, (lds_cdp)(smem + L.nodes))) - lsig_[u];
+                    v = x > b ? -dinf() : v;                                               // fainter than the limit, yet detected
+                    v_[u] = (inside_[u] & !sbad_[u] & (b > -dinf()) & (x == x)) ? v : dnan();
+                }
         }
         gp_[0] = 0.0; gp_[1] = 0.0;
         if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
@@ -1811,7 +1825,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
                                    (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : 0,
+                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : (FAST == 5 && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
                                    ((WALKF & 31) == 16 || (WALKF != 0 && R == 2)) ? (WALKF & 31) : 0);
     const int TS = 16 * R;
     g_launch_note.clear();

@@ -14,7 +14,7 @@ def hc():
     lib = C.CDLL(hc_build.build())
     d, i, pd = C.c_double, C.c_int, C.POINTER(C.c_double)
     sig = {"hc_interp_np": [d, pd, pd, i, d, d], "hc_lerp_np": [d] * 5, "hc_ndtr": [d], "hc_log_ndtr": [d],
-           "hc_log_gauss_mass_neginf": [d], "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
+           "hc_log_gauss_mass_neginf": [d], "hc_log_gauss_mass_tab": [d], "hc_detection_term_tab": [d] * 5, "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
            "hc_apply_slot": [i, i, d, pd], "hc_distance_modulus": [d], "hc_redshift_correction": [d],
            "hc_extinction_mag": [i, d, d, d]}
     for name, args in sig.items():
@@ -54,6 +54,36 @@ def test_log_ndtr_and_ndtr_match_scipy(hc):
     np.testing.assert_allclose(got, special.log_ndtr(xs), rtol=5e-11, atol=0)
     got = np.array([hc.hc_ndtr(x) for x in xs])
     np.testing.assert_allclose(got, special.ndtr(xs), rtol=2e-13, atol=1e-300)
+
+
+def test_truncation_mass_from_the_table_matches_scipy(hc):
+    """``log_gauss_mass_tab`` -- the polynomial table the general lean task reads for detections under a finite limit -- against
+    scipy's ``_log_gauss_mass(-inf, b)`` = ``log_ndtr(b)`` (3e-15; 6e-16 against 30-digit arithmetic) on the table's range, 0 beyond 8.5 (where scipy's value is
+    below half an ulp of every term it is subtracted from), scipy's own formula below -1; and the detection term built on it against
+    ``truncnorm.logpdf`` like the exact one."""
+    b = np.concatenate([np.linspace(-1.0, 8.5, 4001)[:-1], np.arange(-1.0, 8.5, 0.5), np.nextafter(np.arange(-0.5, 8.5, 0.5), -10)])
+    got = np.array([hc.hc_log_gauss_mass_tab(x) for x in b])
+    assert np.abs(got - special.log_ndtr(b)).max() <= 3e-15            # (scipy's own log_ndtr is a few ulp off around b = -0.84)
+    import mpmath as mp
+    mp.mp.dps = 30
+    assert np.abs(got[::7] - np.array([float(mp.log(mp.ncdf(float(x)))) for x in b[::7]])).max() <= 6e-16
+    for x in (8.5, 9.0, 37.0, np.inf):
+        assert hc.hc_log_gauss_mass_tab(x) == 0.0 and abs(special.log_ndtr(x)) < 0.5 * np.spacing(0.9189385332046727)
+    low = np.array([-1.0000001, -1.5, -5.0, -20.0, -37.0])
+    np.testing.assert_allclose([hc.hc_log_gauss_mass_tab(x) for x in low], special.log_ndtr(low), rtol=5e-11)
+    assert np.isnan(hc.hc_log_gauss_mass_tab(np.nan))
+    rng = np.random.default_rng(11)
+    m, est, sig = rng.uniform(17, 22, 400), rng.uniform(17, 22, 400), rng.uniform(0.05, 1.5, 400)
+    for lim in (20.5, 22.5, 30.0):
+        got = np.array([hc.hc_detection_term_tab(a, b_, c, np.log(c), lim) for a, b_, c in zip(m, est, sig)])
+        exact = np.array([hc.hc_detection_term(a, b_, c, np.log(c), lim) for a, b_, c in zip(m, est, sig)])
+        with np.errstate(divide="ignore"):
+            want = stats.truncnorm.logpdf(m, -np.inf, (lim - est) / sig, loc=est, scale=sig)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isneginf(got), np.isneginf(want))
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(got[fin], exact[fin], rtol=0, atol=2e-15 * np.abs(exact[fin]).max())
+    assert np.isnan(hc.hc_detection_term_tab(18.0, np.inf, 0.3, np.log(0.3), 21.0))
 
 
 def test_detection_term_matches_truncnorm(hc):
