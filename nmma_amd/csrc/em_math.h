@@ -210,10 +210,10 @@ NM_HD double detection_term(double m, double est, double sigma, double log_sigma
     return ((-(x * x) / 2.0 - kNormPdfLogC) - mass) - log_sigma;
 }
 
-// log Phi(b) for the truncation mass of a detection from the table of logphi_tab.h (`tab`: the table, in LDS for the kernels):
-// |error| <= 4.2e-16 on [-1, 8.5); 0 beyond 8.5 (absorbed by the subtraction it enters: see the generator); scipy's own formula
-// below -1 and for NaN (a limit brighter than the model by more than one sigma: rare, out of line).  One clamp, one index, eleven
-// coefficients, ten FMAs -- against erfc + log1p (~210 instructions) per detection with a finite limit.
+// log Phi(b) -- the truncation mass of a detection under a finite limit, and norm.logsf of an upper limit -- from the table of
+// logphi_tab.h (`tab`: the table, in LDS for the kernels): relative error <= 5e-16 on [-9.5, 8.5) (4e-16 absolute above -1); 0 beyond 8.5
+// (9.5e-18: absorbed by the sum it enters, see the generator); scipy's own formula below -9.5 and for NaN (out of line).  One clamp, one
+// index, fourteen coefficients, thirteen FMAs -- against erfc + log1p or erfcx + log (~210 instructions).
 template <typename TabPtr>
 NM_HD double log_gauss_mass_tab(double b, TabPtr tab) {
     double bc = b > LOGPHI_LO ? b : LOGPHI_LO;                 // (NaN -> LO: the value is replaced below)
@@ -244,9 +244,23 @@ NM_HD double detection_term_tab(double m, double est, double sigma, double log_s
     return ((-(x * x) / 2.0 - kNormPdfLogC) - mass) - log_sigma;
 }
 
+// upper_limit_term with log Phi from the table (the lean tasks of em_logl: one or a few upper limits per filter, evaluated on the lanes
+// that hold one while the rest of the wave waits -- 1.05 of 28 us at BASELINE config 2 with scipy's formula out of line)
+template <typename TabPtr>
+NM_HD double upper_limit_term_tab(double m, double est, double sigma_sys, TabPtr tab) {
+    const double x = (m - est) / sigma_sys;
+    double r = log_gauss_mass_tab(-x, tab);
+    r = (x == -dinf()) ? 0.0 : r;
+    r = (x == dinf()) ? -dinf() : r;
+    return (!(sigma_sys > 0) || x != x) ? dnan() : r;
+}
+
 // One upper limit: norm.logsf(m, est, sigma_sys) = log_ndtr(-(m - est)/sigma_sys);
 // rv_continuous.logsf: scale <= 0 or NaN args -> NaN; x at the lower support edge -> 0.
 NM_HD double upper_limit_term(double m, double est, double sigma_sys) {
+#ifdef NMMA_DBG_NOUL        // measurement build: what the out-of-line log_ndtr of an upper limit costs a lean task
+    return (m - est) * sigma_sys * 1e-300;
+#endif
     if (!(sigma_sys > 0)) return dnan();
     const double x = (m - est) / sigma_sys;
     if (x != x) return dnan();

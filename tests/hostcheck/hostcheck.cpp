@@ -11,6 +11,7 @@ double hc_lerp_np(double x, double x0, double x1, double y0, double y1) { return
 double hc_ndtr(double x) { return nmma::ndtr(x); }
 double hc_log_ndtr(double x) { return nmma::log_ndtr(x); }
 double hc_log_gauss_mass_neginf(double b) { return nmma::log_gauss_mass_neginf(b); }
+double hc_upper_limit_term_tab(double m, double est, double sigma_sys) { return nmma::upper_limit_term_tab(m, est, sigma_sys, nmma::kLogPhiTab); }
 double hc_log_gauss_mass_tab(double b) { return nmma::log_gauss_mass_tab(b, nmma::kLogPhiTab); }
 double hc_detection_term_tab(double m, double est, double sigma, double log_sigma, double lim) {
     return nmma::detection_term_tab(m, est, sigma, log_sigma, lim, nmma::kLogPhiTab);

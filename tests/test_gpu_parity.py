@@ -633,6 +633,9 @@ def test_item_staged_photometry_gives_the_same_bits(grid, torch_cuda, monkeypatc
     th = torch.as_tensor(theta, device="cuda:0")
     monkeypatch.setenv("NMMA_EM_NO_DENSE", "1")
     monkeypatch.setenv("NMMA_EM_NO_ITEM_DAT", "1")
+    # (two LAYOUTS of one task are compared bit for bit: keep the upper limits on one formula -- whether their log Phi table fits
+    #  next to the ring is decided per handle, and these two handles differ in exactly that)
+    monkeypatch.setenv("NMMA_EM_NO_UL_TAB", "1")
     eng = engine_from_case(case)
     want = eng.loglike(th).cpu().numpy()
     lds_all = eng.last_launch_geometry()["lds_bytes"]
@@ -678,6 +681,7 @@ def test_dense_lean_task_matches_the_row_form(sampled_sys, grid, torch_cuda, mon
     theta[7, 2] = np.nan
     th = torch.as_tensor(theta, device="cuda:0")
     monkeypatch.setenv("NMMA_EM_NO_DENSE", "1")
+    monkeypatch.setenv("NMMA_EM_NO_UL_TAB", "1")              # (the row form as the dense task evaluates its upper limits: scipy's formula)
     eng = engine_from_case(case)
     want = eng.loglike(th).cpu().numpy()
     lds_rows = eng.last_launch_geometry()["lds_bytes"]

@@ -14,7 +14,7 @@ def hc():
     lib = C.CDLL(hc_build.build())
     d, i, pd = C.c_double, C.c_int, C.POINTER(C.c_double)
     sig = {"hc_interp_np": [d, pd, pd, i, d, d], "hc_lerp_np": [d] * 5, "hc_ndtr": [d], "hc_log_ndtr": [d],
-           "hc_log_gauss_mass_neginf": [d], "hc_log_gauss_mass_tab": [d], "hc_detection_term_tab": [d] * 5, "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
+           "hc_log_gauss_mass_neginf": [d], "hc_log_gauss_mass_tab": [d], "hc_upper_limit_term_tab": [d] * 3, "hc_detection_term_tab": [d] * 5, "hc_detection_term": [d] * 5, "hc_upper_limit_term": [d] * 3,
            "hc_apply_slot": [i, i, d, pd], "hc_distance_modulus": [d], "hc_redshift_correction": [d],
            "hc_extinction_mag": [i, d, d, d]}
     for name, args in sig.items():
@@ -58,18 +58,20 @@ def test_log_ndtr_and_ndtr_match_scipy(hc):
 
 def test_truncation_mass_from_the_table_matches_scipy(hc):
     """``log_gauss_mass_tab`` -- the polynomial table the general lean task reads for detections under a finite limit -- against
-    scipy's ``_log_gauss_mass(-inf, b)`` = ``log_ndtr(b)`` (3e-15; 6e-16 against 30-digit arithmetic) on the table's range, 0 beyond 8.5 (where scipy's value is
-    below half an ulp of every term it is subtracted from), scipy's own formula below -1; and the detection term built on it against
+    scipy's ``_log_gauss_mass(-inf, b)`` = ``log_ndtr(b)`` (3e-15 relative; 6e-16 against 30-digit arithmetic) on the table's range [-9.5, 8.5), 0 beyond 8.5 (where scipy's value is
+    below half an ulp of every term it is subtracted from), scipy's own formula below -9.5; and the detection term built on it against
     ``truncnorm.logpdf`` like the exact one."""
-    b = np.concatenate([np.linspace(-1.0, 8.5, 4001)[:-1], np.arange(-1.0, 8.5, 0.5), np.nextafter(np.arange(-0.5, 8.5, 0.5), -10)])
+    b = np.concatenate([np.linspace(-9.5, 8.5, 7001)[:-1], np.arange(-9.5, 8.5, 1.0), np.nextafter(np.arange(-8.5, 8.5, 1.0), -10)])
     got = np.array([hc.hc_log_gauss_mass_tab(x) for x in b])
-    assert np.abs(got - special.log_ndtr(b)).max() <= 3e-15            # (scipy's own log_ndtr is a few ulp off around b = -0.84)
+    want = special.log_ndtr(b)
+    assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= 3e-15          # (scipy's own log_ndtr is a few ulp off around b = -0.84)
     import mpmath as mp
     mp.mp.dps = 30
-    assert np.abs(got[::7] - np.array([float(mp.log(mp.ncdf(float(x)))) for x in b[::7]])).max() <= 6e-16
+    exact = np.array([float(mp.log(mp.ncdf(float(x)))) for x in b[::7]])
+    assert (np.abs(got[::7] - exact) / np.maximum(1.0, np.abs(exact))).max() <= 6e-16
     for x in (8.5, 9.0, 37.0, np.inf):
         assert hc.hc_log_gauss_mass_tab(x) == 0.0 and abs(special.log_ndtr(x)) < 0.5 * np.spacing(0.9189385332046727)
-    low = np.array([-1.0000001, -1.5, -5.0, -20.0, -37.0])
+    low = np.array([-9.5000001, -10.5, -15.0, -20.0, -37.0])
     np.testing.assert_allclose([hc.hc_log_gauss_mass_tab(x) for x in low], special.log_ndtr(low), rtol=5e-11)
     assert np.isnan(hc.hc_log_gauss_mass_tab(np.nan))
     rng = np.random.default_rng(11)
@@ -84,6 +86,13 @@ def test_truncation_mass_from_the_table_matches_scipy(hc):
         np.testing.assert_allclose(got[fin], want[fin], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(got[fin], exact[fin], rtol=0, atol=2e-15 * np.abs(exact[fin]).max())
     assert np.isnan(hc.hc_detection_term_tab(18.0, np.inf, 0.3, np.log(0.3), 21.0))
+    # an upper limit: norm.logsf(m, est, sigma_sys) (em_likelihood.py:246-249)
+    m, est, sig = rng.uniform(17, 22, 600), rng.uniform(14, 25, 600), rng.uniform(0.1, 2.0, 600)
+    got = np.array([hc.hc_upper_limit_term_tab(a, b_, c) for a, b_, c in zip(m, est, sig)])
+    want = stats.norm.logsf(m, est, sig)
+    np.testing.assert_allclose(got, want, rtol=3e-15, atol=3e-15)
+    assert hc.hc_upper_limit_term_tab(18.0, -np.inf, 1.0) == -np.inf and hc.hc_upper_limit_term_tab(18.0, np.inf, 1.0) == 0.0
+    assert np.isnan(hc.hc_upper_limit_term_tab(18.0, 19.0, 0.0)) and np.isnan(hc.hc_upper_limit_term_tab(np.nan, 19.0, 1.0))
 
 
 def test_detection_term_matches_truncnorm(hc):
