@@ -228,7 +228,7 @@ NM_HD double log_gauss_mass_tab(double b, TabPtr tab) {
 #endif
     for (int k = 1; k <= LOGPHI_DEG; ++k) acc = fma(acc, t, row[k]);
     acc = b >= LOGPHI_HI ? 0.0 : acc;
-    if (!(b >= LOGPHI_LO)) acc = log_gauss_mass_neginf(b);
+    if (!(b >= LOGPHI_LO)) acc = log_ndtr(b);       // (= _log_gauss_mass(-inf, b) for b <= 0; NaN for NaN.  ONE out-of-line call: a nested one costs the kernel a stack)
     return acc;
 }
 
