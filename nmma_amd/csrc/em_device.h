@@ -130,6 +130,10 @@ struct EmDev {
     double bg_inv_h;
     int32_t bg_nbis, pad_bg;
     int32_t lean_gen, mass_tab;       // (mass_tab: a band has a finite detection limit -- the general lean task reads log Phi from the table it keeps in LDS at LdsW::nodes, logphi_tab.h)  general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
+    // Pei-1992 extinction of the lean task without the pre-pass launch: per model filter [z_mid, 1 / z_half, c_0 .. c_13] -- Chebyshev
+    // coefficients of the extinction magnitude PER UNIT E(B-V) over the handle's redshift range (nmma_em_create: built and verified
+    // against em_math.h:p92_smc_ext_mag on a dense grid; null where the range or the accuracy does not allow it: ext_tab then)
+    const double* p92_cheb;   // [M][16]
 };
 
 }  // namespace nmma

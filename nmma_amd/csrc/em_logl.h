@@ -124,14 +124,17 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // Lean task with extinction: ext_mag[item][sample] of this tile in LDS, filled by the prologue lane that owns the sample's
     // E(B-V) -- coefficient x E(B-V) for the linear law, the pre-pass kernel's value for the Pei-1992 law -- so that a task reads
     // ONE LDS word per slot (anything more inside the task tips hipcc into spilling: see the register-budget test)
-    auto fill_ext = [&](const int s_l, const double ebv) {
+    auto fill_ext = [&](const int s_l, const double ebv, const double zp1) {
         double* et = reinterpret_cast<double*>(smem + L.exttab);
         if (!P.has_ebv) { et[s_l] = 0.0; return; }        // one row of zeros that every item reads
         long bb = tile0 + s_l;
         if (bb >= B) bb = B - 1;
         for (int kk = 0; kk < W; ++kk) {
             const int m_k = P.item_desc[kk].m;
-            et[kk * TS + s_l] = P.p92_tab ? P.ext_tab[bb * P.M + m_k] : ((ebv != 0.0) ? P.item_desc[kk].ebvc * ebv : 0.0);
+            if (P.p92_cheb != nullptr)       // Pei 1992: magnitude per unit E(B-V) from the filter's series in the redshift (no pre-pass launch)
+                et[kk * TS + s_l] = (ebv != 0.0) ? cheb14_eval(P.p92_cheb + m_k * 16, zp1 - 1.0) * ebv : 0.0;
+            else
+                et[kk * TS + s_l] = P.p92_tab ? P.ext_tab[bb * P.M + m_k] : ((ebv != 0.0) ? P.item_desc[kk].ebvc * ebv : 0.0);
         }
     };
     if (!helper) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 // measurement build: what a pre-pass kernel for the per-sample scalars could save AT MOST -- the chains are gone,
                 // plausible constants stand in (the tasks run the same instruction stream on wrong numbers)
                 if (vwave == 0) { sc[S_ZP1] = 1.0093; sc[S_IZP1] = 1.0 / 1.0093; sc[S_RC] = -0.01; }
-                else if (vwave == 1) { sc[S_DMOD] = 33.0; sc[S_TS] = -0.3; sc[S_EBV] = 0.0; if constexpr (LEANX) fill_ext(lane, 0.0); }
+                else if (vwave == 1) { sc[S_DMOD] = 33.0; sc[S_TS] = -0.3; sc[S_EBV] = 0.0; if constexpr (LEANX) fill_ext(lane, 0.0, 1.0); }
                 else if (vwave == 3) bad[lane] = 0;
                 (void)row; (void)dgl_l; (void)zgl_l;
 #else
@@ -190,13 +193,15 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     sc[S_IZP1] = 1.0 / (1 + z);
                     sc[S_RC] = redshift_correction(z);
                     chk = d_l + z;
+                    // (the Pei-1992 series needs the redshift: this wave fills the extinction rows then, with its own copy of E(B-V))
+                    if constexpr (LEANX) if (P.p92_cheb != nullptr) fill_ext(lane, P.has_ebv ? apply_slot(P.ebv, row) : 0.0, 1 + z);
                 } else if (vwave == 1) {
                     const double d_l = apply_slot(P.lumdist, row);
                     sc[S_DMOD] = distance_modulus(d_l);
                     sc[S_TS] = apply_slot(P.timeshift, row);
                     sc[S_EBV] = P.has_ebv ? apply_slot(P.ebv, row) : 0.0;
                     chk = sc[S_TS] + sc[S_EBV];
-                    if constexpr (LEANX) fill_ext(lane, sc[S_EBV]);
+                    if constexpr (LEANX) if (P.p92_cheb == nullptr) fill_ext(lane, sc[S_EBV], 1.0);
                 } else if (vwave == 2) {
                     for (int p = 0; p < P.NP; ++p) chk += apply_slot(P.model_param[p], row);
                 } else {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if constexpr (FAST)
                     if (nodes && odd) repair_nodes(reinterpret_cast<double*>(smem + L.epar) + q0 * TS + vt, TS, P.sys_node_t + q0, q1 - q0);
             }
-            if constexpr (LEANX) fill_ext(vt, scal[vt * 8 + S_EBV]);
+            if constexpr (LEANX) fill_ext(vt, scal[vt * 8 + S_EBV], scal[vt * 8 + S_ZP1]);
             badp[vt] = (chk - chk == 0.0) ? 0 : 1;
             badp[TS + vt] = 0; badp[2 * TS + vt] = 0; badp[3 * TS + vt] = 0;
             bad[vt] = 0;

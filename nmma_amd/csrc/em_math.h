@@ -319,6 +319,22 @@ NM_HD double p92_smc_ext_mag(double nu, double zp1, double ebv) {
     }
     return -2.5 * log10(ext);
 }
+// Chebyshev series sum_k c_k T_k(t), t = (z - row[0]) * row[1], c_k = row[2 + k], k < 14 (Clenshaw): the lean task's Pei-1992
+// extinction per unit E(B-V) as a function of the redshift (EmDev::p92_cheb)
+template <typename RowPtr>
+NM_HD double cheb14_eval(RowPtr row, double z) {
+    const double t = (z - row[0]) * row[1], t2 = t + t;
+    double b1 = 0.0, b2 = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 13; k >= 1; --k) {
+        const double b0 = fma(t2, b1, row[2 + k] - b2);
+        b2 = b1; b1 = b0;
+    }
+    return fma(t, b1, row[2] - b2);
+}
+
 // extinction magnitude of one (sample, model filter): `coeff` is ebv_coeff[m] for the linear law and the filter
 // frequency for P92 (law: enum nmma_extinction_law); nothing is applied at Ebv == 0 (model.py:328-330)
 NM_HD double extinction_mag(int law, double coeff, double zp1, double ebv) {

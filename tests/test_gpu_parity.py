@@ -762,3 +762,29 @@ def test_non_finite_systematics_nodes_are_masked_like_the_reference(flavour, tor
     assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
     # the rows whose blue bands / 2massj band lost all but one node are upper limits only there: finite and far from the others
     assert np.isfinite(want[5]) and np.isfinite(want[6])
+
+
+def test_p92_extinction_series_in_the_kernel_matches_the_pre_pass(torch_cuda, monkeypatch):
+    """The Pei-1992 law of the lean task: E(B-V) times a 14-term Chebyshev series in the redshift per filter, evaluated in the kernel's
+    prologue (built and verified against the law at nmma_em_create), against the pre-pass launch that evaluates the law itself per
+    (sample, filter) (``NMMA_EM_NO_P92_SERIES=1``): log L to 1e-12, the same floor pattern, no pre-pass in the launch count -- and both
+    against the oracle at the parity tolerance."""
+    from oracle import nmma_oracle as orc
+    torch = torch_cuda
+    case = cases.SHAPE_CASES["extinction_p92"]()
+    _, theta = syn.draw_theta(91, 3000, case["names"])
+    theta[11, case["names"].index("Ebv")] = 0.0            # (no extinction at all for E(B-V) = 0: model.py:328-330)
+    th = torch.as_tensor(theta, device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    monkeypatch.setenv("NMMA_EM_NO_P92_SERIES", "1")
+    eng = engine_from_case(case)
+    pre = eng.loglike(th).cpu().numpy()
+    eng.close()
+    assert np.array_equal(got == FLOOR, pre == FLOOR)
+    fin = pre > FLOOR
+    assert fin.sum() > 2000 and rel_err(got[fin], pre[fin]).max() <= 1e-12
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], theta[:64])
+    assert rel_err(got[:64][want > FLOOR], want[want > FLOOR]).max() <= LOGL_RTOL

@@ -81,7 +81,8 @@ def _per_filter_syserr_case():
     return c
 
 
-@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape", "c4_syserr", "syserr_per_filter"])
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "fast_np6", "log_grid", "c2_dt05_limit", "averaging", "c4_shape", "c4_syserr", "syserr_per_filter",
+                                  "extinction_p92"])        # (Pei-1992 extinction: in the step since the law is a series in the kernel, no pre-pass launch)
 def test_fused_mcmc_step_is_the_two_launch_step(torch_cuda, name):
     """The queue's one-launch MCMC step (accept + next proposal in the likelihood kernel's epilogue: ``nmma_em_loglike_walk``,
     ``em_logl<..., WALKF>``) against the likelihood launch + ``walk_step_kernel`` (option ``walk_fuse`` = 0) and against the
