@@ -235,6 +235,12 @@ NM_HD double log_gauss_mass_tab(double b, TabPtr tab) {
 // detection_term with the truncation mass from the table (the general lean task of em_logl: finite detection limits)
 template <typename TabPtr>
 NM_HD double detection_term_tab(double m, double est, double sigma, double log_sigma, double lim, TabPtr tab) {
+    if (lim == dinf()) {   // untruncated, as in detection_term
+        if (!(est < dinf()) || !(sigma > 0)) return dnan();
+        const double x = (m - est) / sigma;
+        if (x != x) return dnan();
+        return ((-(x * x) / 2.0 - kNormPdfLogC) - 0.0) - log_sigma;
+    }
     const double b = (lim - est) / sigma;
     if (!(b > -dinf()) || !(sigma > 0)) return dnan();   // also catches b = NaN (est = +inf)
     const double x = (m - est) / sigma;
