@@ -411,7 +411,7 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
     gpu_model_kind = "external"
 
     def __init__(self, model, filters, sample_times, model_parameters=(), cosmo_grid=None, device=0, gap_free=False,
-                 generate_lightcurve=None):
+                 generate_lightcurve=None, generate_lightcurve_batch=None):
         """``gap_free``: the supplied curves never hold a non-finite node strictly inside the time grid (afterglowpy's are finite, or
         the row is reported as failed: lightcurve_generation.py:259-283) -- a combined model's one-launch likelihood then skips its
         re-evaluation launch; a curve that breaks the promise makes the next likelihood call raise.
@@ -419,12 +419,15 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
         {filter: abs_mag[NS]}`` or something falsy when the model has no light curve for these parameters (model.py:378-379, :1423-1426)
         -- e.g. the bound ``generate_lightcurve`` of the reference's own ``GRBLightCurveModel``.  With it the likelihood needs no
         ``external_lc``: ``log_likelihood(parameters)``, ``log_likelihood_batch(theta)`` and a ``GPUPool`` call it once per row on the
-        host, then evaluate the whole batch in one launch."""
+        host, then evaluate the whole batch in one launch.
+        ``generate_lightcurve_batch``: the vectorised form for host models that have one -- ``(sample_times, parameters: dict of
+        arrays [B]) -> {filter: abs_mag[B, NS]}`` or ``({...}, ok[B])`` -- called once per batch instead of once per row."""
         super().__init__(model, filters, list(model_parameters), sample_times)
         self.gap_free = bool(gap_free)
         self.cosmo_grid, self.device = cosmo_grid, device
         self._lc_engine, self._lc_names = None, None
         self.generator = generate_lightcurve
+        self.batch_generator = generate_lightcurve_batch
 
     def generate_lightcurve(self, sample_times, parameters):
         """model.py:405-408: the model's source-frame light curve for one parameter dict (the supplied callable's)."""
@@ -441,6 +444,20 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
         st = np.asarray(self.model_times, float)
         lc = np.full((len(theta), len(self.filters), len(st)), np.inf)
         ok = np.ones(len(theta), dtype=bool)
+        if self.batch_generator is not None:
+            p = {k: np.full(len(theta), v) for k, v in (fixed or {}).items()}
+            p.update({n: theta[:, j].copy() for j, n in enumerate(names)})
+            if conversion is not None:
+                p = conversion(p)
+            res = self.batch_generator(st, p)
+            if isinstance(res, tuple):
+                res, good = res
+                ok &= np.asarray(good, dtype=bool)
+            for k, f in enumerate(self.filters):
+                if f in res:
+                    lc[:, k] = np.asarray(res[f], dtype=float)
+            lc[~ok] = np.inf
+            return lc, ok
         for i, row in enumerate(theta):
             p = dict(fixed or {})
             p.update(zip(names, (float(v) for v in row)))
@@ -541,7 +558,7 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         conversion chain applied first (model.py:1405-1408)."""
         out = dict(have or {})
         for m in self.lc_models:
-            if isinstance(m, ExternalLightCurveModel) and m.model not in out and m.generator is not None:
+            if isinstance(m, ExternalLightCurveModel) and m.model not in out and (m.generator is not None or m.batch_generator is not None):
                 th = theta.detach().cpu().numpy() if hasattr(theta, "detach") else np.asarray(theta)
                 out[m.model] = m.generate_batch(th, names, fixed, self.parameter_conversion)
         return out

@@ -557,6 +557,14 @@ def test_external_model_generator_builds_the_operand_row_by_row():
     assert np.all(np.isinf(lc[:, 2])) and np.all(np.isinf(lc[1]))          # a filter not returned / a failed row: no flux
     # the conversion chain ran first: KNtheta from inclination_EM (conversion.py:119-126), the fixed parameter is there
     assert len(seen) == 3 and abs(seen[0]["KNtheta"] - 0.3 * 180 / np.pi) < 1e-12 and seen[2]["offset"] == -12.5
+    # the vectorised form: one call per batch, arrays in, [B, NS] arrays (and an ok mask) out; conversions apply to the arrays
+    def gen_batch(sample_times, p):
+        assert p["grb_mag0"].shape == (3,) and np.allclose(p["KNtheta"], p["inclination_EM"] * 180 / np.pi) and np.all(p["offset"] == -12.5)
+        g = p["grb_mag0"][:, None] + p["grb_slope"][:, None] * np.log10(sample_times)[None, :]
+        return {"g": g, "r": np.full_like(g, -12.5)}, p["grb_mag0"] <= -14.5
+    ext_b = ExternalLightCurveModel("PLGRB", ["g", "r", "i"], st, model_parameters=["grb_mag0", "grb_slope"], generate_lightcurve_batch=gen_batch)
+    lc_b, ok_b = CombinedLightCurveModelContainer([other, ext_b]).host_operands(theta, names, {"offset": -12.5}, given)["PLGRB"]
+    assert ok_b.tolist() == ok.tolist() and np.array_equal(lc_b, lc)
     # nothing to do when every external sub-model is supplied or has no callable
     assert set(comb.host_operands(theta, names, {}, {"OTHER": given["OTHER"], "PLGRB": (lc, ok)})) == {"OTHER", "PLGRB"}
     with pytest.raises(RuntimeError):
