@@ -212,7 +212,7 @@ def _read_observation_rows(path, time_format):
     with open(path) as fh:
         for line in fh:
             parts = line.split()
-            if not parts or line.startswith(("#", "time", "mjd")):
+            if not parts or parts[0].startswith(("#", "time", "mjd")):
                 continue
             t, filt, mag, err = _to_mjd(parts[0], time_format), parts[1], float(parts[2]), float(parts[3])
             rows.setdefault(filt, []).append((t, mag, err))
