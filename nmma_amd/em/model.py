@@ -428,6 +428,7 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
         self._lc_engine, self._lc_names = None, None
         self.generator = generate_lightcurve
         self.batch_generator = generate_lightcurve_batch
+        self.batch_gap_free = False       # set per batch by CombinedLightCurveModelContainer.host_operands
 
     def generate_lightcurve(self, sample_times, parameters):
         """model.py:405-408: the model's source-frame light curve for one parameter dict (the supplied callable's)."""
@@ -558,9 +559,16 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         conversion chain applied first (model.py:1405-1408)."""
         out = dict(have or {})
         for m in self.lc_models:
-            if isinstance(m, ExternalLightCurveModel) and m.model not in out and (m.generator is not None or m.batch_generator is not None):
+            if not isinstance(m, ExternalLightCurveModel):
+                continue
+            m.batch_gap_free = False
+            if m.model not in out and (m.generator is not None or m.batch_generator is not None):
                 th = theta.detach().cpu().numpy() if hasattr(theta, "detach") else np.asarray(theta)
-                out[m.model] = m.generate_batch(th, names, fixed, self.parameter_conversion)
+                lc, ok = m.generate_batch(th, names, fixed, self.parameter_conversion)
+                # (the curves are in host memory anyway: whether any delivered row has a non-finite node strictly inside the grid is
+                #  one pass over them -- without one, the one-launch likelihood needs no re-evaluation launch for this batch)
+                m.batch_gap_free = bool(np.isfinite(lc[ok][:, :, 1:-1]).all())
+                out[m.model] = (lc, ok)
         return out
 
     def stack2_plan(self):

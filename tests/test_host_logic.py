@@ -565,6 +565,20 @@ def test_external_model_generator_builds_the_operand_row_by_row():
     ext_b = ExternalLightCurveModel("PLGRB", ["g", "r", "i"], st, model_parameters=["grb_mag0", "grb_slope"], generate_lightcurve_batch=gen_batch)
     lc_b, ok_b = CombinedLightCurveModelContainer([other, ext_b]).host_operands(theta, names, {"offset": -12.5}, given)["PLGRB"]
     assert ok_b.tolist() == ok.tolist() and np.array_equal(lc_b, lc)
+    # ... and whether the delivered rows are free of interior gaps is noted per batch (the failed row and the edge nodes do not count;
+    # a filter the model does not return is all +inf -- interior nodes without a value -- so this model makes no such promise)
+    assert not ext_b.batch_gap_free and not other.batch_gap_free
+    ext_gr = ExternalLightCurveModel("PLGRB", ["g", "r"], st, model_parameters=["grb_mag0", "grb_slope"], generate_lightcurve_batch=gen_batch)
+    CombinedLightCurveModelContainer([ExternalLightCurveModel("OTHER", ["g", "r"], st), ext_gr]).host_operands(theta, names, {"offset": -12.5}, {"OTHER": np.zeros((3, 2, 7))})
+    assert ext_gr.batch_gap_free
+
+    def gen_hole(sample_times, p):
+        res, good = gen_batch(sample_times, p)
+        res["g"][0, 3] = np.nan
+        return res, good
+    ext_h = ExternalLightCurveModel("PLGRB", ["g", "r"], st, model_parameters=["grb_mag0", "grb_slope"], generate_lightcurve_batch=gen_hole)
+    CombinedLightCurveModelContainer([ExternalLightCurveModel("OTHER", ["g", "r"], st), ext_h]).host_operands(theta, names, {"offset": -12.5}, {"OTHER": np.zeros((3, 2, 7))})
+    assert not ext_h.batch_gap_free
     # nothing to do when every external sub-model is supplied or has no callable
     assert set(comb.host_operands(theta, names, {}, {"OTHER": given["OTHER"], "PLGRB": (lc, ok)})) == {"OTHER", "PLGRB"}
     with pytest.raises(RuntimeError):
