@@ -515,9 +515,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         lsig = log(sig);
                     }
                     if (sig - sig == 0.0) {   // np.isfinite(data_sigma): detection
-                        chi += detection_term_tab(mobs, est, sig, lsig, lim, static_cast<const double*>(kLogPhiTab));       // (log Phi from the table, read from global memory in the fallback flavours)
+                        chi += detection_term_gtab(mobs, est, sig, lsig, lim);       // (log Phi from the table, read from global memory in the fallback flavours)
                     } else {                  // infinite error: upper limit
-                        gp += upper_limit_term_tab(mobs, est, e, static_cast<const double*>(kLogPhiTab));
+                        gp += upper_limit_term_gtab(mobs, est, e);
                     }
                 }
             }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     if (isig != 0.0 || sig_bad) {
                         double v;
                         if (EXT && lim_finite) {         // uniform: truncated Gaussian with a finite detection limit
-                            v = sig_bad ? dnan() : detection_term_tab(c_m[u], est, 1.0 / isig, lsig, it.lim, static_cast<const double*>(kLogPhiTab));
+                            v = sig_bad ? dnan() : detection_term_gtab(c_m[u], est, 1.0 / isig, lsig, it.lim);
                         } else {
                             const double x = (c_m[u] - est) * isig;
                             v = (-(x * x) / 2.0 - kNormPdfLogC) - lsig;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         }
                         add_chi = v;
                     } else {
-                        add_gp = upper_limit_term_tab(c_m[u], est, e_sys, static_cast<const double*>(kLogPhiTab));
+                        add_gp = upper_limit_term_gtab(c_m[u], est, e_sys);
                     }
                     opaque(add_chi); opaque(add_gp);
                     chi += add_chi; gp += add_gp;

@@ -1,4 +1,4 @@
-// em_logl_w4.hip -- em_logl instantiations: the fused MCMC step on 32-sample tiles (plain lean task, lean tasks with extras)
+// em_logl_w4.hip -- em_logl instantiations: the fused MCMC step on 32-sample tiles (plain lean task, lean task with extras on equally spaced grids)
 #include "em_logl.h"
 
 namespace nmma {
@@ -6,7 +6,6 @@ namespace nmma {
 #ifndef NMMA_DEV_HEADLINE_ONLY
 NMMA_LOGL_WALK2(1);
 NMMA_LOGL_WALK2(3);
-NMMA_LOGL_WALK2(4);
 #endif
 
 }  // namespace nmma

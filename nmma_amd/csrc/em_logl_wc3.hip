@@ -1,4 +1,4 @@
-// em_logl_wc3.hip -- em_logl instantiations: the fused MCMC step with a Constraint program on 32-sample tiles
+// em_logl_wc3.hip -- em_logl instantiations: the fused MCMC step with a Constraint program on 32-sample tiles (FASTM 1, 3)
 #include "em_logl.h"
 
 namespace nmma {
@@ -6,7 +6,6 @@ namespace nmma {
 #ifndef NMMA_DEV_HEADLINE_ONLY
 NMMA_LOGL_WALK2_CON(1);
 NMMA_LOGL_WALK2_CON(3);
-NMMA_LOGL_WALK2_CON(4);
 #endif
 
 }  // namespace nmma

@@ -261,6 +261,15 @@ NM_HD double upper_limit_term_tab(double m, double est, double sigma_sys, TabPtr
     return (!(sigma_sys > 0) || x != x) ? dnan() : r;
 }
 
+// The same two terms with the table read from global memory (kLogPhiTab: 2 KB, cache-resident), OUT OF LINE: for the kernels where the
+// term is rare per lane and the code size matters more than the call (em_lc_loglike's general datum, the fallback flavours of em_logl)
+NM_HD_COLD double upper_limit_term_gtab(double m, double est, double sigma_sys) {
+    return upper_limit_term_tab(m, est, sigma_sys, static_cast<const double*>(kLogPhiTab));
+}
+NM_HD_COLD double detection_term_gtab(double m, double est, double sigma, double log_sigma, double lim) {
+    return detection_term_tab(m, est, sigma, log_sigma, lim, static_cast<const double*>(kLogPhiTab));
+}
+
 // One upper limit: norm.logsf(m, est, sigma_sys) = log_ndtr(-(m - est)/sigma_sys);
 // rv_continuous.logsf: scale <= 0 or NaN args -> NaN; x at the lower support edge -> 0.
 NM_HD double upper_limit_term(double m, double est, double sigma_sys) {
