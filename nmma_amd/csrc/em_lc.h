@@ -380,10 +380,10 @@ __device__ __forceinline__ void em_lc_loglike_body(
             lsig = log(sig);
         }
         const double mobs = dm_p[di];
-        if (sig - sig == 0.0) chi += detection_term_gtab(mobs, est, sig, lsig, lim);
+        if (sig - sig == 0.0) chi += detection_term_tab(mobs, est, sig, lsig, lim, static_cast<const double*>(kLogPhiTab));
         // (log Phi from the polynomial table of logphi_tab.h, read from global memory here -- 2 KB, cache-resident: the out-of-line
         //  scipy formula was most of the 4.9 us this kernel spent on ONE upper limit per sample, profiles/r04_config3_tail.md)
-        else gp += upper_limit_term_gtab(mobs, est, e);
+        else gp += upper_limit_term_tab(mobs, est, e, static_cast<const double*>(kLogPhiTab));       // (inline: out of line it costs this kernel 1.8 of the 3.5 us the table saves)
     };
 
     double chi_tot = 0.0, gp_tot = 0.0;
