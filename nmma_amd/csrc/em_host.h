@@ -48,6 +48,7 @@ struct nmma_em_handle {
     int walk_split = 1;             // "walk_split" / NMMA_WALK_NO_SPLIT: small queues' fused launches split by band
     int lc_group = 0;               // "lc_group"   / NMMA_LC_GROUP, NMMA_LC_NO_GROUPS: lanes per sample of em_lc_loglike (0: by batch size; 16 / 32 / 64)
     int stack2_fixup = 1;           // "stack2_fixup" / NMMA_STACK2_NO_FIXUP: re-evaluation launches of nmma_em_loglike_stack2 (0: measurement only)
+    int walk_tab_mask = 0;          // fused-MCMC-step forms (bit 2 (R - 1) + (16 lanes per chain)) that give way to two launches: the log Phi table of the upper limits would cost them a ring slot
     int stack2_ok = 0;              // the handle has the one-launch form of the combined model (em_logl<.., 7>; nmma_em_loglike_stack2)
     std::string stack2_why;         // ... or why not (what nmma_last_error says after status 2)
     unsigned char* gap_ws = nullptr;    // [B] rows em_logl<.., 7> flagged for re-evaluation

@@ -788,3 +788,43 @@ def test_p92_extinction_series_in_the_kernel_matches_the_pre_pass(torch_cuda, mo
     assert fin.sum() > 2000 and rel_err(got[fin], pre[fin]).max() <= 1e-12
     want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], theta[:64])
     assert rel_err(got[:64][want > FLOOR], want[want > FLOOR]).max() <= LOGL_RTOL
+
+
+@pytest.mark.parametrize("name", ["c2_default", "syserr_param", "c2_dt05_limit", "log_grid"])
+def test_upper_limits_from_the_table_match_the_formula(name, torch_cuda, monkeypatch):
+    """Many upper limits per filter (a third of every band's epochs turned into non-detections, some far brighter than any model --
+    log Phi down to the table's lower end and beyond it -- some far fainter -- beyond its upper end): the lean tasks with the table of
+    logphi_tab.h against the same handle built with ``NMMA_EM_NO_UL_TAB=1`` (scipy's formula out of line) at 1e-12, and against the
+    oracle at the parity tolerance.  (The general lean task, ``c2_dt05_limit``, has no formula form: oracle only.)"""
+    from oracle import nmma_oracle as orc
+    torch = torch_cuda
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    rng = np.random.default_rng(17)
+    times, mags, sigmas = (dict(d) for d in case["data"])
+    for f in case["observed_filters"]:
+        m, sg = np.array(mags[f], float), np.array(sigmas[f], float)
+        ul = rng.uniform(size=len(m)) < 0.34
+        sg[ul] = np.inf
+        m[ul] += rng.choice([-9.0, -3.0, -0.5, 0.5, 3.0, 12.0], size=int(ul.sum()))
+        mags[f], sigmas[f] = m, sg
+    case["data"] = (times, mags, sigmas)
+    _, theta = syn.draw_theta(23, 1500, case["names"])
+    th = torch.as_tensor(theta, device="cuda:0")
+    eng = engine_from_case(case)
+    got = eng.loglike(th).cpu().numpy()
+    eng.check()
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), case["names"], theta[:96])
+    fin = want > FLOOR
+    assert np.array_equal(got[:96] > FLOOR, fin) and fin.sum() > 40
+    assert rel_err(got[:96][fin], want[fin]).max() <= LOGL_RTOL
+    if name != "c2_dt05_limit":
+        monkeypatch.setenv("NMMA_EM_NO_UL_TAB", "1")
+        eng = engine_from_case(case)
+        ref = eng.loglike(th).cpu().numpy()
+        eng.close()
+        assert np.array_equal(got == FLOOR, ref == FLOOR)
+        ok = ref > FLOOR
+        assert rel_err(got[ok], ref[ok]).max() <= 1e-12
+        if name == "c2_default":                      # (config 2's handle has room for the table in every launch form: last bits differ somewhere)
+            assert not np.array_equal(got, ref)
