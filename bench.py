@@ -288,6 +288,15 @@ def main():
     # with more than one GPU the other scaling mode is measured in the same invocation and reported under "other_scaling"
     other = measure("strong" if args.scaling == "weak" else "weak") if world > 1 else None
 
+    # the sampler queue sharded over the ranks (parallel.ShardedQueue: what the reference's task farm does with a queue's chains,
+    # core/mpi_setup.py:651-667, :679-683) -- every rank takes part, rank 0 reports; context, never `value`
+    sharded = None
+    if use_dist:
+        try:
+            sharded = device_walk_queue_sharded(eng, case, syn, dist, world, rank, dev, share_gpu)
+        except Exception as exc:      # noqa: BLE001  (a failure here must not cost the contract line; every rank fails alike or the barrier below reports)
+            sharded = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         m = main_mode
         B, global_batch, prof = m["B"], m["global_batch"], m["prof"]
@@ -324,6 +333,8 @@ def main():
                                      "unit": "evals/s", "ms_per_step": 1e3 * other["elapsed"] / args.steps,
                                      "batch_per_gpu": other["B"], "global_batch": other["global_batch"],
                                      "exchange": exchange_label(other), "kernel_ms": o_ms}
+        if sharded is not None:
+            line["device_walk_queue_sharded"] = sharded
         if world == 1 and args.sustained_seconds > 0:
             try:
                 line["sustained"] = sustained_leg(eng, m["thetas"], m["out"], B, args.sustained_seconds, line["value"], fused_ms)
@@ -346,7 +357,7 @@ def main():
             context("device_walk_queue", lambda: device_walk_queue(case, syn, line["device_walk"]["evals_per_s"]))
             line["cpu_baseline"] = cpu_baseline(case, args.cpu_seconds)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
-            context("cpu_baseline_all_cores", lambda: cpu_baseline_all_cores(args.cpu_seconds))
+            context("cpu_baseline_all_cores", lambda: cpu_baseline_all_cores(args.cpu_seconds, line["cpu_baseline"]["value"]))
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None and dist.is_initialized():
@@ -362,6 +373,7 @@ def sustained_leg(eng, thetas, out, batch, seconds, value, kernel_ms_region, chu
     import gc
     import numpy as np
     import torch
+    saved_env = {k: os.environ.get(k) for k in ("NMMA_PROFILE_GROUP", "NMMA_PROFILE_STRIDE")}
     os.environ["NMMA_PROFILE_GROUP"], os.environ["NMMA_PROFILE_STRIDE"] = "8", "16"
     n_sets = len(thetas)
     gc.collect()
@@ -383,6 +395,11 @@ def sustained_leg(eng, thetas, out, batch, seconds, value, kernel_ms_region, chu
         total = time.perf_counter() - t_start
     finally:
         gc.enable()
+        for k, v in saved_env.items():      # (the legs that follow -- host calls, CPU baseline children -- must not inherit the profiling knobs)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     start, wall, kern_us = (np.array(v) for v in zip(*chunks))
     first, last = start < 1.0, start >= start[-1] - 1.0
     k_first, k_last = float(kern_us[first].mean()), float(kern_us[last].mean())
@@ -448,6 +465,83 @@ def device_walk_step_ms(eng, case, syn, n=4096, steps=400):
     t0 = time.perf_counter()
     smp.device_walk(table, live, live, bound, keys, steps, ll, device=eng.device)
     return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def device_walk_queue_sharded(eng, case, syn, dist, world, rank, dev, share_gpu, per_rank=4096, walks=100, repeats=7):
+    """ONE queue of the nested sampler sharded over the torchrun ranks -- ``parallel.ShardedQueue`` with this rank's ``EMEngine``:
+    every rank walks its contiguous shard of the chains on its GPU (one library call: upload, `walks` fused likelihood + MCMC-step
+    launches, fresh draws), the library packs the shard's records on the device, ONE all-gather (RCCL over xGMI; gloo through the host
+    in the share-GPU test mode) exchanges them and one download brings all records to every rank.  Weak: `per_rank` chains per rank;
+    strong: `per_rank` chains in total.  Times are wall per queue, MAX over ranks, median of `repeats` (barrier + synchronize on both
+    sides).  The reference spreads a queue's chains over its MPI ranks the same way (core/mpi_setup.py:651-667, :679-683)."""
+    import numpy as np
+    import torch
+    from nmma_amd import sampler as smp
+    from nmma_amd.parallel import ShardedQueue, shard_bounds
+
+    class Uniform:          # (the analytic prior the device table recognises by name)
+        def __init__(self, lo, hi):
+            self.minimum, self.maximum = float(lo), float(hi)
+
+    names = case["names"]
+    th = syn.draw_theta(3, 20000, names)[1]
+    lo, hi = th.min(axis=0), th.max(axis=0)
+    table = smp.device_prior_table({k: Uniform(a, b) for k, a, b in zip(names, lo, hi)}, names)
+    ndim = len(names)
+    queue = ShardedQueue(engine=eng, table=table)
+
+    def timed(fn):
+        vals = []
+        for _ in range(repeats):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            vals.append(time.perf_counter() - t0)
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if share_gpu:
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(np.median(t.cpu().numpy()))
+
+    out = {}
+    for mode, n in (("weak", per_rank * world), ("strong", per_rank)):
+        live = np.random.default_rng(11).uniform(0.3, 0.7, (n, ndim))            # (the same on every rank: seeded)
+        # (the bound a nested sampler would hold at this moment: a low quantile of the live points' likelihoods -- tools/perf_device_walk.py)
+        bound = float(np.quantile(eng.loglike(np.ascontiguousarray(lo + live * (hi - lo))), 0.2))
+        keys = np.arange(1000, 1000 + n, dtype=np.uint64)
+        res = queue.run(live, live, bound, keys, walks)                         # (warm-up: workspace, buffers, communicator)
+        a, b = shard_bounds(n, world, rank)
+        t_queue = timed(lambda: queue.run(live, live, bound, keys, walks))
+        walk_ms, exch_ms = queue.last_gpu_ms, queue.last_exchange_ms
+        # the rank's shard alone, records downloaded instead of exchanged (what one GPU does with its share of the queue)
+        t_local = timed(lambda: eng.walk_queue(table, live, live[a:b], bound, keys[a:b], walks)) if b > a else 0.0
+        u, v, logl, counts = res
+        assert u.shape == (n, ndim) and np.all(np.isfinite(logl)) and int(counts[:, 3].sum()) > 0
+        out[mode] = {"chains": n, "chains_per_rank": b - a, "walks": walks, "queue_ms": 1e3 * t_queue, "evals_per_s": n * walks / t_queue,
+                     "rank0_walk_gpu_ms": walk_ms, "rank0_exchange_ms": exch_ms, "rank_shard_alone_ms": 1e3 * t_local,
+                     "record_bytes_per_rank": (-(-n // world)) * (2 * ndim + 3) * 8}
+    # the collective by itself: the weak-mode send buffer, all-gathered back to back
+    slot, width = per_rank, 2 * ndim + 3
+    if share_gpu:
+        send, recv = torch.zeros((slot, width), dtype=torch.float64), torch.empty((world * slot, width), dtype=torch.float64)
+    else:
+        send, recv = torch.zeros((slot, width), dtype=torch.float64, device=dev), torch.empty((world * slot, width), dtype=torch.float64, device=dev)
+    for _ in range(5):
+        dist.all_gather_into_tensor(recv, send)
+    calls = 50
+
+    def gathers():
+        for _ in range(calls):
+            dist.all_gather_into_tensor(recv, send)
+    out["allgather_us_per_call"] = 1e6 * timed(gathers) / calls
+    out["allgather_bytes_per_rank"] = slot * width * 8
+    out["exchange"] = "gloo all_gather through the host (TEST MODE: ranks share one GPU)" if share_gpu else "RCCL all_gather of the device-packed records, one download"
+    out["what"] = ("parallel.ShardedQueue over the ranks, one EMEngine per rank: wall per queue (max over ranks, median), weak = "
+                   f"{per_rank} chains per rank, strong = {per_rank} chains in total, {walks} MCMC steps per chain; rank_shard_alone_ms = the "
+                   "same shard walked and downloaded without the exchange")
+    return out
 
 
 def device_walk_queue(case, syn, inner_rate, n=4096, walks=100, repeats=7):
@@ -550,7 +644,26 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline_all_cores(budget_s):
+def _cgroup_cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 ``cpu.max`` or v1 ``cpu.cfs_quota_us / cpu.cfs_period_us``), or None when
+    unlimited / unreadable: ``sched_getaffinity`` reports the host's hardware threads whatever the quota is."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = float(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = float(fh.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline_all_cores(budget_s, one_core_rate=None):
     """The MPI task farm of the reference (one likelihood per rank, core/mpi_setup.py:651-667) as independent
     single-threaded processes, one per host core -- children that never touch the GPU."""
     import subprocess
@@ -567,8 +680,15 @@ def cpu_baseline_all_cores(budget_s):
             total += int(n); slowest = max(slowest, float(dt))
         except (ValueError, IndexError):
             pass
-    return {"value": total / slowest if slowest > 0 else None, "unit": "evals/s", "cores": cores, "cpu_model": _cpu_model(),
-            "kind": "port", "sample": f"{cores} independent single-threaded processes x {budget:.0f} s of the same loop"}
+    value = total / slowest if slowest > 0 else None
+    # `cores` = the processes started (one per hardware thread this process may run on); a container's CPU quota can be far below
+    # that -- then the rate is the quota's, not 256 cores' -- so the quota and the rate in units of the one-core leg are stated too
+    return {"value": value, "unit": "evals/s", "cores": cores, "cpu_model": _cpu_model(),
+            "cgroup_cpu_quota_cores": _cgroup_cpu_quota(),
+            "equivalent_single_cores": (value / one_core_rate) if (value and one_core_rate) else None,
+            "kind": "port", "sample": f"{cores} independent single-threaded processes x {budget:.0f} s of the same loop; cores = processes started "
+                                      "(sched_getaffinity), cgroup_cpu_quota_cores = the container's CPU-time limit (null: none), "
+                                      "equivalent_single_cores = this rate / the one-core leg's"}
 
 
 def cpu_baseline(case, budget_s):

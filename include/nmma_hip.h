@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 6
+#define NMMA_ABI_VERSION 7
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -504,6 +504,12 @@ typedef struct nmma_walk_queue {
     double* logl;                    /* out [n]                                      */
     int32_t* counts;                 /* out [n][4] accept, reject, outside the cube, likelihood calls                  */
     double gpu_ms;                   /* out: upload .. download complete, HIP events */
+    double* records_dev;             /* NULL, or a DEVICE buffer [n][2 ndim + 3]: row c = u | v | logl | counts (the four int32 in the bit
+                                      * patterns of two doubles).  The records are then packed there on `stream` INSTEAD of being downloaded
+                                      * (u, v, logl, counts may be NULL; end only waits and checks the handle) -- the send buffer of a queue
+                                      * sharded over ranks, whose records are all-gathered on the device (RCCL over xGMI) and downloaded
+                                      * once: nmma_amd/parallel.py:ShardedQueue, the reference's chains-over-ranks split of
+                                      * core/mpi_setup.py:651-667, :679-683 */
 } nmma_walk_queue;
 int32_t nmma_em_walk_queue(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_queue* q, void* stream);
 /* The same call in two halves, for a queue SHARDED over several devices from one host thread (the reference spreads the chains of a

@@ -28,7 +28,7 @@ UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 #: seconds each unit took in this process's last build_library call (tools: order SOURCES longest first)
 UNIT_SECONDS = {}
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 STACK2_GAP_FREE = 1
 MAX_PARAMS = 8
 MAX_COEFF = 16
@@ -119,6 +119,7 @@ class WalkQueue(C.Structure):
         ("live", C.c_void_p), ("n_live", C.c_int64), ("u0", C.c_void_p), ("loglstar", C.c_void_p), ("key", C.c_void_p),
         ("walks_per_chain", C.c_void_p), ("n", C.c_int64), ("first_step", C.c_uint64), ("constraints", C.c_void_p),
         ("u", C.c_void_p), ("v", C.c_void_p), ("logl", C.c_void_p), ("counts", C.c_void_p), ("gpu_ms", C.c_double),
+        ("records_dev", C.c_void_p),
     ]
 
 

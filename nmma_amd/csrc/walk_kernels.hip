@@ -78,6 +78,25 @@ __global__ __launch_bounds__(256) void walk_fresh_logl_kernel(const long n, cons
     counts[4 * c + 3] += 1;
 }
 
+// A queue's records as ONE device buffer (nmma_walk_queue::records_dev): row c = [u[D] | v[D] | logl | counts], the four int32 counters in
+// the bit patterns of two doubles -- what a rank of a sharded queue hands to the all-gather (parallel.ShardedQueue: the shards' records are
+// exchanged on the device, RCCL over xGMI, and downloaded once).  One thread per (chain, column).
+__global__ __launch_bounds__(256) void walk_pack_records_kernel(const long n, const int D, const double* __restrict__ u, const double* __restrict__ v,
+                                                                const double* __restrict__ logl, const int32_t* __restrict__ counts,
+                                                                double* __restrict__ rec) {
+    const int W = 2 * D + 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * W) return;
+    const long c = i / W;
+    const int j = (int)(i - c * W);
+    double x;
+    if (j < D) x = u[c * D + j];
+    else if (j < 2 * D) x = v[c * D + (j - D)];
+    else if (j == 2 * D) x = logl[c];
+    else x = reinterpret_cast<const double*>(counts + 4 * c)[j - 2 * D - 1];      // (counts + 4 c is 16-byte aligned)
+    rec[i] = x;
+}
+
 // accept of step `step` and proposal of step `step + 1` in one launch (a chain's accept touches only its own row, and its next proposal
 // reads that row and the fixed live points; lane d of the group owns element d of both): an MCMC step is then two launches -- this one
 // and the likelihood.  (The group reads inside[c] for the accept before its lane 0 stores the next flag: one wavefront, program order.)
@@ -390,6 +409,7 @@ struct nmma_walk_ws {
     hipStream_t pend_stream = nullptr;
     long pend_n = 0, pend_d = 0;
     size_t pend_u = 0, pend_v = 0, pend_logl = 0, pend_cnt = 0;
+    bool pend_dev_records = false;   // the records went to nmma_walk_queue::records_dev: nothing to unpack
 };
 
 int32_t nmma_walk_ws_create(int32_t device, nmma_walk_ws** out) {
@@ -424,13 +444,14 @@ int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma
     WalkSpec S;
     if (walk_spec(q->priors, q->ndim, &S, "nmma_em_walk_queue")) return 1;
     const long n = (long)q->n, D = q->ndim, NL = (long)q->n_live;
-    if (n < 0 || NL < 3 || !q->live || !q->u0 || !q->loglstar || !q->key || !q->u || !q->v || !q->logl || !q->counts ||
+    const bool dev_rec = q->records_dev != nullptr;
+    if (n < 0 || NL < 3 || !q->live || !q->u0 || !q->loglstar || !q->key || (!dev_rec && (!q->u || !q->v || !q->logl || !q->counts)) ||
         (!q->walks_per_chain && q->walks < 1))
-        return fail("nmma_em_walk_queue: bad argument (at least three live points, walks >= 1)");
+        return fail("nmma_em_walk_queue: bad argument (at least three live points, walks >= 1, host outputs or records_dev)");
     if (nmma_em_device(h) != ws->device) return fail("nmma_em_walk_queue: the workspace belongs to another device than the likelihood handle");
     if (q->constraints && (q->constraints->device != ws->device || q->constraints->n_cols > D))
         return fail("nmma_em_walk_queue: the constraint program belongs to another device or reads columns the walk does not sample");
-    ws->pend_n = n; ws->pend_d = D; ws->pend_stream = static_cast<hipStream_t>(stream);
+    ws->pend_n = n; ws->pend_d = D; ws->pend_stream = static_cast<hipStream_t>(stream); ws->pend_dev_records = dev_rec;
     if (n == 0) { ws->pending = true; return 0; }
     if (hipSetDevice(ws->device) != hipSuccess) return fail("nmma_em_walk_queue: hipSetDevice failed");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -494,6 +515,9 @@ int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma
         wf->first_step = q->first_step;
     }
 #define NMQ(call, what) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return fail(std::string("nmma_em_walk_queue: ") + what + ": " + hipGetErrorString(e_)); } while (0)
+    // (everything from here on is enqueued work that reads ws->pin / ws->dev: a failure part-way drains the stream before it returns, so
+    //  that a retry never writes into a pinned buffer a copy is still reading)
+    auto enqueue = [&]() -> int {
     NMQ(hipEventRecord(ws->ev0, s), "event");
     NMQ(hipMemcpyAsync(d, p, up_end, hipMemcpyHostToDevice, s), "upload");
     NMQ(hipMemcpyAsync(d + o_logl, p + o_logl, o_prop - o_logl, hipMemcpyHostToDevice, s), "upload of the initial state");
@@ -535,8 +559,17 @@ int32_t nmma_em_walk_queue_begin(nmma_em_handle* h, nmma_walk_ws* ws, const nmma
     if (nmma_em_loglike(h, theta_d, n, D, lp_d, stream)) return 1;
     hipLaunchKernelGGL(walk_fresh_logl_kernel, grid_t, block, 0, s, n, (int)D, stuck_d, lp_d, theta_d, logl_d, cnt_d, con_ops, n_con);
     NMQ(hipGetLastError(), "launch");
-    NMQ(hipMemcpyAsync(p + o_u, d + o_u, down_end - o_u, hipMemcpyDeviceToHost, s), "download");
+    if (dev_rec) {      // the records stay on the device, packed for the caller's collective; no download
+        const long cells = n * (2 * D + 3);
+        hipLaunchKernelGGL(walk_pack_records_kernel, dim3((unsigned)((cells + 255) / 256)), block, 0, s, n, (int)D, u_d, v_d, logl_d, cnt_d, q->records_dev);
+        NMQ(hipGetLastError(), "launch of the record packing");
+    } else {
+        NMQ(hipMemcpyAsync(p + o_u, d + o_u, down_end - o_u, hipMemcpyDeviceToHost, s), "download");
+    }
     NMQ(hipEventRecord(ws->ev1, s), "event");
+    return 0;
+    };
+    if (enqueue()) { (void)hipStreamSynchronize(s); return 1; }
     ws->pend_u = o_u; ws->pend_v = o_v; ws->pend_logl = o_logl; ws->pend_cnt = o_cnt;
     ws->pending = true;
     return 0;
@@ -550,7 +583,8 @@ int32_t nmma_em_walk_queue_end(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_qu
     q->gpu_ms = 0.0;
     const long n = ws->pend_n, D = ws->pend_d;
     if (n == 0) return 0;
-    if (n != (long)q->n || D != q->ndim || !q->u || !q->v || !q->logl || !q->counts)
+    const bool dev_rec = ws->pend_dev_records;
+    if (n != (long)q->n || D != q->ndim || (dev_rec ? q->records_dev == nullptr : (!q->u || !q->v || !q->logl || !q->counts)))
         return fail("nmma_em_walk_queue_end: the queue record does not match the one that was begun");
     if (hipSetDevice(ws->device) != hipSuccess) return fail("nmma_em_walk_queue_end: hipSetDevice failed");
     NMQ(hipStreamSynchronize(ws->pend_stream), "stream");
@@ -558,6 +592,7 @@ int32_t nmma_em_walk_queue_end(nmma_em_handle* h, nmma_walk_ws* ws, nmma_walk_qu
     NMQ(hipEventElapsedTime(&ms, ws->ev0, ws->ev1), "event time");
 #undef NMQ
     q->gpu_ms = ms;
+    if (dev_rec) return nmma_em_check(h) ? 1 : 0;
     const unsigned char* p = ws->pin;
     memcpy(q->u, p + ws->pend_u, sizeof(double) * n * D);
     memcpy(q->v, p + ws->pend_v, sizeof(double) * n * D);

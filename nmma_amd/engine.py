@@ -593,10 +593,13 @@ class EMEngine:
         :class:`nmma_amd.core.constraints.ConstraintProgram` or None.  Returns ``(u, v, logl, counts[n, 4])`` as numpy arrays."""
         return self.walk_queue_end(self.walk_queue_begin(table, live, u0, loglstar, keys, walks, constraints, first_step, stream))
 
-    def walk_queue_begin(self, table, live, u0, loglstar, keys, walks, constraints=None, first_step=1, stream=None):
+    def walk_queue_begin(self, table, live, u0, loglstar, keys, walks, constraints=None, first_step=1, stream=None, records=None):
         """First half of :meth:`walk_queue` (``nmma_em_walk_queue_begin``): packs, uploads and enqueues the whole queue on this engine's
         device and returns a token WITHOUT waiting -- a queue sharded over several devices is begun on every engine, then collected
-        with :meth:`walk_queue_end` (``GPUPool(devices=[...])``).  One queue in flight per engine."""
+        with :meth:`walk_queue_end` (``GPUPool(devices=[...])``).  One queue in flight per engine.
+        ``records``: a float64 CUDA tensor on this engine's device with at least ``n`` rows of ``2 D + 3`` -- the records then STAY on the
+        device, packed ``u | v | logl | counts`` per row (``nmma_walk_queue::records_dev``; :func:`nmma_amd.parallel.unpack_records` reads them), instead
+        of being downloaded: the send buffer of a queue sharded over ranks (``parallel.ShardedQueue``); ``walk_queue_end`` returns None."""
         import torch
         live, u0 = _f64(live), _f64(u0)
         n, ndim = u0.shape
@@ -616,19 +619,27 @@ class EMEngine:
             ws = C.c_void_p()
             L.check(self._lib.nmma_walk_ws_create(self.device, C.byref(ws)), "nmma_walk_ws_create")
             self._walk_ws = ws
-        u, v = np.empty((n, ndim)), np.empty((n, ndim))
-        logl, counts = np.empty(n), np.empty((n, 4), dtype=np.int32)
+        if records is not None:
+            if (not isinstance(records, torch.Tensor) or not records.is_cuda or records.device.index != self.device or records.dtype != torch.float64
+                    or records.dim() != 2 or records.shape[1] != 2 * ndim + 3 or records.shape[0] < n or not records.is_contiguous()):
+                raise L.NMMAHipError(f"walk_queue: records must be a contiguous float64 tensor [>= {n}, {2 * ndim + 3}] on cuda:{self.device}")
+            outs = None
+        else:
+            outs = (np.empty((n, ndim)), np.empty((n, ndim)), np.empty(n), np.empty((n, 4), dtype=np.int32))
         q = L.WalkQueue()
         q.priors, q.ndim, q.walks = table, ndim, 0 if per_chain else int(walks)
         q.live, q.n_live, q.u0, q.loglstar, q.key = live.ctypes.data, live.shape[0], u0.ctypes.data, star.ctypes.data, keys.ctypes.data
         q.walks_per_chain = wl.ctypes.data if per_chain else None
         q.n, q.first_step = n, int(first_step)
         q.constraints = constraints.handle if constraints is not None else None
-        q.u, q.v, q.logl, q.counts = u.ctypes.data, v.ctypes.data, logl.ctypes.data, counts.ctypes.data
+        if outs is not None:
+            q.u, q.v, q.logl, q.counts = (a.ctypes.data for a in outs)
+        else:
+            q.records_dev = records.data_ptr()
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         L.check(self._lib.nmma_em_walk_queue_begin(self._handle, self._walk_ws, C.byref(q), C.c_void_p(s.cuda_stream)), "nmma_em_walk_queue_begin")
         # (everything the library reads until `end` stays referenced by the token)
-        return (q, (u, v, logl, counts), (table, live, u0, star, keys, wl, constraints, s))
+        return (q, outs, (table, live, u0, star, keys, wl, constraints, s, records))
 
     def walk_queue_end(self, token):
         q, outs, _keep = token

@@ -23,13 +23,23 @@ import numpy as np
 
 class GPUPool:
     def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None, priors=None, device=0, device_walk=True,
-                 devices=None):
+                 devices=None, group=None):
         """``devices``: several HIP devices driven from this one process (e.g. ``range(8)``) -- a queue of the device walk and a
         batch of ``log_likelihood`` calls are then SHARDED over them, contiguous balanced shards with the live set replicated, as
         the reference's task farm spreads a queue's chains over its MPI ranks (core/mpi_setup.py:651-667, :679-683); results come
-        back in queue order and are the single-device results bit for bit.  Default: the likelihood's own device only."""
+        back in queue order and are the single-device results bit for bit.  Default: the likelihood's own device only.
+        ``group``: one process per GPU instead (``torchrun``; ``True`` = the default ``torch.distributed`` group, or a group object):
+        EVERY rank runs the same sampler on the same seeds and calls ``map`` with the same queue; this rank walks / evaluates its
+        contiguous shard on its own device and the shards are exchanged with ONE all-gather per queue / batch (RCCL over xGMI:
+        ``parallel.ShardedQueue`` -- records packed on the device, one download -- and ``parallel.ShardedEvaluator``), so every rank
+        continues with the full result, bit-identical to the single-device run."""
         self.likelihood = likelihood
         self.devices = [int(d) for d in devices] if devices is not None else None
+        if group is not None and devices is not None:
+            raise ValueError("GPUPool: `devices` (one process, several GPUs) and `group` (one process per GPU) exclude each other")
+        self.group = group
+        self._rank_queue = None           # parallel.ShardedQueue over `group`, built on first use
+        self._rank_eval = None            # parallel.ShardedEvaluator over `group`
         self._shard_engines = None        # [(engine, constraint program)] per entry of `devices`, built on first use
         self._evaluator = None
         self.size = int(queue_size)
@@ -55,11 +65,8 @@ class GPUPool:
         return None
 
     def close(self):
-        if self._shard_engines:
-            for eng, _ in self._shard_engines[1:]:        # (the first one belongs to the likelihood)
-                eng.close()
-        self._shard_engines = None
-        self._evaluator = None
+        self._drop_shards()
+        self._rank_queue = self._rank_eval = None
         return None
 
     def __enter__(self):
@@ -80,7 +87,18 @@ class GPUPool:
         else:
             theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
         shards = self._walk_engines() if self.devices is not None and len(self.devices) > 1 else None
-        if shards and all(prog is None for _, prog in shards):
+        if self.group is not None:
+            # one process per GPU: this rank's row shard, then ONE all-gather of the logL shards (parallel.ShardedEvaluator)
+            if self._rank_eval is None:
+                from .parallel import ShardedEvaluator
+                self._rank_eval = ShardedEvaluator(lambda th: self.likelihood.log_likelihood_batch(th, self.names),
+                                                   group=None if self.group is True else self.group)
+            import torch
+            eng = self._walk_engine()[0] if self.names is not None else None
+            dev = eng.device if eng is not None else self.device
+            res = self._rank_eval.evaluate(torch.as_tensor(theta).to(f"cuda:{dev}"))      # (the shard is evaluated and exchanged on the device)
+            out = res.cpu().numpy() if hasattr(res, "cpu") else np.asarray(res)
+        elif shards and all(prog is None for _, prog in shards):
             # several devices: row shards launched asynchronously on every device, gathered on the first (no collective library)
             if self._evaluator is None:
                 from .parallel import MultiDeviceEvaluator
@@ -117,13 +135,24 @@ class GPUPool:
                 return None, None
         return eng, prog
 
+    def _drop_shards(self):
+        if self._shard_engines:
+            for e, _ in self._shard_engines[1:]:        # (the first one belongs to the likelihood)
+                e.close()
+        self._shard_engines = None
+        self._evaluator = None
+
     def _walk_engines(self):
         """One (engine, constraint program) per entry of ``devices`` (the likelihood's own engine first; further engines are copies
         of it on the other devices -- or on the same one, which is how the sharding is tested on a single GPU); None when the
         likelihood has no single-engine form."""
-        if self._shard_engines is not None:
-            return self._shard_engines
         eng, prog = self._walk_engine()
+        if self._shard_engines is not None:
+            # the likelihood rebuilds its engine when the sampled names or the detection limit change: copies made from the old one
+            # would keep its data -- results that differ between devices -- so they go with it
+            if eng is self._shard_engines[0][0] and prog is self._shard_engines[0][1]:
+                return self._shard_engines
+            self._drop_shards()
         if eng is None:
             return None
         lik, sub = self.likelihood, self.likelihood.sub_model
@@ -162,6 +191,13 @@ class GPUPool:
                         shards = self._walk_engines()
                         if shards is not None:
                             kw["engine"], kw["constraints"] = shards, None
+                    elif kw["engine"] is not None and self.group is not None:
+                        q = self._rank_queue
+                        if q is None or q.engine is not kw["engine"] or q.constraints is not kw["constraints"]:
+                            from .parallel import ShardedQueue
+                            q = self._rank_queue = ShardedQueue(engine=kw["engine"], constraints=kw["constraints"],
+                                                                group=None if self.group is True else self.group)
+                        kw["engine"], kw["constraints"] = q, None
                 res = walker.run_many_device(items, self._log_likelihood_device, self.priors, self.names, device=self.device,
                                              loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many, **kw)
                 self.n_batches += getattr(walker, "n_batches", 0)

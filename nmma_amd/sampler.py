@@ -614,21 +614,35 @@ class EnsembleWalkSampler(_LockstepWalk):
             # queue is then SHARDED over them (the reference spreads a queue's chains over its MPI ranks, core/mpi_setup.py:651-667,
             # :679-683): contiguous balanced shards, the live points replicated, every shard's call begun before the first is collected;
             # a chain's path depends on its key only, so the result is the single-device queue's, bit for bit
-            shards = list(engine) if isinstance(engine, (list, tuple)) else [(engine, constraints)]
-            if len(shards) == 1:
+            # or a ``parallel.ShardedQueue`` (one process per GPU: this rank walks its shard, ONE all-gather of the packed records)
+            from .parallel import ShardedQueue, shard_bounds
+            shards = [] if isinstance(engine, ShardedQueue) else list(engine) if isinstance(engine, (list, tuple)) else [(engine, constraints)]
+            if isinstance(engine, ShardedQueue):
+                u, v, logl, counts = engine.run(live, u0, loglstar, rseeds, steps, table=table)
+            elif len(shards) == 1:
                 u, v, logl, counts = shards[0][0].walk_queue(table, live, u0, loglstar, rseeds, steps, constraints=shards[0][1])
             else:
-                from .parallel import shard_bounds
                 u0 = np.ascontiguousarray(u0, dtype=float)
                 star = np.ascontiguousarray(np.broadcast_to(np.asarray(loglstar, dtype=float), (n,)))
                 keys_all = np.ascontiguousarray(rseeds, dtype=np.uint64)
-                begun = []
-                for r, (eng_r, con_r) in enumerate(shards):
-                    lo, hi = shard_bounds(n, len(shards), r)
-                    if hi > lo:
-                        st = steps if same else np.ascontiguousarray(steps[lo:hi])
-                        begun.append((eng_r, eng_r.walk_queue_begin(table, live, u0[lo:hi], star[lo:hi], keys_all[lo:hi], st, constraints=con_r)))
-                parts = [eng_r.walk_queue_end(tok) for eng_r, tok in begun]
+                begun, parts, failure = [], [], None
+                try:
+                    for r, (eng_r, con_r) in enumerate(shards):
+                        lo, hi = shard_bounds(n, len(shards), r)
+                        if hi > lo:
+                            st = steps if same else np.ascontiguousarray(steps[lo:hi])
+                            begun.append((eng_r, eng_r.walk_queue_begin(table, live, u0[lo:hi], star[lo:hi], keys_all[lo:hi], st, constraints=con_r)))
+                except Exception as exc:      # noqa: BLE001  (a shard that could not begin: the begun ones are still collected below)
+                    failure = exc
+                # every begun shard is collected whatever happened to the others: a workspace left "pending" would refuse every
+                # later queue on its engine
+                for eng_r, tok in begun:
+                    try:
+                        parts.append(eng_r.walk_queue_end(tok))
+                    except Exception as exc:      # noqa: BLE001
+                        failure = failure or exc
+                if failure is not None:
+                    raise failure
                 u, v, logl, counts = (np.concatenate([p[i] for p in parts]) for i in range(4))
             self.n_batches, self.n_evals = max(walks) + int(np.any(counts[:, 0] == 0)), int(counts[:, 3].sum())
         else:

@@ -194,3 +194,32 @@ def test_queue_sharded_over_engines_in_one_process():
             assert [b[2] for b in begins] == sizes
             first_end = next(i for i, e in enumerate(log) if e[0] == "end")
             assert all(e[0] == "begin" for e in log[:first_end]) and first_end == len(sizes)      # every shard begun before any is collected
+
+
+def test_record_packing_round_trips_bits():
+    """``pack_records`` / ``unpack_records`` (the layout of ``nmma_walk_queue::records_dev``): NaN payloads, infinities and the full
+    int32 range of the counters survive a byte-moving collective unchanged."""
+    from nmma_amd.parallel import pack_records, unpack_records
+    rng = np.random.default_rng(5)
+    n, d = 37, 6
+    u, v = rng.uniform(size=(n, d)), rng.normal(size=(n, d)) * 1e300
+    logl = rng.normal(size=n)
+    logl[3], logl[4] = np.nan, -np.inf
+    counts = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(n, 4)).astype(np.int32)
+    rows = pack_records(u, v, logl, counts)
+    assert rows.shape == (n, 2 * d + 3) and rows.dtype == np.float64
+    moved = np.frombuffer(rows.tobytes(), dtype=np.float64).reshape(rows.shape)       # (what a collective does: bytes)
+    gu, gv, gl, gc = unpack_records(moved, d)
+    assert np.array_equal(gu, u) and np.array_equal(gv, v) and np.array_equal(gl, logl, equal_nan=True) and np.array_equal(gc, counts)
+    assert gc.dtype == np.int32
+    eu, ev, el, ec = unpack_records(np.empty((0, 2 * d + 3)), d)
+    assert eu.shape == (0, d) and el.shape == (0,) and ec.shape == (0, 4)
+
+
+def test_sharded_queue_takes_either_a_function_or_an_engine():
+    import pytest
+    from nmma_amd.parallel import ShardedQueue
+    with pytest.raises(ValueError):
+        ShardedQueue()
+    with pytest.raises(ValueError):
+        ShardedQueue(local_fn=lambda *a: None, engine=object())
