@@ -45,6 +45,7 @@ struct nmma_em_handle {
     // run-time options (nmma_em_set_option; the environment variables of the same purpose are read ONCE, at nmma_em_create:
     // a getenv per launch raced with the host program's own environment writes)
     int walk_fuse = 1;              // "walk_fuse"  / NMMA_WALK_NO_FUSE : the MCMC step fused into the likelihood launch where an instantiation exists
+    int walk_lanes = 0;             // "walk_lanes" : 0 = 8 lanes per chain up to 8 sampled dimensions, 16 beyond; 16 = always 16 (measurement)
     int walk_split = 1;             // "walk_split" / NMMA_WALK_NO_SPLIT: small queues' fused launches split by band
     int lc_group = 0;               // "lc_group"   / NMMA_LC_GROUP, NMMA_LC_NO_GROUPS: lanes per sample of em_lc_loglike (0: by batch size; 16 / 32 / 64)
     int stack2_fixup = 1;           // "stack2_fixup" / NMMA_STACK2_NO_FIXUP: re-evaluation launches of nmma_em_loglike_stack2 (0: measurement only)

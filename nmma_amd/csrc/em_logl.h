@@ -1675,25 +1675,26 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 else if (kind == NMMA_SYS_NODES) fast_task(std::integral_constant<int, 2>{}, k, t);
                 else fast_task(std::integral_constant<int, 0>{}, k, t);
             } else {
-                const bool two = !(itab[k].identity != 0 && itab[k].same_grid != 0);       // uniform per item
+                // (round 6: no task is two-stage any more -- where sample_times differ from the SVD grid the handle's table holds rows ON
+                //  the sample grid with the stage-1 lerp folded in, nmma_em_create -- so every lean flavour reconstructs two rows per
+                //  datum; the TWO = true forms of the lambdas are no longer instantiated: half the inlined task variants per kernel)
                 const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || (FASTM == 5 && itab[k].kind == NMMA_SYS_NODES));
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
-                    if constexpr (FASTM == 4 || FASTM == 8) {          // an unequally spaced grid never coincides with the SVD grid: always two-stage
-                        if (sysp) lean_task(tb, T{}, T{}, T{}, k, t); else lean_task(tb, T{}, F{}, T{}, k, t);
+                    if constexpr (FASTM == 4 || FASTM == 8) {          // unequally spaced sample_times: bracket by lookup + bisection
+                        if (sysp) lean_task(tb, F{}, T{}, T{}, k, t); else lean_task(tb, F{}, F{}, T{}, k, t);
                     } else if constexpr (FASTM == 5) {
-                        if (!P.st_uniform) { if (sysp) lean_gen_task(tb, T{}, T{}, T{}, k, t); else lean_gen_task(tb, T{}, F{}, T{}, k, t); }
-                        else if (sysp) { if (two) lean_gen_task(tb, T{}, T{}, F{}, k, t); else lean_gen_task(tb, F{}, T{}, F{}, k, t); }
-                        else { if (two) lean_gen_task(tb, T{}, F{}, F{}, k, t); else lean_gen_task(tb, F{}, F{}, F{}, k, t); }
+                        if (!P.st_uniform) { if (sysp) lean_gen_task(tb, F{}, T{}, T{}, k, t); else lean_gen_task(tb, F{}, F{}, T{}, k, t); }
+                        else if (sysp) lean_gen_task(tb, F{}, T{}, F{}, k, t);
+                        else lean_gen_task(tb, F{}, F{}, F{}, k, t);
                     } else if constexpr (FASTM == 3 || FASTM == 7) {
-                        if (sysp) { if (two) lean_task(tb, T{}, T{}, F{}, k, t); else lean_task(tb, F{}, T{}, F{}, k, t); }
-                        else { if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t); }
+                        if (sysp) lean_task(tb, F{}, T{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     } else if constexpr (FASTM == 6) {   // dense: more than 16 points in every filter (host); any sample grid -- the
                         // stage-1 lerp lives in the A operands, an unequally spaced grid only changes how a datum finds its bracket
                         if (P.st_uniform) { if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t); }
                         else { if (sysp) lean_task(F{}, F{}, T{}, T{}, k, t); else lean_task(F{}, F{}, F{}, T{}, k, t); }
                     } else {
-                        if (two) lean_task(tb, T{}, F{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
+                        lean_task(tb, F{}, F{}, F{}, k, t);
                     }
                 };
                 if constexpr (FASTM == 6) run(std::false_type{});

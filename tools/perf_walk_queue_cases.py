@@ -31,6 +31,8 @@ for spec in (sys.argv[1].split(",") if len(sys.argv) > 1 else DEFAULT):
     name, _, flag = spec.partition("+")
     case = _per_filter_syserr_case() if name == "syserr_per_filter" else (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
     eng = engine_from_case(case)
+    if os.environ.get("NMMA_PERF_LANES"):          # (16: the fused step with 16 lanes per chain whatever the number of sampled dimensions)
+        eng.set_option("walk_lanes", int(os.environ["NMMA_PERF_LANES"]))
     names = case["names"]
     th = case["theta"]
     lo, hi = th.min(axis=0) - 1e-3, th.max(axis=0) + 1e-3
