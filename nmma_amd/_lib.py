@@ -13,13 +13,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMMA_HIP_LIB") or os.path.join(_HERE, "libnmma_hip.so")   # env: experiment builds
 SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
-#: translation units of the library; every other file under csrc/ and include/ is a dependency of both
 #: translation units of libnmma_hip.so, longest first (they compile concurrently; build_library caps the number in flight).  em_logl's
-#: 100 instantiations are spread over the em_logl_*.hip units, one or two task flavours each: as one unit they took 170 s;
-#: em_lc.hip holds the fourteen variants of the likelihood-from-curves kernel (inside em_kernels.hip they made it the critical path).
-SOURCES = ("em_logl_w5.hip", "em_logl_w3.hip", "em_logl_wc3.hip", "em_kernels.hip", "em_logl_w4.hip", "em_logl_w1.hip", "em_logl_wc1.hip", "em_logl_f5.hip",
-           "em_lc.hip", "em_logl_w2.hip", "em_logl_w6.hip", "em_logl_w7.hip", "em_logl_wc4.hip", "em_logl_f02.hip", "em_logl_wc2.hip", "em_logl_f7.hip",
-           "em_logl_f3.hip", "em_logl_f8.hip", "em_logl_f4.hip", "em_logl_f6.hip", "gw_kernels.hip", "em_logl_f1.hip", "walk_kernels.hip")
+#: 76 instantiations (round 5: 100) are spread over the em_logl_*.hip units, one or two task flavours each: as one unit round 4's 38
+#: took 170 s; em_lc.hip holds the fourteen variants of the likelihood-from-curves kernel (inside em_kernels.hip they made it the
+#: critical path).  Order = this machine's unit times, longest first (tools: _lib.UNIT_SECONDS after a forced build).
+SOURCES = ("em_kernels.hip", "em_lc64.hip", "em_lc.hip", "em_logl_w3.hip", "em_logl_w2.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_f5.hip", "em_logl_f02.hip",
+           "em_logl_w4.hip", "em_logl_wc2.hip", "em_logl_w5.hip", "em_logl_f8.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f7.hip",
+           "gw_kernels.hip", "em_logl_f1.hip", "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference
 #: arithmetic is third-party and absent) and lets hipcc fuse multiply-adds: a quarter fewer instructions in the bin loop.

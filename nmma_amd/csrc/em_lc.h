@@ -577,12 +577,16 @@ int launch_lc_loglike_sd(nmma_em_handle* h, const double* theta, int64_t B, int6
 
 // The variants that exist (launch_lc_loglike_as, em_api.inc): curves staged in LDS (SA) for every form; the unstaged fallback only for
 // one materialised set and a wave per sample; the 16- and 32-lane groups only with the photometry staged (SD).
-#define NMMA_LC_VARIANTS(X)                                                               \
+// (two translation units: em_lc.hip holds the sub-wave groups, em_lc64.hip the wave-per-sample forms -- as one unit they were the
+//  longest single compile of the library)
+#define NMMA_LC_VARIANTS_SUBWAVE(X)                                                       \
     X(16, 0, true, true) X(16, 1, true, true) X(16, 2, true, true)                        \
-    X(32, 0, true, true) X(32, 1, true, true) X(32, 2, true, true)                        \
+    X(32, 0, true, true) X(32, 1, true, true) X(32, 2, true, true)
+#define NMMA_LC_VARIANTS_WAVE(X)                                                          \
     X(64, 0, true, true) X(64, 1, true, true) X(64, 2, true, true)                        \
     X(64, 0, false, true) X(64, 1, false, true) X(64, 2, false, true)                     \
     X(64, 1, true, false) X(64, 1, false, false)
+#define NMMA_LC_VARIANTS(X) NMMA_LC_VARIANTS_SUBWAVE(X) NMMA_LC_VARIANTS_WAVE(X)
 #define NMMA_LC_SIGNATURE(G, NM, SD, SA)                                                                                                  \
     launch_lc_loglike_sd<G, NM, SD, SA>(nmma_em_handle*, const double*, int64_t, int64_t, const LcSets&, int, const unsigned char*, int, \
                                         int, double*, double*, double*, hipStream_t)

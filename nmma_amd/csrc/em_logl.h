@@ -1921,16 +1921,10 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 72);    \
     NMMA_LOGL_INSTANCE(1, 1, 8, FASTM, 80);    \
     NMMA_LOGL_INSTANCE(1, 2, 8, FASTM, 80)
-// (the same on 32-sample tiles: queues beyond one round of 16-sample tiles -- 4096 chains)
+// (32-sample tiles -- queues beyond one round of 16-sample tiles, 4096 chains: 16 lanes per chain only, no Constraint program, not the
+//  dense task; nmma_em_loglike_walk says why)
 #define NMMA_LOGL_WALK2(FASTM)                 \
-    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 8);     \
-    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 8);     \
     NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 16);    \
     NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 16)
-#define NMMA_LOGL_WALK2_CON(FASTM)             \
-    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 72);    \
-    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 72);    \
-    NMMA_LOGL_INSTANCE(2, 1, 8, FASTM, 80);    \
-    NMMA_LOGL_INSTANCE(2, 2, 8, FASTM, 80)
 
 }  // namespace nmma
