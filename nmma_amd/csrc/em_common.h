@@ -241,13 +241,14 @@ __device__ __forceinline__ void sync_signal(int* cnt, const int lane) {
 // epilogue then writes the floor for the whole tile instead of whatever the unfinished hand-off left behind.
 __shared__ int g_wd_trip;
 
+template <int SLEEP = NMMA_SYNC_SLEEP>
 __device__ __forceinline__ void sync_wait(int* cnt, const int target, int* watchdog_generic = nullptr, const int code = 0) {
     g_ip watchdog = (g_ip)(uintptr_t)watchdog_generic;
     // Every VALU instruction of a polling wave takes an issue slot from the MFMA waves of its SIMD (a poll is
     // v_mov + ds_read + v_cmp): sleep ~400 cycles between polls so that waiting costs next to nothing.
     int spins = 0;
     while (__hip_atomic_load((lds_ip)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-        __builtin_amdgcn_s_sleep(NMMA_SYNC_SLEEP);
+        __builtin_amdgcn_s_sleep(SLEEP);
         if (++spins > (1 << 18)) {
             if ((threadIdx.x & 63) == 0) g_wd_trip = 1;
             if (watchdog_generic != nullptr && (threadIdx.x & 63) == 0) {

@@ -277,8 +277,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 const int nd = P.n_data;
                 if constexpr (!EXT) {      // lean task: one {t, m, 1/sigma, ln sigma} record per datum
                     if (LEANX && P.dat_in_tab) {      // item-staged photometry: the epochs only, the records come with the item's rows
-                        gcf64p sdt = as_global(P.dt);
-                        for (int j = cvt; j < nd; j += cnv) dat[j] = sdt[j];
+                        if constexpr (!DENSE) {       // (the dense task reads the epochs from the records too: nothing staged here)
+                            gcf64p sdt = as_global(P.dt);
+                            for (int j = cvt; j < nd; j += cnv) dat[j] = sdt[j];
+                        }
                     } else {
                         gcf64p src4 = as_global(P.dat4);
                         for (int j = cvt; j < 4 * nd; j += cnv) dat[j] = src4[j];
@@ -298,9 +300,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             double* dst = reinterpret_cast<double*>(smem + L.nodes);
             for (int j = cvt; j < STACK2_NINT * STACK2_ROW; j += cnv) dst[j] = kStack2Tab[j];
         }
-        if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4 || FASTM == 5) {       // log Phi for upper limits / detections under a finite limit (logphi_tab.h)
+        if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4 || FASTM == 5 || FASTM == 6) {       // log Phi for upper limits / detections under a finite limit (logphi_tab.h)
             if (P.mass_tab) {
-                double* dst = reinterpret_cast<double*>(smem + L.nodes);
+                // (the dense task keeps it behind its node buffers)
+                double* dst = reinterpret_cast<double*>(smem + L.nodes) + (DENSE ? DENSE_NBUF * ((NS + 15) & ~15) * DENSE_STRIDE : 0);
                 for (int j = cvt; j < LOGPHI_NINT * LOGPHI_ROW; j += cnv) dst[j] = kLogPhiTab[j];
             }
         }
@@ -1571,6 +1574,225 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         for (int kk = k0; kk <= k; ++kk) sync_signal(sync + W + 2 + kk, lane);     // one signal per task and source item
     };
 
+    // ---------------------------------------------------------------------------------
+    // dense_task (FASTM == 6; round 6 -- before, a variant of lean_task): every filter has so many points that reconstructing ALL nodes of
+    // (item, 16 samples) beats two basis rows per datum (config 4: 12 filters x 200 points).  The four tasks of a UNIT (item k, 16 samples) -- four
+    // samples x 16 lanes each -- share:
+    //   * app[node][sample] = (VA[node, :] o span) . c[sample, :] + mins[node] + offset[sample] -- offset = extinction of the item's
+    //     filter + distance modulus + K-correction (model.py:390-397) -- on the fp64 matrix cores, 16 nodes x 16 samples per
+    //     v_mfma_f64_16x16x4_f64 with K = NC + 2 in three steps (A operands: EmDev::dva, rows on the SAMPLE grid with the stage-1 lerp
+    //     folded in, pre-swizzled at create; its column of ones multiplies the sample's offset), into one of DENSE_NBUF LDS buffers;
+    //   * the datum loop, lane = (sample lane % 16, data slice lane / 16): what is left per datum is the interpolation and the term
+    //     themselves, written for the issue port the task shares with the surrogate's f32 MFMA stream (~18 vector instructions):
+    //       u = t c1 + c0 (the datum's position on the sample's observer-frame grid in node units: one FMA on per-sample constants),
+    //       lo = clamp(int(u)), frac = u - lo, the two node magnitudes (one LDS read of two), est = y0 + (y1 - y0) frac,
+    //       x = (m - est) / sigma, term = -x^2 / 2 + k with k = -(ln sqrt(2 pi) + ln sigma) from the record;
+    //     the window test of np.interp(left = right = inf) -> NaN (em_likelihood.py:252-256) accumulates in a mask, the records are
+    //     padded to whole passes (no per-slot validity), upper limits sit behind the detections and are evaluated after the loop.
+    // Round 5's form (four tasks of 4 samples x 16 lanes per unit, each building the unit's B operands and a quarter of its node tiles)
+    // spent more vector instructions on a task's set-up than on its data (profiles/r06_c4.md).
+    // Deviation from the reference's association order (est from the fraction instead of slope x (t - x0), the offset added inside the
+    // matrix product): a few ulp of a magnitude, DEVIATIONS.md; unequally spaced grids take the bracket search and the exact node times.
+    // ---------------------------------------------------------------------------------
+    auto dense_task = [&](auto sys_tag, auto nonuni_tag, const int k, const int c) {
+        constexpr bool SYS = decltype(sys_tag)::value;           // a sampled em_syserr: sigma_tot per (datum, sample)
+        constexpr bool NONUNI = decltype(nonuni_tag)::value;     // unequally spaced sample_times: lookup + bisection, node times from the table
+        const ItemDesc& it = itab[k];
+        const int o = it.o;
+        typedef __attribute__((address_space(3))) unsigned char* lds_bp;
+        typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
+        typedef const __attribute__((address_space(3))) double* lds_cdp;
+        typedef const __attribute__((address_space(3))) float* lds_cfp;
+        typedef __attribute__((address_space(3))) double* lds_dp;
+        typedef __attribute__((ext_vector_type(2))) double f64x2;
+        typedef const __attribute__((address_space(3))) f64x2* lds_c2p;
+        if (c == 0) {      // this wave stages the item's [b2 | records] (LDS-DMA, no registers)
+            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), itab[k - NBUF].ntask[R - 1], P.watchdog, 800 + k);
+            gbyte_p src = (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes + P.tab_off_b2);
+            lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
+            for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
+                __builtin_amdgcn_global_load_lds(src + q * 1024 + lane * 16, dst + q * 1024, 16, 0, 0);
+        }
+        const lds_cfp pbuf = (lds_cfp)(part + (k % NBUF) * (NSLICE * TS * PSTR));
+        const int jlo = __builtin_amdgcn_readfirstlane(it.jlo), jhi = __builtin_amdgcn_readfirstlane(it.jhi);
+        const int ndet = __builtin_amdgcn_readfirstlane(it.pad_i), nul = __builtin_amdgcn_readfirstlane(it.has_ul);
+        const int g = lane >> 4, gi = lane & 15;
+        const int s = 4 * c + g;                       // this lane group's sample
+        const lds_cdp stl_l = (lds_cdp)stl;
+        // the A operands of this task's node tiles, requested before the waits for the surrogate and the node buffer
+        const int dn_tt = (NS + 15) >> 4;              // node tiles of the sample grid (<= 16: four per task, checked at create)
+        double dav[4][3];
+        {
+            gcf64p dva = as_global(P.dva) + (size_t)it.m * dn_tt * 3 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (c & 3) + 4 * q;
+#pragma unroll
+                for (int step = 0; step < 3; ++step) dav[q][step] = tt < dn_tt ? dva[(tt * 3 + step) * 64] : 0.0;
+            }
+        }
+        // per-sample constants of the datum loop
+        const lds_cdp sc = (lds_cdp)(scal + s * 8);
+        const double zp1 = sc[S_ZP1], tsh = sc[S_TS], izp1 = sc[S_IZP1];
+        const double t_lo = stl_l[jlo] * zp1 + tsh, t_hi = stl_l[jhi] * zp1 + tsh;
+        const double c1 = izp1 * P.st_inv_dt, c0 = -((tsh * izp1 + P.st0) * P.st_inv_dt);
+        const int nbis = NONUNI ? __builtin_amdgcn_readfirstlane(P.bg_nbis) : 0;
+        const double bg_inv_h = NONUNI ? P.bg_inv_h : 0.0, st0 = P.st0;
+        if (c == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sync_signal(sync + 2 * W + 4 + k, lane);     // [b2 | records] of item k staged
+        }
+        sync_wait(sync + 2 * W + 4 + k, 1, P.watchdog, 350 + k);
+#ifndef NMMA_DENSE_SLEEP
+#define NMMA_DENSE_SLEEP NMMA_SYNC_SLEEP
+#endif
+        sync_wait<NMMA_DENSE_SLEEP>(sync + k, NMW, P.watchdog, 300 + k);   // coefficients of item k published
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
+        const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
+        const lds_cfp b2l = (lds_cfp)tbl;
+        const int hh = c >> 2;                                 // tasks 4 hh .. 4 hh + 3 share the 16 samples of half hh
+        const int unit = R * k + hh;
+        int* const unit_prod = sync + 3 * W + 4 + unit;
+        int* const unit_done = sync + 3 * W + 4 + R * W + unit;
+        const int nrows = (NS + 15) & ~15;
+        const lds_dp nb = (lds_dp)(smem + L.nodes) + (unit % DENSE_NBUF) * (nrows * DENSE_STRIDE);
+        {
+            // B operands: coefficient 4 step + lane / 16 of sample 16 hh + lane % 16 (slice sums in the fixed order, + b2, as fp64);
+            // "coefficient" NC is the constant 1 that multiplies mins, NC + 1 the sample's offset that multiplies the column of ones
+            const int sj = 16 * hh + (lane & 15), kq = lane >> 4;
+            const lds_cdp scj = (lds_cdp)(scal + sj * 8);
+            const double off = ((lds_cdp)(smem + L.exttab))[(P.has_ebv ? k : 0) * TS + sj] + (scj[S_DMOD] + scj[S_RC]);
+            double bq[3];
+#pragma unroll
+            for (int step = 0; step < 3; ++step) {
+                const int kc = 4 * step + kq;
+                const lds_cfp pp = pbuf + ((sj >> 4) * 16 + (sj & 15)) * PSTR + (kc < 16 ? kc : 0);
+                float cm = pp[0];
+#pragma unroll
+                for (int w = 1; w < NSLICE; ++w) cm += pp[w * (R * 16 * PSTR)];
+                cm += b2l[kc < 16 ? kc : 0];
+                bq[step] = kc < NC ? (double)cm : (kc == NC ? 1.0 : (kc == NC + 1 ? off : 0.0));
+            }
+            // the buffer's previous unit has been consumed by all four of its tasks
+            if (unit >= DENSE_NBUF) sync_wait(unit_done - DENSE_NBUF, 4, P.watchdog, 360 + k);
+            typedef double f64x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (c & 3) + 4 * q;                  // this task's node tiles (uniform)
+                if (tt >= dn_tt) break;
+                f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int step = 0; step < 3; ++step) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dav[q][step], bq[step], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nb[(16 * tt + 4 * r + kq) * DENSE_STRIDE + (lane & 15)] = acc[r];
+            }
+            sync_signal(unit_prod, lane);
+            sync_wait(unit_prod, 4, P.watchdog, 370 + k);        // all node tiles of the unit are in LDS
+        }
+        // ---- the datum loop: detections in passes of 32 (two slots per lane), then the upper limits
+        const lds_c2p recs = (lds_c2p)(tbl + P.tab_off_dat - P.tab_off_b2);
+        const lds_cdp ncol = (lds_cdp)nb + (s & 15);
+        const double e_sys = SYS ? ((lds_cdp)(smem + L.epar))[__builtin_amdgcn_readfirstlane(P.sys_off[o]) * TS + s] : 0.0;
+        // a datum's bracket on the sample's observer-frame grid and its position inside it
+        auto bracket = [&](const double t, int& lo, double& frac) {
+            if constexpr (NONUNI) {
+                typedef const __attribute__((address_space(3))) int* lds_cip_bg;
+                const lds_cip_bg bgl = (lds_cip_bg)(stl_l + 2 * NS);
+                int cq = (int)(((t - tsh) * izp1 - st0) * bg_inv_h);
+                cq = cq < 0 ? 0 : (cq > BG_CELLS - 1 ? BG_CELLS - 1 : cq);
+                lo = bgl[cq] - 1;
+                int hi = bgl[cq + 1] + 2;
+                lo = lo < jlo ? jlo : lo;
+                hi = hi > jhi ? jhi : hi;
+                for (int itb = 0; itb < nbis; ++itb) {         // uniform trip count
+                    const int mid = (lo + hi) >> 1;
+                    const bool le = (stl_l[mid] * zp1 + tsh) <= t;
+                    lo = le ? mid : lo;
+                    hi = le ? hi : mid;
+                }
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+                frac = (t - (stl_l[lo] * zp1 + tsh)) * (izp1 * stl_l[NS + lo]);
+            } else {
+                const double u = fma(t, c1, c0);
+                lo = (int)u;                                    // (truncation = floor where it matters: a negative u is clamped anyway)
+                lo = lo > jhi - 1 ? jhi - 1 : lo;
+                lo = lo < jlo ? jlo : lo;
+                frac = u - (double)lo;
+            }
+        };
+        double vacc0 = 0.0, vacc1 = 0.0;
+        bool outside = false;
+        const int npad = (ndet + 31) & ~31;
+#pragma unroll 1
+        for (int d0_ = 0; d0_ < npad; d0_ += 32) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int dd = d0_ + gi + 16 * u;
+                const f64x2 tm = recs[2 * dd], sk = recs[2 * dd + 1];       // {t, m}, {1 / sigma, k} (sampled: {sigma_data, 0})
+                int lo;
+                double frac;
+                bracket(tm[0], lo, frac);
+                const lds_cdp nd = ncol + lo * DENSE_STRIDE;
+                const double y0 = nd[0], y1 = nd[DENSE_STRIDE];
+                const double est = fma(y1 - y0, frac, y0);
+                outside = outside | !((tm[0] >= t_lo) & (tm[0] <= t_hi));
+                double v;
+                if constexpr (SYS) {
+                    // 1 / sigma_tot and ln sigma_tot per (datum, sample): rsqrt_pos / log_pos (em_common.h)
+                    const double s2 = sk[0] * sk[0] + e_sys * e_sys;
+                    const double rs = rsqrt_pos(s2);
+                    const double lsig = log_pos(s2 * rs);
+                    const double x = (tm[1] - est) * rs;
+                    v = fma(x * -0.5, x, -kNormPdfLogC) - lsig;
+                    v = (s2 > 0.0) ? v : dnan();                 // (sigma_tot = 0, or a NaN systematic: scipy's NaN)
+                    v = dd < ndet ? v : 0.0;
+                } else {
+                    const double x = (tm[1] - est) * sk[0];
+                    v = fma(x * -0.5, x, sk[1]);
+                }
+                if (u == 0) vacc0 += v; else vacc1 += v;
+            }
+        }
+        double vacc = vacc0 + vacc1;
+        vacc = outside ? dnan() : vacc;
+        double gacc = 0.0;
+        if (nul) {                                               // uniform; the term itself only on the lanes that hold a limit
+            const lds_cdp ptab = (lds_cdp)(smem + L.nodes) + DENSE_NBUF * nrows * DENSE_STRIDE;
+            for (int q0 = 0; q0 < nul; q0 += 16) {
+                const int dd = q0 + gi;
+                if (dd < nul) {
+                    const f64x2 tm = recs[2 * (npad + dd)], sk = recs[2 * (npad + dd) + 1];      // {t, m}, {sigma_sys, 0}
+                    int lo;
+                    double frac;
+                    bracket(tm[0], lo, frac);
+                    const lds_cdp nd = ncol + lo * DENSE_STRIDE;
+                    const double y0 = nd[0], y1 = nd[DENSE_STRIDE];
+                    const bool in = (tm[0] >= t_lo) & (tm[0] <= t_hi);
+                    const double est = in ? fma(y1 - y0, frac, y0) : dinf();
+                    const double e = SYS ? e_sys : sk[0];
+                    gacc += P.mass_tab ? upper_limit_term_tab(tm[1], est, e, ptab) : upper_limit_term(tm[1], est, e);
+                }
+            }
+        }
+        const double chi = group_sum(vacc, 16);
+        double gp = 0.0;
+        if (nul) gp = group_sum(gacc, 16);
+        if (gi == 0) {
+            lds_dp chi_l = (lds_dp)chi_tot;
+            lds_dp gp_l = (lds_dp)gp_tot;
+            chi_l[o * TS + s] = chi;
+            gp_l[o * TS + s] = gp;
+            if (chi != chi) bad[s] = 1;
+            if (chi_parts != nullptr && tile0 + s < B) {
+                chi_parts[(long)o * B + tile0 + s] = sample_bad(s) ? dnan() : chi;
+                gp_parts[(long)o * B + tile0 + s] = gp;
+            }
+        }
+        if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
+        sync_signal(unit_done, lane);            // this task no longer reads the unit's node buffer
+        sync_signal(sync + W + 2 + k, lane);     // one signal per task
+    };
+
     if constexpr (FAST) {
         sync_wait(sync + W + 1, NVW, P.watchdog, 400);   // prologue data of every likelihood wave in LDS
         if constexpr (WALKF) {
@@ -1691,8 +1913,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         if (sysp) lean_task(tb, F{}, T{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     } else if constexpr (FASTM == 6) {   // dense: more than 16 points in every filter (host); any sample grid -- the
                         // stage-1 lerp lives in the A operands, an unequally spaced grid only changes how a datum finds its bracket
-                        if (P.st_uniform) { if (sysp) lean_task(F{}, F{}, T{}, F{}, k, t); else lean_task(F{}, F{}, F{}, F{}, k, t); }
-                        else { if (sysp) lean_task(F{}, F{}, T{}, T{}, k, t); else lean_task(F{}, F{}, F{}, T{}, k, t); }
+                        if (P.st_uniform) { if (sysp) dense_task(T{}, F{}, k, t); else dense_task(F{}, F{}, k, t); }
+                        else { if (sysp) dense_task(T{}, T{}, k, t); else dense_task(F{}, T{}, k, t); }
                     } else {
                         lean_task(tb, F{}, F{}, F{}, k, t);
                     }
@@ -1840,8 +2062,8 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     constexpr int LOGL_THREADS = logl_threads(NMW, NVW);
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
-                                   (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dat_in_tab ? 8 : 32,
-                                   P.dense ? ((P.NT + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
+                                   (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dense ? 0 : (P.dat_in_tab ? 8 : 32),
+                                   P.dense ? ((P.NS + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5 || FAST == 6) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
                                    ((WALKF & 31) == 16 || (WALKF != 0 && R == 2)) ? (WALKF & 31) : 0);
     const int TS = 16 * R;
     g_launch_note.clear();

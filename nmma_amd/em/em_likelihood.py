@@ -147,7 +147,8 @@ class MultiFilterTransient:
                 th = th.to(f"cuda:{eng2.device}", dtype=torch.float64)
                 lc2, failed = model.second_operand(th, eng2.parameter_names, external_lc)
                 other = model.stack2_plan()[1]
-                out = eng2.loglike_stack2(th, lc2, failed, gap_free=bool(getattr(other, "gap_free", False) or getattr(other, "batch_gap_free", False)))
+                out = eng2.loglike_stack2(th, lc2, failed, gap_free=bool(getattr(other, "batch_gap_free", False) if getattr(other, "batch_checked", False)
+                                                                        else getattr(other, "gap_free", False)))
                 if out is None:                             # (the handle has no one-launch form: decided once per likelihood)
                     self._stack2_off = True
                     self._engine2.close()

@@ -285,6 +285,10 @@ def _is_number(v):
         return False
 
 
+#: model names the reference's factory resolves to classes that are not surrogates (model.py:1572-1579); ``Me2017`` is built here
+HOST_ONLY_MODELS = ("TrPi2018", "Piro2021", "PL_BB_fixedT", "Sr2023", "Arnett")
+
+
 def create_light_curve_model_from_args(em_transient, args, filters=None, sample_times=None, host_models=None):
     """Factory with the reference's shape (model.py:1617-1668, :1591-1614): ``em_transient`` is a model name or a comma-separated
     list / list of names; EVERY sub-model gets the same ``filters`` and ``sample_times = setup_sample_times(args)`` (which is what
@@ -296,9 +300,18 @@ def create_light_curve_model_from_args(em_transient, args, filters=None, sample_
     from . import utils
     names = em_transient.split(",") if isinstance(em_transient, str) else list(em_transient)
     names = [n.strip() for n in names]
+    if filters is None:
+        filters = utils.set_filters(args)          # (model.py:1618-1619: --filters / --em-detectors)
     if sample_times is None:
         sample_times = utils.setup_sample_times(args)
     host_models = host_models or {}
+    # names the reference maps to models whose arithmetic is third-party or not built here (model.py:1572-1586: afterglowpy, the
+    # shock-cooling / host-galaxy / bolometric / power-law black-body models): they need the host object -- falling through to the SVD
+    # surrogate would fail later with an unrelated missing-file error
+    missing = [n for n in names if n in HOST_ONLY_MODELS and n not in host_models]
+    if missing:
+        raise ValueError(f"model(s) {missing} are evaluated on the host: pass host_models={{name: model}} -- an object with the reference's "
+                         "generate_lightcurve(sample_times, parameters) and model_parameters -- the likelihood then takes their curves as an operand")
     law = getattr(args, "em_extinction_law", None)
     models = []
     for name in names:
@@ -429,6 +442,7 @@ class ExternalLightCurveModel(_TensorModelMixin, LightCurveModelContainer):
         self.generator = generate_lightcurve
         self.batch_generator = generate_lightcurve_batch
         self.batch_gap_free = False       # set per batch by CombinedLightCurveModelContainer.host_operands
+        self.batch_checked = False        # ... which has then LOOKED at the batch's curves: its finding stands in for `gap_free`
 
     def generate_lightcurve(self, sample_times, parameters):
         """model.py:405-408: the model's source-frame light curve for one parameter dict (the supplied callable's)."""
@@ -561,13 +575,16 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         for m in self.lc_models:
             if not isinstance(m, ExternalLightCurveModel):
                 continue
-            m.batch_gap_free = False
+            m.batch_gap_free = m.batch_checked = False
             if m.model not in out and (m.generator is not None or m.batch_generator is not None):
                 th = theta.detach().cpu().numpy() if hasattr(theta, "detach") else np.asarray(theta)
                 lc, ok = m.generate_batch(th, names, fixed, self.parameter_conversion)
                 # (the curves are in host memory anyway: whether any delivered row has a non-finite node strictly inside the grid is
                 #  one pass over them -- without one, the one-launch likelihood needs no re-evaluation launch for this batch)
+                # (and it REPLACES a constructor promise `gap_free=True` for this batch: a filter the generator does not return is +inf
+                #  on every node -- a legal "no flux" outcome that a blanket promise would turn into a poisoned handle)
                 m.batch_gap_free = bool(np.isfinite(lc[ok][:, :, 1:-1]).all())
+                m.batch_checked = True
                 out[m.model] = (lc, ok)
         return out
 

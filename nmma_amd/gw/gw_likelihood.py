@@ -407,6 +407,10 @@ class GravitationalWaveTransient:
                         warnings.warn("jitter_time with a non-uniform geocent_time prior: the device path cannot evaluate the time prior per "
                                       "sample; continuing with jitter_time=False (a fixed time grid)", RuntimeWarning, stacklevel=2)
                         self.jitter_time, self._time_bounds = False, None
+                        # (on record: a result file's meta data then says that this run differs from bilby's configuration)
+                        self.deviations_from_reference = getattr(self, "deviations_from_reference", []) + [
+                            "jitter_time=True requested with a non-uniform geocent_time prior: run with jitter_time=False (no time_jitter prior)"]
+                        self.meta_data = dict(getattr(self, "meta_data", None) or {}, deviations_from_reference=list(self.deviations_from_reference))
                 if self.jitter_time and "time_jitter" not in priors:
                     # bilby/gw/likelihood/base.py: priors['time_jitter'] = Uniform(-delta_tc / 2, delta_tc / 2)
                     half = 0.5 * float(ifo.strain_data.duration) / (len(ifo.frequency_array) - 1)
