@@ -128,7 +128,8 @@ struct EmDev {
     // so that the lean tasks bisect bg_nbis times (3 for the CLI's 150 log-spaced nodes) instead of ceil(log2 NS) = 8.
     const int32_t* bguess;
     double bg_inv_h;
-    int32_t bg_nbis, pad_bg;
+    int32_t bg_nbis;
+    int32_t mass_tab2;        // combined-model flavour (em_logl<.., 7 | 8>): log Phi for its upper limits from the table it keeps behind the flux-sum table
     int32_t lean_gen, mass_tab;       // (mass_tab: a band has a finite detection limit -- the general lean task reads log Phi from the table it keeps in LDS at LdsW::nodes, logphi_tab.h)  general lean task (averaged bands: several source filters per observed filter; time-node systematics): em_logl<.., 5>
     // Pei-1992 extinction of the lean task without the pre-pass launch: per model filter [z_mid, 1 / z_half, c_0 .. c_13] -- Chebyshev
     // coefficients of the extinction magnitude PER UNIT E(B-V) over the handle's redshift range (nmma_em_create: built and verified

@@ -299,6 +299,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         if constexpr (COMB) {       // the two-model flux-sum table (stack2_tab.h): every lane gathers its own row from LDS
             double* dst = reinterpret_cast<double*>(smem + L.nodes);
             for (int j = cvt; j < STACK2_NINT * STACK2_ROW; j += cnv) dst[j] = kStack2Tab[j];
+            if (P.mass_tab2) {      // ... and log Phi for the upper limits behind it (logphi_tab.h)
+                double* dst2 = reinterpret_cast<double*>(smem + L.nodes + STACK2_LDS_BYTES);
+                for (int j = cvt; j < LOGPHI_NINT * LOGPHI_ROW; j += cnv) dst2[j] = kLogPhiTab[j];
+            }
         }
         if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4 || FASTM == 5 || FASTM == 6) {       // log Phi for upper limits / detections under a finite limit (logphi_tab.h)
             if (P.mass_tab) {
@@ -1179,6 +1183,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (ul_[u]) {
                     if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4) {
                         if (P.mass_tab) gp_[u] = upper_limit_term_tab(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const, (lds_cdp)(smem + L.nodes));
+                        else gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const);
+                    } else if constexpr (COMB) {
+                        if (P.mass_tab2) gp_[u] = upper_limit_term_tab(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const, (lds_cdp)(smem + L.nodes + STACK2_LDS_BYTES));
                         else gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const);
                     } else {
                         gp_[u] = upper_limit_term(m_[u], inside_[u] ? est_[u] : dinf(), SYS ? esys_[u] : it.e_const);
@@ -2063,7 +2070,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
                                    (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dense ? 0 : (P.dat_in_tab ? 8 : 32),
-                                   P.dense ? ((P.NS + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5 || FAST == 6) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
+                                   P.dense ? ((P.NS + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES + (P.mass_tab2 ? LOGPHI_LDS_BYTES : 0) : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5 || FAST == 6) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
                                    ((WALKF & 31) == 16 || (WALKF != 0 && R == 2)) ? (WALKF & 31) : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
