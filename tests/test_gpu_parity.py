@@ -5,6 +5,8 @@ Tolerance (BASELINE.json north_star): 1e-6 relative on fp64 logL magnitudes.  Th
 surrogate MLP is fp32 in the reference (Keras) -- its summation order is not
 reproducible, so coefficients are compared at fp32-rounding level (stated below).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -740,6 +742,63 @@ def test_dense_lean_task_with_extinction_and_sampled_systematic(grid, ext, torch
     assert np.array_equal(got == FLOOR, floor) and np.array_equal(rows == FLOOR, floor) and (~floor).sum() > 30
     assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
     assert rel_err(got[~floor], rows[~floor]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("sampled_sys", [False, True])
+@pytest.mark.parametrize("grid", ["svd", "cli", "log"])
+def test_dense_task_edge_cases_against_the_oracle(grid, sampled_sys, torch_cuda):
+    """The dense task's datum loop (round 6: padded detection records, upper limits behind them, the window test as a mask) where
+    its bookkeeping can go wrong: a band with more upper limits than one pass of lanes holds (21), bands whose detection count is
+    and is not a multiple of the pass (64, 47), a band that is ALL upper limits but one pair, detections pushed outside the model
+    window by the time shift (floor), upper limits outside the window (log sf(-inf) = 0: no floor), a NaN and a zero systematic
+    (floor), a non-finite model parameter (floor) -- all against the oracle."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"] + (["em_syserr"] if sampled_sys else [])
+    case = cases._base(seed=9771, filters=["g", "r", "i", "z", "y"], counts=dict(g=64, r=47, i=85, z=40, y=33), batch=64, names=names,
+                       upper_limit_filter="i")
+    if sampled_sys:
+        case["systematics"] = dict(mode="param", name="em_syserr")
+        case["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    times, mags, sig = (dict(d) for d in case["data"])
+    sig = {f: np.array(v, dtype=float) for f, v in sig.items()}
+    sig["i"][::4] = np.inf                                   # 22 upper limits in one band (one was there already)
+    sig["y"][2:] = np.inf                                    # two detections, 31 upper limits
+    case["data"] = (times, mags, sig)
+    if grid == "cli":
+        case["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    elif grid == "log":
+        case["sample_times"] = np.geomspace(0.2, 20.0, 150)
+    th = case["theta"]
+    ts = names.index("timeshift")
+    th[3, ts] = 30.0                                         # every epoch before the window: detections -> NaN -> floor
+    th[4, ts] = -25.0                                        # ... behind it
+    th[5, names.index("log10_mej_dyn")] = np.nan
+    if sampled_sys:
+        th[6, names.index("em_syserr")] = np.nan
+        th[7, names.index("em_syserr")] = 0.0                # sigma_tot = sigma_data: fine (all sigma_data > 0)
+    os.environ["NMMA_EM_DENSE_PCT"] = "1"                    # (engage the dense task whatever the row count)
+    try:
+        eng = engine_from_case(case)
+        got = eng.loglike(torch.as_tensor(th, device="cuda:0")).cpu().numpy()
+        eng.check()
+        geom = eng.last_launch_geometry()
+        os.environ["NMMA_EM_NO_DENSE"] = "1"
+        rows_eng = engine_from_case(case)
+        rows = rows_eng.loglike(torch.as_tensor(th, device="cuda:0")).cpu().numpy()
+        assert rows_eng.last_launch_geometry()["lds_bytes"] != geom["lds_bytes"], "dense task not engaged"
+        rows_eng.close()
+    finally:
+        os.environ.pop("NMMA_EM_DENSE_PCT", None)
+        os.environ.pop("NMMA_EM_NO_DENSE", None)
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), names, th)
+    floor = want == FLOOR
+    assert floor[3] and floor[4] and floor[5] and (~floor).sum() > 40
+    assert np.array_equal(got == FLOOR, floor) and np.array_equal(rows == FLOOR, floor)
+    assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+    for n in (1, 17, 33):                                    # batch-size independence (tile geometry, band split)
+        assert np.array_equal(eng.loglike(torch.as_tensor(th[:n], device="cuda:0")).cpu().numpy(), got[:n]), n
+    eng.close()
 
 
 @pytest.mark.parametrize("flavour", ["general_lean", "extended", "generic"])
