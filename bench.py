@@ -514,13 +514,13 @@ def device_walk_queue_sharded(eng, case, syn, dist, world, rank, dev, share_gpu,
         res = queue.run(live, live, bound, keys, walks)                         # (warm-up: workspace, buffers, communicator)
         a, b = shard_bounds(n, world, rank)
         t_queue = timed(lambda: queue.run(live, live, bound, keys, walks))
-        walk_ms, exch_ms = queue.last_gpu_ms, queue.last_exchange_ms
+        walk_ms, exch_ms = queue.last_gpu_ms, queue.last_collect_ms
         # the rank's shard alone, records downloaded instead of exchanged (what one GPU does with its share of the queue)
         t_local = timed(lambda: eng.walk_queue(table, live, live[a:b], bound, keys[a:b], walks)) if b > a else 0.0
         u, v, logl, counts = res
         assert u.shape == (n, ndim) and np.all(np.isfinite(logl)) and int(counts[:, 3].sum()) > 0
         out[mode] = {"chains": n, "chains_per_rank": b - a, "walks": walks, "queue_ms": 1e3 * t_queue, "evals_per_s": n * walks / t_queue,
-                     "rank0_walk_gpu_ms": walk_ms, "rank0_exchange_ms": exch_ms, "rank_shard_alone_ms": 1e3 * t_local,
+                     "rank0_walk_gpu_ms": walk_ms, "rank0_wait_exchange_download_ms": exch_ms, "rank_shard_alone_ms": 1e3 * t_local,
                      "record_bytes_per_rank": (-(-n // world)) * (2 * ndim + 3) * 8}
     # the collective by itself: the weak-mode send buffer, all-gathered back to back
     slot, width = per_rank, 2 * ndim + 3

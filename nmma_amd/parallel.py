@@ -114,7 +114,7 @@ class ShardedQueue:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._bufs = {}               # (slot, width) -> (send, gathered) device buffers, reused from queue to queue
         self.last_gpu_ms = 0.0        # the rank's own walk, HIP events (engine form)
-        self.last_exchange_ms = 0.0   # host wall time of all-gather + download (engine form)
+        self.last_collect_ms = 0.0    # host wall time from `begin` returning to the records on the host: rest of the walk + all-gather + download
 
     def _backend(self):
         return self.dist.get_backend(self.group) if self.dist.is_initialized() else None
@@ -156,7 +156,7 @@ class ShardedQueue:
                     else:                                 # RCCL: same stream as the walk, no host round trip before the one download
                         self.dist.all_gather_into_tensor(gathered, send, group=self.group)
                         full = gathered.cpu().numpy()
-                    self.last_exchange_ms = 1e3 * (time.perf_counter() - t0)
+                    self.last_collect_ms = 1e3 * (time.perf_counter() - t0)
                 finally:
                     if token is not None:
                         eng.walk_queue_end(token)         # (the stream is idle by now: waits for nothing, checks the handle)

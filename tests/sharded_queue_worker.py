@@ -74,7 +74,7 @@ def main():
                 assert a.shape == b.shape and a.dtype == b.dtype and same(a, b), (rank, n, np.ndim(steps))
             if n:
                 assert np.all(got[3][::50, 0] == 0)          # never moved: came back as fresh draws
-                assert queue.last_gpu_ms >= 0 and queue.last_exchange_ms > 0
+                assert queue.last_gpu_ms >= 0 and queue.last_collect_ms > 0
             done += 1
 
     # the same through the pool a driver holds: GPUPool(group=True).map(walker.sample, queue) on every rank
