@@ -82,3 +82,27 @@ for name in ("stats_models.log", "stats_dt05.log", "stats_dt05ext.log", "stats_c
         keep = [ln for ln in open(f, errors="replace") if not ln.startswith(("W2026", "E2026", "I2026")) and "amdgpu.ids" not in ln]
         open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)
 print(json.dumps({k: v["mean"] for k, v in pmc.items() if isinstance(v, dict)}, indent=1))
+
+# One table of what the documents quote (DESIGN.md / README.md cite the averages of the committed CSVs): every em_* / stack2 / walk kernel
+# of every profiled command with its call count, average, minimum -- profiles/<tag>_summary.md, generated, never edited.
+rows = []
+for what in ("bench", "dt05", "dt05ext", "c4", "models", "at2017gfo", "device_walk", "queue"):
+    f = os.path.join(dst, f"{tag}_{what}_kernel_stats.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        name = r["Name"]
+        if not any(k in name for k in ("em_logl", "em_fused", "em_lc_loglike", "stack2", "lc_stack", "me2017", "walk_", "lc_regrid")):
+            continue
+        short = name.replace("void ", "").replace("nmma::", "")
+        short = short[:short.index("(")] if "(" in short else short
+        rows.append((what, short, int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+if rows:
+    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as fh:
+        fh.write(f"# {tag}: kernel times of the committed rocprofv3 CSVs (generated by tools/summarize_profiles.py)\n\n"
+                 "`what` = the profiled command of tools/profile_round.sh (bench: bench.py --steps 200, steady state; the others: 35-call runs of a "
+                 "fresh process, i.e. at ramping clocks -- config 2's own kernel reads ~30.8 us there).\n\n"
+                 "| what | kernel | calls | average us | min us |\n|---|---|---|---|---|\n")
+        for what, short, calls, avg, mn in rows:
+            fh.write(f"| {what} | `{short}` | {calls} | {avg:.2f} | {mn:.2f} |\n")
+    print("wrote", f"{tag}_summary.md", len(rows), "rows")
