@@ -19,6 +19,9 @@ live points per GPU; ``--scaling strong`` splits ONE 4096-point batch over the r
 Before the W warmup steps ``--clock-warmup-steps`` (1536) untimed steps let the GPU's clocks settle (a fresh process runs its first
 ~900 launches at ramping clocks).  The K-step region (W untimed steps first, each region bracketed by barrier + synchronize) is timed ``--repeats`` times and
 `value` / `ms_per_step` are the MEDIAN region's (`spread_pct` = the 10-90 percentile spread over the repeats, relative to it).
+With N > 1 over RCCL the K steps of a timed region -- evaluation on one stream, the all-gather of the previous step's log L on a second --
+are replayed as ONE captured HIP graph (issued step by step the pipeline's event calls cost the host more than the kernel they overlap with;
+NMMA_BENCH_NO_GRAPH=1 keeps the stream form, NMMA_BENCH_BLOCKING=1 one stream).
 With N > 1 BOTH scaling modes are measured in the one invocation: the line's top level is the mode ``--scaling`` names, the
 other one sits under ``other_scaling``.  Rank 0 prints ONE JSON line.  `roofline` prices the log-likelihood kernel (em_logl: surrogate
 MLP on the f32 MFMA pipe, SVD reconstruction, interpolation and likelihood terms in one launch)
@@ -225,10 +228,66 @@ def main():
                 t = torch.tensor([cold_elapsed], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 cold_elapsed = float(t.item())
+        # N > 1, pipelined: the K steps of a timed region as ONE captured HIP graph.  Issued step by step the two-stream pipeline costs
+        # the HOST 38 us per step -- four event record / wait calls at ~5.5 us each on top of the kernel launch (5.4 us) and the
+        # collective's call (10.5 us): tools/experiments/step_cost_probe.py -- i.e. more than the 27.6 us kernel it is meant to overlap
+        # with; in a graph the same dependencies are edges and the host issues one launch per region.  The graph holds exactly
+        # args.steps steps (kernel on s_eval -> all-gather on s_coll, two log L buffers); capture failures fall back to the stream form.
+        graph, graph_note, graph_last = None, None, None
+        if pipelined and os.environ.get("NMMA_BENCH_NO_GRAPH") != "1":
+            try:
+                torch.cuda.synchronize()
+                if use_dist:
+                    dist.barrier()
+                g = torch.cuda.CUDAGraph()
+                # (events of their own: an event last recorded inside a capture must not be waited on by the stream-ordered steps)
+                # (NB log L buffers: evaluation i + NB waits for the collective of step i.  With one rank over RCCL 2, 4 and 8 buffers give the
+                #  same 35 us per step at K = 200 -- the collective's kernel beside the likelihood's costs the latter 4 us and the pair ~3 us
+                #  of serialisation whatever the depth -- so two, as in the stream form; NMMA_BENCH_GRAPH_BUFFERS for an 8-GPU ring that
+                #  needs more slack)
+                NB = max(2, int(os.environ.get("NMMA_BENCH_GRAPH_BUFFERS", "2")))
+                gev_eval = [torch.cuda.Event() for _ in range(NB)]
+                gev_coll = [torch.cuda.Event() for _ in range(NB)]
+                g_outs = [torch.empty_like(out) for _ in range(NB)]
+                g_gathers = [torch.empty_like(gathered) for _ in range(NB)]
+                with torch.cuda.graph(g, stream=s_eval):
+                    for i in range(args.steps):
+                        b = i % NB
+                        if i >= NB:
+                            s_eval.wait_event(gev_coll[b])
+                        eng.loglike(thetas[i % N_THETA_SETS], out=g_outs[b], stream=s_eval)
+                        gev_eval[b].record(s_eval)
+                        s_coll.wait_event(gev_eval[b])
+                        with torch.cuda.stream(s_coll):
+                            dist.all_gather_into_tensor(g_gathers[b], g_outs[b])
+                        gev_coll[b].record(s_coll)
+                    for b in range(min(NB, args.steps)):      # join: the capture ends on s_eval with every collective behind it
+                        s_eval.wait_event(gev_coll[b])
+                graph_last = g_outs[(args.steps - 1) % NB]
+                torch.cuda.synchronize()
+                graph = g
+            except Exception as exc:      # noqa: BLE001
+                graph, graph_note = None, f"{type(exc).__name__}: {exc}"[:200]
+                torch.cuda.synchronize()
+
+        def region():
+            """K steps: one graph launch, or K stream-ordered steps."""
+            nonlocal done
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(done, done + args.steps):
+                    step(i)
+            done += args.steps
+
         n_before_clock = done
-        for _ in range(args.clock_warmup_steps):        # (a fixed count: every rank issues the same collectives)
-            step(done)
-            done += 1
+        if graph is not None:
+            for _ in range(-(-args.clock_warmup_steps // args.steps)):      # (the same count on every rank)
+                region()
+        else:
+            for _ in range(args.clock_warmup_steps):        # (a fixed count: every rank issues the same collectives)
+                step(done)
+                done += 1
         torch.cuda.synchronize()
         n_clock = done - n_before_clock
         for _ in range(args.warmup):
@@ -248,19 +307,33 @@ def main():
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
-            eng.profile_begin(args.steps)
+            if graph is None:
+                eng.profile_begin(args.steps)
             t0 = time.perf_counter()
-            for i in range(done, done + args.steps):
-                step(i)
+            region()
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
                 torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-            done += args.steps
-            p = eng.profile_end()
-            prof["fused_ms_total"] += p["fused_ms_total"]
-            prof["n_launches"] += p["n_launches"]
+            if graph is None:
+                p = eng.profile_end()
+                prof["fused_ms_total"] += p["fused_ms_total"]
+                prof["n_launches"] += p["n_launches"]
+        if graph is not None:
+            # (HIP events cannot bracket launches inside a captured graph: the kernel time of `roofline` comes from the same K steps
+            #  issued stream by stream right after the timed regions -- same kernels, same collectives beside them; the line says so)
+            for _ in range(min(args.repeats, 5)):
+                if use_dist:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                eng.profile_begin(args.steps)
+                for i in range(args.steps):
+                    step(i)
+                torch.cuda.synchronize()
+                p = eng.profile_end()
+                prof["fused_ms_total"] += p["fused_ms_total"]
+                prof["n_launches"] += p["n_launches"]
         gc.enable()
         if pipelined:
             torch.cuda.set_stream(prev_stream)
@@ -270,11 +343,15 @@ def main():
             times = t.cpu().tolist()
         elapsed = float(np.median(times))
         spread = 100.0 * (float(np.percentile(times, 90)) - float(np.percentile(times, 10))) / elapsed if len(times) > 1 else 0.0
-        n_done = done
+        n_done = args.steps if graph is not None else done      # (the profiling leg's steps count from 0)
         # sanity: the numbers we just timed are real likelihood values
         last = (outs[(n_done - 1) & 1] if pipelined else out).cpu().numpy()
+        if graph is not None:
+            glast = graph_last.cpu().numpy()
+            assert np.all(np.isfinite(glast)) and np.all(glast < 0)
         assert np.all(np.isfinite(last)) and np.all(last < 0)
-        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, prof=prof, geom=eng.last_launch_geometry(), n_clock=n_clock,
+        return dict(elapsed=elapsed, B=B, global_batch=global_batch, pipelined=pipelined, graph=graph is not None, graph_note=graph_note, prof=prof,
+                    geom=eng.last_launch_geometry(), n_clock=n_clock,
                     spread_pct=spread, best=min(times), worst=max(times), cold_elapsed=cold_elapsed, thetas=thetas, out=out)
 
     def exchange_label(m):
@@ -282,7 +359,9 @@ def main():
             return "none"
         if share_gpu:
             return "gloo all_gather (TEST MODE: ranks share one GPU)"
-        return "RCCL all_gather of logL per step" + (", pipelined with the next evaluation" if m["pipelined"] else "")
+        return ("RCCL all_gather of logL per step" + (", pipelined with the next evaluation" if m["pipelined"] else "")
+                + (", the K steps of a region replayed as ONE captured HIP graph (kernel time of `roofline`: the same steps issued stream by stream)"
+                   if m.get("graph") else (f" (graph capture failed: {m['graph_note']})" if m.get("graph_note") else "")))
 
     main_mode = measure(args.scaling, cold=True)
     # with more than one GPU the other scaling mode is measured in the same invocation and reported under "other_scaling"

@@ -820,8 +820,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             typedef __attribute__((address_space(3))) unsigned char* lds_bp;
             typedef const __attribute__((address_space(1))) unsigned char* gbyte_p;
             // (item-staged photometry: the item's own table, its records behind the filter's rows)
-            // (dense: [b2 | records] only -- the basis rows are the A operands of the reconstruction, read from global memory)
-            gbyte_p src = (LEANX && P.dat_in_tab) ? (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes + (DENSE ? P.tab_off_b2 : 0))
+            gbyte_p src = (LEANX && P.dat_in_tab) ? (gbyte_p)(uintptr_t)(P.tabi + (size_t)it.tabi * P.tabi_bytes)
                                                   : (gbyte_p)(uintptr_t)(P.tab + (size_t)it.m * P.tab_bytes);
             lds_bp dst = (lds_bp)(tabl + (k % NBUF) * P.tab_fast_bytes);
             for (int q = 0; q * 1024 < P.tab_fast_bytes; ++q)
@@ -845,7 +844,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const bool item_dat = LEANX && __builtin_amdgcn_readfirstlane(P.dat_in_tab) != 0;
         const lds_cdp tdat = (lds_cdp)(smem + L.dat);
         const int tstride = item_dat ? 1 : 4;                                   // doubles between the epochs of consecutive points
-        const lds_c2p dat4 = item_dat ? (lds_c2p)(tabl + (k % NBUF) * P.tab_fast_bytes + P.tab_off_dat - (DENSE ? P.tab_off_b2 : 0))
+        const lds_c2p dat4 = item_dat ? (lds_c2p)(tabl + (k % NBUF) * P.tab_fast_bytes + P.tab_off_dat)
                                       : (lds_c2p)(smem + L.dat);
         const int dbase = item_dat ? 0 : d0;
         const double st_lo = stl_l[jlo], st_hi = stl_l[jhi];
@@ -933,20 +932,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         };
         stage_p(0);
-        // dense: the A operands of this task's node tiles -- rows of [VA o span | mins | 0] on the sample grid (the stage-1 lerp
-        // between SVD nodes folded in), pre-swizzled per filter at create
-        // (EmDev::dva, one coalesced 512-byte load per MFMA) -- requested before the waits for the surrogate and the node buffer
-        const int dn_tt = (NS + 15) >> 4;          // node tiles of the SAMPLE grid (<= 16: four per task, checked at create)
-        double dav[DENSE ? 4 : 1][3];
-        if constexpr (DENSE) {
-            gcf64p dva = as_global(P.dva) + (size_t)it.m * dn_tt * 3 * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tt = (c & 3) + 4 * q;
-#pragma unroll
-                for (int step = 0; step < 3; ++step) dav[q][step] = tt < dn_tt ? dva[(tt * 3 + step) * 64] : 0.0;
-            }
-        }
         NM_TS(2);
         // ---- stage Q (needs the coefficients of item k)
         if (c == 0) {
@@ -960,55 +945,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         NM_TS(5);
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k] = clock64();
         const unsigned char* tbl = tabl + (k % NBUF) * P.tab_fast_bytes;
-        const lds_cfp b2l = (lds_cfp)(tbl + (DENSE ? 0 : P.tab_off_b2));
+        const lds_cfp b2l = (lds_cfp)(tbl + P.tab_off_b2);
         const float b2v = b2l[gi];
         constexpr int NCC = TYPEB ? 2 : 1;
         lds_c2p cc_[NCC];          // the sample's 10 coefficients (fp64) in this wave's LDS slots: [wave][q][g][16]
-        // ---- dense: the four tasks of (item k, 16 samples) reconstruct ALL nodes of those samples together,
-        //      mag[node][sample] = (VA[node, :] . c[sample, :]) span[node] + mins[node], 16 nodes x 16 samples per
-        //      v_mfma_f64_16x16x4_f64 (K = NC in three steps, zero-padded; operand layout as in em_fused) into one of
-        //      DENSE_NBUF LDS buffers; a datum then READS its two node magnitudes instead of reconstructing two rows.
-        lds_cdp nodes_l = nullptr;
-        int* unit_done = nullptr;
-        if constexpr (DENSE) {
-            const int h = c >> 2;                                 // 4 samples per task: tasks 4h .. 4h + 3 share the 16 samples of half h
-            const int unit = R * k + h;
-            int* const unit_prod = sync + 3 * W + 4 + unit;
-            unit_done = sync + 3 * W + 4 + R * W + unit;
-            const lds_dp nb = (lds_dp)(smem + L.nodes) + (unit % DENSE_NBUF) * (((NS + 15) & ~15) * DENSE_STRIDE);
-            nodes_l = (lds_cdp)nb;
-            // B operands: coefficient 4 step + lane / 16 of sample 16 h + lane % 16 (slice sums in the fixed order, + b2, as fp64);
-            // "coefficient" NC is the constant 1 that multiplies the mins column of the A table
-            const int sj = 16 * h + (lane & 15), kq = lane >> 4;
-            double bq[3];
 #pragma unroll
-            for (int step = 0; step < 3; ++step) {
-                const int kc = 4 * step + kq;
-                const lds_cfp pp = pbuf + ((sj >> 4) * 16 + (sj & 15)) * PSTR + (kc < 16 ? kc : 0);
-                float cm = pp[0];
-#pragma unroll
-                for (int w = 1; w < NSLICE; ++w) cm += pp[w * (R * 16 * PSTR)];
-                cm += b2l[kc < 16 ? kc : 0];
-                bq[step] = kc < NC ? (double)cm : (kc == NC ? 1.0 : 0.0);
-            }
-            // the buffer's previous unit has been consumed by all four of its tasks
-            if (unit >= DENSE_NBUF) sync_wait(unit_done - DENSE_NBUF, 4, P.watchdog, 360 + k);
-            typedef double f64x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tt = (c & 3) + 4 * q;                  // this task's node tiles (uniform)
-                if (tt >= dn_tt) break;
-                f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int step = 0; step < 3; ++step) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dav[q][step], bq[step], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nb[(16 * tt + 4 * r + kq) * DENSE_STRIDE + (lane & 15)] = acc[r];
-            }
-            sync_signal(unit_prod, lane);
-            sync_wait(unit_prod, 4, P.watchdog, 370 + k);        // all node tiles of the unit are in LDS
-        }
-#pragma unroll
-        for (int q = 0; q < (DENSE ? 0 : NCC); ++q) {
+        for (int q = 0; q < NCC; ++q) {
             // slice reduction (fixed order) + bias of the second Dense: lane gi owns coefficient gi of its sample
             const int s = s_[q];
             const lds_cfp pp = pbuf + ((s >> 4) * 16 + (s & 15)) * PSTR + gi;
@@ -1032,15 +974,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cdp ext_l = (lds_cdp)(smem + L.exttab) + (P.has_ebv ? k : 0) * TS;
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
-        if constexpr (DENSE) {
 #pragma unroll
-            for (int u = 0; u < NSL; ++u) {
-                const lds_cdp nd = nodes_l + lo_[u] * DENSE_STRIDE + (s_[0] & 15);
-                ynode_[0][u] = nd[0]; ynode_[1][u] = nd[DENSE_STRIDE];
-            }
-        }
-#pragma unroll
-        for (int pass = 0; pass < (DENSE ? 0 : (TWO ? 2 : 1)); ++pass) {
+        for (int pass = 0; pass < (TWO ? 2 : 1); ++pass) {
             lds_c2p ra_[NSL], rb_[NSL];
 #pragma unroll
             for (int u = 0; u < NSL; ++u) {
@@ -1238,7 +1173,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         }
         if (dbg && blockIdx.x == 0 && c == 0 && lane == 0) dbg[66 + 2 * k + 1] = clock64();
         NM_TS(6);
-        if constexpr (DENSE) sync_signal(unit_done, lane);      // this task no longer reads the unit's node buffer
         sync_signal(sync + W + 2 + k, lane);     // one signal per task
 #undef NM_TS
     };

@@ -56,16 +56,19 @@ def test_bench_small_batches(batch):
     assert np.isfinite(line["value"]) and line["value"] > 0
 
 
-@pytest.mark.parametrize("blocking", ["0", "1"])
+@pytest.mark.parametrize("blocking", ["0", "1", "stream"])
 def test_bench_rccl_exchange_with_one_rank(blocking):
     """The RCCL path of bench.py on the one GPU of the box: process group `nccl` (= RCCL) of world size 1, the all-gather of logL
     after every evaluation -- on a second stream, overlapping the next kernel (the form an 8-GPU run takes), and blocking on the
     compute stream -- plus the barrier / max-over-ranks timing.  No scaling number; the code an N-GPU run executes has run."""
-    line = _bench("--gpus", "1", "--repeats", "3", NMMA_BENCH_SHARE_GPU="0", NMMA_BENCH_FORCE_DIST="1", NMMA_BENCH_BLOCKING=blocking,
+    # ("stream": the two-stream pipeline issued step by step; "0": the same K steps of a region replayed as one captured HIP graph)
+    line = _bench("--gpus", "1", "--repeats", "3", NMMA_BENCH_SHARE_GPU="0", NMMA_BENCH_FORCE_DIST="1", NMMA_BENCH_BLOCKING="1" if blocking == "1" else "0",
+                  NMMA_BENCH_NO_GRAPH="1" if blocking == "stream" else "0",
                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["repeats"] == 3
     ex = line["config"]["exchange"]
-    assert ex.startswith("RCCL all_gather of logL per step") and ("pipelined" in ex) == (blocking == "0")
+    assert ex.startswith("RCCL all_gather of logL per step") and ("pipelined" in ex) == (blocking != "1")
+    assert ("captured HIP graph" in ex) == (blocking == "0"), ex
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert line["value"] == pytest.approx(4096 / (line["ms_per_step"] * 1e-3), rel=1e-9)
     assert line["roofline"]["kernel"] == "em_logl" and 0 < line["roofline"]["frac"] < 1
