@@ -236,6 +236,11 @@ def main():
         graph, graph_note, graph_last = None, None, None
         if pipelined and os.environ.get("NMMA_BENCH_NO_GRAPH") != "1":
             try:
+                # (two stream-ordered steps first: whatever the library allocates on the first launch of a batch size -- the band split's
+                #  workspace -- must exist before a capture, which forbids allocations)
+                for _ in range(2):
+                    step(done)
+                    done += 1
                 torch.cuda.synchronize()
                 if use_dist:
                     dist.barrier()
