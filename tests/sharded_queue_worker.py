@@ -108,6 +108,25 @@ def main():
     assert same(got_c.u, ref_c.u) and same(got_c.logl, ref_c.logl) and np.array_equal(got_c.ncall, ref_c.ncall)
     assert not same(got_c.u, one.u)              # (the constraint bites)
     done += 1
+    # a whole nested-sampling run, SPMD: every rank runs the same sampler on the same seed, the pool shards every queue over the ranks
+    # -- the run has to be THE single-device run (same iterations, evidence, weights) on every rank
+    from tests.test_gpu_nested_sampling import nested_sampling
+    host_ll = lambda v: lik.log_likelihood_batch(np.ascontiguousarray(v), names)
+    runs = []
+    for pool_r in (GPUPool(lik, queue_size=384, names=names, prior_transform_many=pt, priors=pri),
+                   GPUPool(lik, queue_size=384, names=names, prior_transform_many=pt, priors=pri, group=True)):
+        walker = smp.EnsembleWalkSampler(ndim=len(names), naccept=10, walks=20, maxmcmc=500)
+        runs.append(nested_sampling(pool_r, walker, pt, host_ll, len(names), 300, 384, seed=13, dlogz=0.5, max_iter=20000))
+    a, b = runs
+    assert a["niter"] == b["niter"] and a["ncall"] == b["ncall"] and a["logz"] == b["logz"] and a["niter"] > 300 * 5
+    assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["samples"], b["samples"])
+    z = torch.tensor([b["logz"], float(b["niter"])], dtype=torch.float64)
+    zs = [torch.empty_like(z) for _ in range(world)]
+    if backend == "nccl":
+        z, zs = z.cuda(), [t.cuda() for t in zs]
+    dist.all_gather(zs, z)
+    assert all(torch.equal(t, z) for t in zs)        # the same run on every rank
+    done += 1
     dist.barrier()
     print(f"OK {rank} {done}", flush=True)
     dist.destroy_process_group()
