@@ -274,6 +274,11 @@ def main():
             except Exception as exc:      # noqa: BLE001
                 graph, graph_note = None, f"{type(exc).__name__}: {exc}"[:200]
                 torch.cuda.synchronize()
+            # every rank must issue the same collectives in the same order: graph mode only if EVERY rank captured its graph
+            agree = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 0 and graph is not None:
+                graph, graph_note = None, "another rank could not capture its graph"
 
         def region():
             """K steps: one graph launch, or K stream-ordered steps."""
