@@ -224,3 +224,12 @@ def test_factory_builds_what_the_reference_drivers_build(tmp_path):
     assert isinstance(single, SimpleKilonovaLightCurveModel) and len(single.model_times) == 41
     one = create_light_curve_model_from_args(["Bu2019nsbh_tf"], args, filters=["ztfr"])
     assert isinstance(one, SVDLightCurveModel) and list(one.filters) == ["ztfr"]
+    # (advisor, round 5) --filters from the arguments when the caller passes none (model.py:1618-1619) ...
+    args_f = types.SimpleNamespace(**dict(vars(args), filters="ztfr, ztfg"))
+    from_args = create_light_curve_model_from_args("Bu2019nsbh_tf", args_f)
+    assert list(from_args.filters) == ["ztfr", "ztfg"]
+    # ... and a name the reference resolves to a host-side model (model.py:1572-1579) needs its host object: a clear error, not a
+    # fall-through to a surrogate that fails on a missing file
+    for name in ("TrPi2018", "Piro2021", "PL_BB_fixedT", "Sr2023", "Arnett"):
+        with pytest.raises(ValueError, match="host_models"):
+            create_light_curve_model_from_args(f"Bu2019nsbh_tf,{name}", args, filters=["ztfr"])
