@@ -384,8 +384,40 @@ def case_small_hidden():
     return _base(seed=8234, n_hidden=64, batch=16)
 
 
+def case_dense_edges(sampled_sys=False):
+    """The dense task's bookkeeping (round 6: padded detection records, upper limits behind them, the window test as a mask) pinned by
+    the reference itself: five bands of 64 / 47 / 85 / 40 / 33 points on the documented CLI grid, 22 upper limits in one band, a band
+    that is all upper limits but two detections, rows whose time shift pushes every epoch out of the model window (detections ->
+    floor; upper limits alone would contribute log sf(-inf) = 0), a NaN model parameter."""
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"] + (["em_syserr"] if sampled_sys else [])
+    c = _base(seed=9771, filters=["g", "r", "i", "z", "y"], counts=dict(g=64, r=47, i=85, z=40, y=33), batch=64, names=names, upper_limit_filter="i")
+    if sampled_sys:
+        c["systematics"] = dict(mode="param", name="em_syserr")
+        c["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    times, mags, sig = (dict(d) for d in c["data"])
+    sig = {f: np.array(v, dtype=float) for f, v in sig.items()}
+    sig["i"][::4] = np.inf
+    sig["y"][2:] = np.inf
+    c["data"] = (times, mags, sig)
+    c["sample_times"] = np.arange(0.1, 20.5, 0.5)
+    th = c["theta"]
+    ts = names.index("timeshift")
+    th[3, ts] = 30.0
+    th[4, ts] = -25.0
+    th[5, names.index("log10_mej_dyn")] = np.nan
+    if sampled_sys:
+        th[6, names.index("em_syserr")] = np.nan
+    return c
+
+
+def case_dense_edges_syserr():
+    return case_dense_edges(sampled_sys=True)
+
+
 CASES = {
     "c2_default": case_c2_default,
+    "dense_edges": case_dense_edges,
+    "dense_edges_syserr": case_dense_edges_syserr,
     "c2_dt05_limit": case_c2_dt05_limit,
     "c2_dt05": case_c2_dt05,
     "grid_subset": case_grid_subset,
