@@ -1517,21 +1517,24 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
 
     // ---------------------------------------------------------------------------------
     // dense_task (FASTM == 6; round 6 -- before, a variant of lean_task): every filter has so many points that reconstructing ALL nodes of
-    // (item, 16 samples) beats two basis rows per datum (config 4: 12 filters x 200 points).  The four tasks of a UNIT (item k, 16 samples) -- four
-    // samples x 16 lanes each -- share:
+    // (item, 16 samples) beats two basis rows per datum (config 4: 12 filters x 200 points).  The four tasks of a UNIT (item k, 16
+    // samples) -- task c: samples 4 c .. 4 c + 3, 16 lanes each -- share
     //   * app[node][sample] = (VA[node, :] o span) . c[sample, :] + mins[node] + offset[sample] -- offset = extinction of the item's
     //     filter + distance modulus + K-correction (model.py:390-397) -- on the fp64 matrix cores, 16 nodes x 16 samples per
     //     v_mfma_f64_16x16x4_f64 with K = NC + 2 in three steps (A operands: EmDev::dva, rows on the SAMPLE grid with the stage-1 lerp
-    //     folded in, pre-swizzled at create; its column of ones multiplies the sample's offset), into one of DENSE_NBUF LDS buffers;
-    //   * the datum loop, lane = (sample lane % 16, data slice lane / 16): what is left per datum is the interpolation and the term
-    //     themselves, written for the issue port the task shares with the surrogate's f32 MFMA stream (~18 vector instructions):
+    //     folded in, pre-swizzled at create; its column of ones multiplies the sample's offset), a quarter of the node tiles per task,
+    //     into one of DENSE_NBUF LDS buffers (hand-off: unit_prod / unit_done counters);
+    // and each then walks the data of its four samples, two slots per lane and pass.  What is left per datum is the interpolation and
+    // the term themselves, written for the issue port the task shares with the surrogate's f32 MFMA stream (17.5 vector instructions per
+    // datum in the ISA; the variant of lean_task: 48):
     //       u = t c1 + c0 (the datum's position on the sample's observer-frame grid in node units: one FMA on per-sample constants),
     //       lo = clamp(int(u)), frac = u - lo, the two node magnitudes (one LDS read of two), est = y0 + (y1 - y0) frac,
     //       x = (m - est) / sigma, term = -x^2 / 2 + k with k = -(ln sqrt(2 pi) + ln sigma) from the record;
-    //     the window test of np.interp(left = right = inf) -> NaN (em_likelihood.py:252-256) accumulates in a mask, the records are
-    //     padded to whole passes (no per-slot validity), upper limits sit behind the detections and are evaluated after the loop.
-    // Round 5's form (four tasks of 4 samples x 16 lanes per unit, each building the unit's B operands and a quarter of its node tiles)
-    // spent more vector instructions on a task's set-up than on its data (profiles/r06_c4.md).
+    // the window test of np.interp(left = right = inf) -> NaN (em_likelihood.py:252-256) accumulates in a mask, the records are padded to
+    // whole passes (no per-slot validity: the padding's term is exactly 0), upper limits sit behind the detections and are evaluated after
+    // the loop (log Phi from the table behind the node buffers).
+    // ONE task per unit (no redundant B-operand builds) was measured and lost -- two node buffers then keep only two long tasks in
+    // flight and the VALU load no longer spreads over the four SIMDs, whose slowest gates the surrogate's items (profiles/r06_c4.md).
     // Deviation from the reference's association order (est from the fraction instead of slope x (t - x0), the offset added inside the
     // matrix product): a few ulp of a magnitude, DEVIATIONS.md; unequally spaced grids take the bracket search and the exact node times.
     // ---------------------------------------------------------------------------------
