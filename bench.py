@@ -164,7 +164,8 @@ def main():
         # buffers; events order "kernel i -> gather i" and "gather i -> kernel i + 2").  Host cost per step is the same as the
         # blocking form (~38 us, tools/overlap_probe.py), but the GPU no longer serialises kernel + collective.
         # NMMA_BENCH_BLOCKING=1 keeps everything on one stream.
-        pipelined = use_dist and not share_gpu and slot == B and os.environ.get("NMMA_BENCH_BLOCKING") != "1"
+        # (decided from the GLOBAL split, so that every rank takes the same form: the forms issue different numbers of collectives)
+        pipelined = use_dist and not share_gpu and global_batch % world == 0 and os.environ.get("NMMA_BENCH_BLOCKING") != "1"
         prev_stream = torch.cuda.current_stream()
         if pipelined:
             s_eval, s_coll = torch.cuda.Stream(), torch.cuda.Stream()
