@@ -12,11 +12,13 @@ case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
 eng = engine_from_case(case)
 th = torch.as_tensor(syn.draw_theta(7, B, case["names"])[1], device="cuda:0")
 out = torch.empty(B, dtype=torch.float64, device="cuda:0")
-for _ in range(5):
+# (NMMA_PERF_WARM=<n>: n untimed launches first -- ~1600 bring the clocks to the steady state bench.py measures in; default: the 5 of a
+#  fresh process, the protocol of the committed *_kernel_stats.csv files)
+for _ in range(int(os.environ.get("NMMA_PERF_WARM", "5"))):
     eng.loglike(th, out=out)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 30
+n = int(os.environ.get("NMMA_PERF_N", "30"))
 e0.record()
 for _ in range(n):
     eng.loglike(th, out=out)
