@@ -15,8 +15,8 @@ from tests import cases, cases_combined, cases_me2017  # noqa: E402
 from tests.helpers import engine_from_case  # noqa: E402
 
 
-def timeit(fn, n=20):
-    for _ in range(3):
+def timeit(fn, n=int(os.environ.get("NMMA_PERF_N", "20"))):
+    for _ in range(int(os.environ.get("NMMA_PERF_WARM", "3"))):      # (NMMA_PERF_WARM=2000: the steady state bench.py measures in)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
