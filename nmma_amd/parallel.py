@@ -177,6 +177,48 @@ class ShardedQueue:
         return unpack_records(out.cpu().numpy()[rows_of], ndim)
 
 
+def send_command(dist, group, header, arrays, device=None):
+    """Rank 0 of ``group`` hands a command to the others (the master / worker form of ``GPUPool``): ``header`` (a small picklable dict) and
+    ``arrays`` (name -> numpy array) travel as ONE ``broadcast_object_list`` of the header + the arrays' shapes and ONE broadcast of their
+    bytes (RCCL with backend ``nccl``: from ``device``; gloo: host tensors).  Returns what :func:`recv_command` returns on the workers."""
+    import torch
+    arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    meta = [(k, v.shape, v.dtype.str, v.nbytes) for k, v in arrays.items()]
+    dist.broadcast_object_list([dict(header, _arrays=meta)], src=0, group=group)
+    total = sum(m[3] for m in meta)
+    if total:
+        blob = np.concatenate([v.reshape(-1).view(np.uint8) for v in arrays.values()]) if len(arrays) > 1 else next(iter(arrays.values())).reshape(-1).view(np.uint8)
+        t = torch.from_numpy(np.ascontiguousarray(blob))
+        if dist.get_backend(group) == "nccl":
+            t = t.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        dist.broadcast(t, src=0, group=group)
+    return header, arrays
+
+
+def recv_command(dist, group, device=None):
+    """The workers' side of :func:`send_command`: ``(header, {name: numpy array})``."""
+    import torch
+    box = [None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    header = dict(box[0])
+    meta = header.pop("_arrays")
+    total = sum(m[3] for m in meta)
+    arrays = {}
+    if total:
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.empty(total, dtype=torch.uint8, device=(device if device is not None else f"cuda:{torch.cuda.current_device()}") if on_dev else "cpu")
+        dist.broadcast(t, src=0, group=group)
+        blob = t.cpu().numpy()
+        off = 0
+        for name, shape, dtype, nbytes in meta:
+            arrays[name] = blob[off:off + nbytes].view(np.dtype(dtype)).reshape(shape).copy()
+            off += nbytes
+    else:
+        for name, shape, dtype, _ in meta:
+            arrays[name] = np.empty(shape, dtype=np.dtype(dtype))
+    return header, arrays
+
+
 class MultiDeviceEvaluator:
     """ONE process driving several GPUs ("single process x 8 devices (ctypes + streams) avoids MPI").
 

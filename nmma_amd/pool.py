@@ -23,7 +23,7 @@ import numpy as np
 
 class GPUPool:
     def __init__(self, likelihood, queue_size=4096, names=None, prior_transform_many=None, priors=None, device=0, device_walk=True,
-                 devices=None, group=None):
+                 devices=None, group=None, master_worker=False):
         """``devices``: several HIP devices driven from this one process (e.g. ``range(8)``) -- a queue of the device walk and a
         batch of ``log_likelihood`` calls are then SHARDED over them, contiguous balanced shards with the live set replicated, as
         the reference's task farm spreads a queue's chains over its MPI ranks (core/mpi_setup.py:651-667, :679-683); results come
@@ -32,12 +32,19 @@ class GPUPool:
         EVERY rank runs the same sampler on the same seeds and calls ``map`` with the same queue; this rank walks / evaluates its
         contiguous shard on its own device and the shards are exchanged with ONE all-gather per queue / batch (RCCL over xGMI:
         ``parallel.ShardedQueue`` -- records packed on the device, one download -- and ``parallel.ShardedEvaluator``), so every rank
-        continues with the full result, bit-identical to the single-device run."""
+        continues with the full result, bit-identical to the single-device run.
+        ``master_worker=True`` (with ``group``): the reference's own structure instead of SPMD (core/mpi_setup.py:651-667 -- ``with POOL()
+        as pool: if pool.is_master(): run the sampler``): only rank 0 runs the sampler; the other ranks block in ``wait()`` (entered by
+        ``with pool:`` / ``pool.wait()``) and serve -- rank 0's ``map`` broadcasts the queue (one object + one byte broadcast), every rank
+        walks its shard, ONE all-gather brings the records back -- until rank 0 closes the pool.  Nothing a worker does can diverge from
+        the master (wall-clock checkpoints, ``max_run_time``): the sampler exists once."""
         self.likelihood = likelihood
         self.devices = [int(d) for d in devices] if devices is not None else None
         if group is not None and devices is not None:
             raise ValueError("GPUPool: `devices` (one process, several GPUs) and `group` (one process per GPU) exclude each other")
         self.group = group
+        self.master_worker = bool(master_worker) and group is not None
+        self._closed = False
         self._rank_queue = None           # parallel.ShardedQueue over `group`, built on first use
         self._rank_eval = None            # parallel.ShardedEvaluator over `group`
         self._shard_engines = None        # [(engine, constraint program)] per entry of `devices`, built on first use
@@ -55,21 +62,80 @@ class GPUPool:
         self.n_evals = 0
 
     # ---- schwimmbad surface
+    def _dist(self):
+        import torch.distributed as dist
+        return dist
+
+    def _grp(self):
+        return None if self.group is True else self.group
+
     def is_master(self):
-        return True
+        if not self.master_worker:
+            return True
+        return self._dist().get_rank(self._grp()) == 0
 
     def is_worker(self):
-        return False
+        return not self.is_master()
+
+    def _rank_device(self):
+        eng = self._walk_engine()[0] if self.names is not None else None
+        return f"cuda:{eng.device if eng is not None else self.device}"
+
+    def _queue_for(self, eng, prog):
+        q = self._rank_queue
+        if q is None or q.engine is not eng or q.constraints is not prog:
+            from .parallel import ShardedQueue
+            q = self._rank_queue = ShardedQueue(engine=eng, constraints=prog, group=self._grp())
+        return q
+
+    def _evaluate_sharded(self, theta):
+        """This rank's row shard of ``theta`` on its device, then ONE all-gather of the log L shards (parallel.ShardedEvaluator)."""
+        import torch
+        if self._rank_eval is None:
+            from .parallel import ShardedEvaluator
+            self._rank_eval = ShardedEvaluator(lambda th: self.likelihood.log_likelihood_batch(th, self.names), group=self._grp())
+        res = self._rank_eval.evaluate(torch.as_tensor(theta).to(self._rank_device()))      # (the shard is evaluated and exchanged on the device)
+        return res.cpu().numpy() if hasattr(res, "cpu") else np.asarray(res)
 
     def wait(self, callback=None):
-        return None
+        """schwimmbad's worker loop (master / worker form): a rank other than 0 serves rank 0's ``map`` calls -- receive the queue, walk
+        / evaluate this rank's shard, take part in the all-gather -- until rank 0 closes the pool.  Rank 0, and every rank of the SPMD
+        form, returns at once."""
+        if self.is_master():
+            return None
+        from . import _lib as L
+        from .parallel import recv_command
+        dist, grp = self._dist(), self._grp()
+        while True:
+            header, arr = recv_command(dist, grp, self._rank_device())
+            op = header["op"]
+            if op == "close":
+                self._closed = True
+                return None
+            if op == "loglike":
+                self._evaluate_sharded(arr["theta"])
+            elif op == "walk":
+                eng, prog = self._walk_engine()
+                if eng is None:
+                    raise RuntimeError("GPUPool worker: the master sent a device queue but this rank's likelihood has no engine form")
+                table = (L.WalkPrior * len(self.names)).from_buffer_copy(arr["table"].tobytes())
+                walks = arr["walks"] if header["per_chain"] else int(arr["walks"][0])
+                self._queue_for(eng, prog).run(arr["live"], arr["u0"], arr["loglstar"], arr["keys"], walks, table=table)
+            else:
+                raise RuntimeError(f"GPUPool worker: unknown command {op!r}")
 
     def close(self):
+        if self.master_worker and not self._closed and self.is_master():
+            from .parallel import send_command
+            send_command(self._dist(), self._grp(), {"op": "close"}, {}, self._rank_device())
+        self._closed = True
         self._drop_shards()
         self._rank_queue = self._rank_eval = None
         return None
 
     def __enter__(self):
+        if self.master_worker and not self.is_master():
+            self.wait()           # (a worker serves here until the master leaves ITS with-block; then it falls through an empty body)
         return self
 
     def __exit__(self, *exc):
@@ -88,16 +154,12 @@ class GPUPool:
             theta = np.ascontiguousarray(np.stack([np.asarray(t, dtype=float) for t in thetas]))
         shards = self._walk_engines() if self.devices is not None and len(self.devices) > 1 else None
         if self.group is not None:
-            # one process per GPU: this rank's row shard, then ONE all-gather of the logL shards (parallel.ShardedEvaluator)
-            if self._rank_eval is None:
-                from .parallel import ShardedEvaluator
-                self._rank_eval = ShardedEvaluator(lambda th: self.likelihood.log_likelihood_batch(th, self.names),
-                                                   group=None if self.group is True else self.group)
-            import torch
-            eng = self._walk_engine()[0] if self.names is not None else None
-            dev = eng.device if eng is not None else self.device
-            res = self._rank_eval.evaluate(torch.as_tensor(theta).to(f"cuda:{dev}"))      # (the shard is evaluated and exchanged on the device)
-            out = res.cpu().numpy() if hasattr(res, "cpu") else np.asarray(res)
+            # one process per GPU: this rank's row shard, then ONE all-gather of the logL shards (parallel.ShardedEvaluator); in the
+            # master / worker form rank 0 first hands the batch to the ranks that wait
+            if self.master_worker:
+                from .parallel import send_command
+                send_command(self._dist(), self._grp(), {"op": "loglike"}, {"theta": theta}, self._rank_device())
+            out = self._evaluate_sharded(theta)
         elif shards and all(prog is None for _, prog in shards):
             # several devices: row shards launched asynchronously on every device, gathered on the first (no collective library)
             if self._evaluator is None:
@@ -192,12 +254,8 @@ class GPUPool:
                         if shards is not None:
                             kw["engine"], kw["constraints"] = shards, None
                     elif kw["engine"] is not None and self.group is not None:
-                        q = self._rank_queue
-                        if q is None or q.engine is not kw["engine"] or q.constraints is not kw["constraints"]:
-                            from .parallel import ShardedQueue
-                            q = self._rank_queue = ShardedQueue(engine=kw["engine"], constraints=kw["constraints"],
-                                                                group=None if self.group is True else self.group)
-                        kw["engine"], kw["constraints"] = q, None
+                        q = self._queue_for(kw["engine"], kw["constraints"])
+                        kw["engine"], kw["constraints"] = (_MasterQueue(self, q) if self.master_worker else q), None
                 res = walker.run_many_device(items, self._log_likelihood_device, self.priors, self.names, device=self.device,
                                              loglike_many=self.log_likelihood_many, prior_transform_many=self.prior_transform_many, **kw)
                 self.n_batches += getattr(walker, "n_batches", 0)
@@ -210,3 +268,26 @@ class GPUPool:
             for r in res:
                 callback(r)
         return res
+
+
+class _MasterQueue:
+    """Rank 0's side of a queue in the master / worker form: hand the queue to the ranks that wait (``GPUPool.wait``), then walk this
+    rank's shard and take part in the all-gather like everybody else (``parallel.ShardedQueue.run``)."""
+
+    def __init__(self, pool, queue):
+        self.pool, self.queue = pool, queue
+        self.engine, self.constraints = queue.engine, queue.constraints
+
+    def run(self, live, u0, loglstar, keys, walks, table=None):
+        from .parallel import send_command
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        n = len(u0)
+        per_chain = np.ndim(walks) > 0
+        arrays = {"live": np.ascontiguousarray(live, dtype=np.float64), "u0": u0,
+                  "loglstar": np.ascontiguousarray(np.broadcast_to(np.asarray(loglstar, dtype=np.float64), (n,))),
+                  "keys": np.ascontiguousarray(keys, dtype=np.uint64),
+                  "walks": np.ascontiguousarray(walks, dtype=np.int32) if per_chain else np.array([int(walks)], dtype=np.int32),
+                  "table": np.frombuffer(bytes(table), dtype=np.uint8).copy()}
+        pool = self.pool
+        send_command(pool._dist(), pool._grp(), {"op": "walk", "per_chain": bool(per_chain)}, arrays, pool._rank_device())
+        return self.queue.run(arrays["live"], u0, arrays["loglstar"], arrays["keys"], walks, table=table)

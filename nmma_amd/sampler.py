@@ -616,8 +616,10 @@ class EnsembleWalkSampler(_LockstepWalk):
             # a chain's path depends on its key only, so the result is the single-device queue's, bit for bit
             # or a ``parallel.ShardedQueue`` (one process per GPU: this rank walks its shard, ONE all-gather of the packed records)
             from .parallel import ShardedQueue, shard_bounds
-            shards = [] if isinstance(engine, ShardedQueue) else list(engine) if isinstance(engine, (list, tuple)) else [(engine, constraints)]
-            if isinstance(engine, ShardedQueue):
+            # (... or the pool's master-side wrapper of one: anything with ``run(live, u0, loglstar, keys, walks, table=)`` that is not an engine)
+            rank_queue = isinstance(engine, ShardedQueue) or (hasattr(engine, "run") and not hasattr(engine, "walk_queue_begin"))
+            shards = [] if rank_queue else list(engine) if isinstance(engine, (list, tuple)) else [(engine, constraints)]
+            if rank_queue:
                 u, v, logl, counts = engine.run(live, u0, loglstar, rseeds, steps, table=table)
             elif len(shards) == 1:
                 u, v, logl, counts = shards[0][0].walk_queue(table, live, u0, loglstar, rseeds, steps, constraints=shards[0][1])

@@ -127,6 +127,23 @@ def main():
     dist.all_gather(zs, z)
     assert all(torch.equal(t, z) for t in zs)        # the same run on every rank
     done += 1
+    # the reference's own structure (core/mpi_setup.py:651-667): ONLY rank 0 runs the sampler, the other ranks wait in the pool and
+    # serve its map calls -- `with POOL() as pool: if pool.is_master(): ...` -- and rank 0's run is again THE single-device run
+    dist.barrier()
+    walker_mw = smp.EnsembleWalkSampler(ndim=len(names), naccept=10, walks=20, maxmcmc=500)
+    result_mw = None
+    with GPUPool(lik, queue_size=384, names=names, prior_transform_many=pt, priors=pri, group=True, master_worker=True) as pool_mw:
+        assert pool_mw.is_master() == (rank == 0) and pool_mw.is_worker() == (rank != 0)
+        if pool_mw.is_master():
+            # (a likelihood batch first: row shards + one all-gather, served by the waiting ranks)
+            assert same(pool_mw.log_likelihood_many(thetas), pool_one.log_likelihood_many(thetas))
+            result_mw = nested_sampling(pool_mw, walker_mw, pt, host_ll, len(names), 300, 384, seed=13, dlogz=0.5, max_iter=20000)
+    if rank == 0:
+        assert result_mw["niter"] == a["niter"] and result_mw["ncall"] == a["ncall"] and result_mw["logz"] == a["logz"]
+        assert np.array_equal(result_mw["weights"], a["weights"]) and np.array_equal(result_mw["samples"], a["samples"])
+    else:
+        assert result_mw is None and pool_mw._closed
+    done += 1
     dist.barrier()
     print(f"OK {rank} {done}", flush=True)
     dist.destroy_process_group()

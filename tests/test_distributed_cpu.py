@@ -223,3 +223,52 @@ def test_sharded_queue_takes_either_a_function_or_an_engine():
         ShardedQueue()
     with pytest.raises(ValueError):
         ShardedQueue(local_fn=lambda *a: None, engine=object())
+
+
+COMMAND_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["NMMA_ROOT"])
+from nmma_amd.parallel import send_command, recv_command
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(3)                        # (the same stream on every rank: the workers know what to expect)
+want = {"live": rng.uniform(size=(37, 6)), "keys": rng.integers(1, 2 ** 62, 11).astype(np.uint64),
+        "walks": np.array([7], dtype=np.int32), "table": np.frombuffer(rng.bytes(40 * 6), dtype=np.uint8).copy(), "empty": np.empty((0, 6))}
+want["live"][3, 2] = np.nan
+for round_ in range(3):
+    if rank == 0:
+        header, got = send_command(dist, None, {"op": "walk", "per_chain": False, "round": round_}, want)
+    else:
+        header, got = recv_command(dist, None)
+    assert header == {"op": "walk", "per_chain": False, "round": round_}, header
+    assert list(got) == list(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and np.array_equal(got[k], want[k], equal_nan=True), k
+header, got = send_command(dist, None, {"op": "close"}, {}) if rank == 0 else recv_command(dist, None)
+assert header == {"op": "close"} and got == {}
+dist.barrier()
+if rank == 0:
+    print("OK", 0, world)
+dist.destroy_process_group()
+'''
+
+
+def test_master_worker_commands_round_trip_over_gloo():
+    """``send_command`` / ``recv_command`` (the master / worker form of ``GPUPool``: rank 0 hands a queue to the ranks that wait): header
+    and arrays -- NaNs, uint64 keys, raw table bytes, an empty array -- arrive bit for bit on every other rank, for world sizes 2 and 3."""
+    import tempfile
+    for world in (2, 3):
+        with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as fh:
+            fh.write(COMMAND_WORKER)
+            path = fh.name
+        env = dict(os.environ, NMMA_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29900 + (os.getpid() + world) % 90), path]
+        try:
+            proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        finally:
+            os.unlink(path)
+        assert proc.returncode == 0, proc.stdout + proc.stderr
+        assert f"OK 0 {world}" in proc.stdout
