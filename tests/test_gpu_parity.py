@@ -744,6 +744,50 @@ def test_dense_lean_task_with_extinction_and_sampled_systematic(grid, ext, torch
     assert rel_err(got[~floor], rows[~floor]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_folded_rows_on_random_sample_grids(seed, torch_cuda):
+    """The stage-1 lerp folded into the lean tasks' rows (round 6) on sample grids the goldens do not have: random spacings, nodes that
+    coincide with SVD nodes mixed with nodes that do not, grids that reach beyond the SVD grid on either side (+inf nodes: the model
+    window shrinks and data outside it floor the row), equally spaced grids with an offset -- the lean task, the lean task with a
+    sampled systematic and the general lean task (a finite detection limit), all against the oracle."""
+    torch = torch_cuda
+    from oracle import nmma_oracle as orc
+    rng = np.random.default_rng(4200 + seed)
+    kind = seed % 3
+    names = ["luminosity_distance", "KNphi", "inclination_EM", "timeshift", "log10_mej_dyn", "log10_mej_wind"] + (["em_syserr"] if kind == 1 else [])
+    case = cases._base(seed=5300 + seed, batch=48, names=names)
+    if kind == 1:
+        case["systematics"] = dict(mode="param", name="em_syserr")
+        case["systematics_ref"] = dict(error_budget=None, systematics_file=None)
+    if kind == 2:
+        lim = {g: np.inf for g in case["observed_filters"]}
+        lim[case["observed_filters"][2]] = float(np.max(case["data"][1][case["observed_filters"][2]]) + 0.7)
+        case["detection_limit"] = lim
+    tt = next(iter(case["svd"].values()))["tt"]
+    n = int(rng.integers(20, 120))
+    form = seed % 4
+    if form == 0:        # random spacings inside the SVD grid, some nodes exactly ON SVD nodes
+        st = np.sort(np.concatenate([rng.uniform(tt[0], tt[-1], n), rng.choice(tt, 9, replace=False)]))
+    elif form == 1:      # equally spaced with an offset, reaching beyond the SVD grid on the right
+        st = 0.37 + 0.43 * np.arange(n)
+    elif form == 2:      # reaching beyond it on both sides
+        st = np.sort(rng.uniform(tt[0] - 1.5, tt[-1] + 3.0, n))
+    else:                # a coarse subset of the SVD nodes plus midpoints
+        sub = tt[::7]
+        st = np.sort(np.concatenate([sub, 0.5 * (sub[1:] + sub[:-1])]))
+    st = np.unique(st)
+    case["sample_times"] = st
+    eng = engine_from_case(case)
+    got = eng.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+    eng.check()
+    eng.close()
+    want = orc.log_likelihood_batch(oracle_from_case(case, use_scipy=False), names, case["theta"])
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor), (seed, np.nonzero((got == FLOOR) != floor)[0][:8])
+    if (~floor).any():
+        assert rel_err(got[~floor], want[~floor]).max() <= LOGL_RTOL
+
+
 @pytest.mark.parametrize("sampled_sys", [False, True])
 @pytest.mark.parametrize("grid", ["svd", "cli", "log"])
 def test_dense_task_edge_cases_against_the_oracle(grid, sampled_sys, torch_cuda):
