@@ -96,6 +96,7 @@ def main():
     # ... and a batch of log_likelihood calls: row shards + ONE all-gather
     thetas = np.ascontiguousarray(pt(rng.uniform(0.2, 0.8, (257, len(names)))))
     assert same(pool_one.log_likelihood_many(thetas), pool_all.log_likelihood_many(thetas))
+    assert pool_one.log_likelihood(thetas[0]) == pool_all.log_likelihood(thetas[0])        # (one row: every rank but the first holds an empty shard)
     done += 2
 
     # a constrained prior set: the likelihood's lowered Constraint program travels with every rank's shard
@@ -137,6 +138,7 @@ def main():
         if pool_mw.is_master():
             # (a likelihood batch first: row shards + one all-gather, served by the waiting ranks)
             assert same(pool_mw.log_likelihood_many(thetas), pool_one.log_likelihood_many(thetas))
+            assert pool_mw.log_likelihood(thetas[1]) == pool_one.log_likelihood(thetas[1])
             result_mw = nested_sampling(pool_mw, walker_mw, pt, host_ll, len(names), 300, 384, seed=13, dlogz=0.5, max_iter=20000)
     if rank == 0:
         assert result_mw["niter"] == a["niter"] and result_mw["ncall"] == a["ncall"] and result_mw["logz"] == a["logz"]
