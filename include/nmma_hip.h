@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NMMA_ABI_VERSION 7
+#define NMMA_ABI_VERSION 8
 #define NMMA_MAX_PARAMS 8      /* surrogate inputs NP (Bu2023Ye: 7; nmma/em/model.py:29-125) */
 #define NMMA_MAX_COEFF 16      /* SVD coefficients NC (reference default 10; em_parsing.py:189) */
 #define NMMA_MAX_SOURCES 3     /* model bands averaged into one observed band (utils.py:549-563) */
@@ -163,7 +163,17 @@ typedef struct nmma_em_config {
      * this handle's surrogate and ONE more transient whose source-frame curves arrive per call on the handle's own sample_times and
      * model filters (nmma_em_loglike_stack2) -- the handle is then laid out for the one-launch form of that call; 0 otherwise ---- */
     int32_t stack_operands;
-    int32_t pad_stack;
+    /* ---- ... whose sub-models bring their OWN time grids (model.py:1372-1374: the combination lives on the sorted union of the
+     * sub-models' model_times; every sub-model's curves are moved there by autocomplete_data(..., extrapolate=inf), :1440-1448):
+     * n_base_times > 0 = the surrogate's own sample_times are base_times[n_base_times] and `sample_times` above is the
+     * COMBINATION's grid.  A surrogate node on the combination's grid is np.interp between two of its own sample nodes, each of
+     * which is np.interp between two nodes of the SVD grid (lightcurve_generation.py:177) -- two static linear maps of the
+     * coefficients, folded into the likelihood task's basis rows at create; nodes outside the surrogate's own grid carry +inf (no
+     * flux).  Such a handle serves nmma_em_loglike_stack2, nmma_em_model_lightcurves (the surrogate's curves on the combination's
+     * grid), nmma_lc_regrid / nmma_lc_stack / nmma_em_loglike_lc[_sets]; the entry points that evaluate the surrogate ALONE as the
+     * likelihood's model refuse it.  Needs stack_operands = 1.  0 = the surrogate lives on sample_times itself. ---- */
+    int32_t n_base_times;
+    const double* base_times;     /* [n_base_times] strictly increasing */
 } nmma_em_config;
 
 typedef struct nmma_em_handle nmma_em_handle;
@@ -239,6 +249,10 @@ int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int6
  * re-evaluation kernel stages -- 4 x M x NS x 8 bytes within 159 KiB of LDS): the caller then takes nmma_em_model_lightcurves +
  * nmma_em_loglike_lc_sets.  Asynchronous. */
 #define NMMA_STACK2_GAP_FREE 1
+/* NMMA_STACK2_COMPLETED: lc2 has been through nmma_lc_regrid (autocomplete_data over its finite nodes already applied: interior gaps
+ * filled, +inf only before its first / after its last finite node) -- a non-finite node of lc2 then means "no flux" wherever it
+ * lies and does not send the row to the re-evaluation launch. */
+#define NMMA_STACK2_COMPLETED 2
 int32_t nmma_em_loglike_stack2(nmma_em_handle* h, const double* theta_dev, int64_t B, int64_t ld, const double* lc2_dev,
                                const uint8_t* bad_rows_dev, double* out_dev, int32_t flags, void* stream);
 

@@ -28,8 +28,9 @@ UNIT_FLAGS = {"gw_kernels.hip": ["-ffp-contract=fast"]}
 #: seconds each unit took in this process's last build_library call (tools: order SOURCES longest first)
 UNIT_SECONDS = {}
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 STACK2_GAP_FREE = 1
+STACK2_COMPLETED = 2
 MAX_PARAMS = 8
 MAX_COEFF = 16
 MAX_SOURCES = 3
@@ -87,7 +88,7 @@ class EmConfig(C.Structure):
         ("detection_limit", _pd), ("n_sources", _pi), ("sources", _pi),
         ("sys_kind", _pi), ("sys_const", _pd), ("sys_n_nodes", _pi), ("sys_slot_offsets", _pi),
         ("sys_slots", C.POINTER(Slot)), ("sys_node_times", _pd),
-        ("stack_operands", C.c_int32), ("pad_stack", C.c_int32),
+        ("stack_operands", C.c_int32), ("n_base_times", C.c_int32), ("base_times", _pd),
     ]
 
 

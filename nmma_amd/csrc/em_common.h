@@ -597,7 +597,8 @@ struct LdsW {
 // a sub-model delivered no light curve (or NULL).
 // gap_rows[B]: written by the kernel for every row -- 1 = the row met an interior non-finite node of lc2 and must be re-evaluated
 // by the materialising kernels (nmma_em_loglike_stack2 launches them restricted to those rows), 0 = out[b] is final.
-struct EmAux { const double* lc2; const unsigned char* bad_rows; unsigned char* gap_rows; };
+// completed != 0 (NMMA_STACK2_COMPLETED): lc2 came out of nmma_lc_regrid -- its non-finite nodes are leading / trailing only and mean "no flux".
+struct EmAux { const double* lc2; const unsigned char* bad_rows; unsigned char* gap_rows; int completed; };
 struct EmNoAux {};      // (what every other flavour takes in that place: their kernel arguments stay as they were)
 template <int FASTM> struct em_aux_of { typedef EmNoAux type; };
 template <> struct em_aux_of<7> { typedef EmAux type; };

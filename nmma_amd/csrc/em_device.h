@@ -135,6 +135,18 @@ struct EmDev {
     // coefficients of the extinction magnitude PER UNIT E(B-V) over the handle's redshift range (nmma_em_create: built and verified
     // against em_math.h:p92_smc_ext_mag on a dense grid; null where the range or the accuracy does not allow it: ext_tab then)
     const double* p92_cheb;   // [M][16]
+    // Combined model on a UNION grid (nmma_em_config::base_times): the surrogate lives on its own sample_times bt[NB]; a node of the
+    // handle's grid st[NS] is np.interp between two of those (autocomplete_data(..., extrapolate=inf), model.py:1440-1448), each of
+    // which is the stage-1 lerp between two SVD nodes.  The lean task has both hops in its basis rows; em_fused (curve outputs, the
+    // re-evaluation launch) evaluates them from these tables.  union_grid = 0: all null.
+    int32_t union_grid, NB;
+    const double* bt;         // [NB]      the surrogate's own sample_times
+    const int32_t* b_idx;     // [M][NB]   left node in tt of base node i (-1: outside the SVD grid)
+    const double* b_dx;       // [M][NB]   tt[a+1] - tt[a]
+    const double* b_off;      // [M][NB]   bt[i] - tt[a]
+    const int32_t* u_idx;     // [M][NS]   left base node of grid node j (-1: outside the surrogate's finite window -> +inf)
+    const double* u_dx;       // [M][NS]   bt[i+1] - bt[i]
+    const double* u_off;      // [M][NS]   st[j] - bt[i]  (0: the grid node IS base node i)
 };
 
 }  // namespace nmma

@@ -92,6 +92,11 @@ struct nmma_em_handle {
     int prof_n = 0, prof_cap = 0, prof_stride = 1, prof_group = 1;
     long prof_calls = 0;
     std::vector<int> same_grid, ranges;   // per model filter (host copies used to build item descriptors)
+    // combined model on a union grid (nmma_em_config::base_times): host copies of EmDev's b_* / u_* tables, used where the lean
+    // task's rows are built; union_only = the entry points that take the surrogate alone as the likelihood's model refuse the handle
+    std::vector<int32_t> u_idx, b_idx;
+    std::vector<double> u_dx, u_off, b_dx, b_off;
+    bool union_only = false;
     long long* dbg = nullptr;   // device buffer of in-kernel timestamps (nmma_em_debug_timeline)
     int* wd_host = nullptr;     // pinned, device-mapped watchdog words written by em_logl's hand-off waits
 };

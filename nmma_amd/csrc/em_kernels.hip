@@ -229,7 +229,25 @@ __device__ __forceinline__ void em_fused_body(
                 ext = extinction_mag(P.ext_law, ebvc, zp1, scal[s * 8 + S_EBV]);
             }
             double v = dinf();
-            if (j >= jlo && j <= jhi && jhi > jlo) {
+            if (P.union_grid) {
+                // Combined model on a union grid (nmma_em_config::base_times; the rare paths: curve outputs and the re-evaluation launch):
+                // the surrogate on its OWN sample node i (stage 1, as below), then np.interp between two of those onto grid node j
+                // (autocomplete_data(..., extrapolate=inf), model.py:1440-1448 -- nmma_lc_regrid's arithmetic); tables in global memory
+                if (j >= jlo && j <= jhi && jhi > jlo) {
+                    const double* magrow = magb + sl * NT;
+                    const int NB = P.NB;
+                    auto own_node = [&](const int i) {
+                        const int a = P.b_idx[(size_t)m * NB + i];
+                        const double of = P.b_off[(size_t)m * NB + i];
+                        if (of == 0.0 || a + 1 >= NT) return magrow[a];
+                        const double y0 = magrow[a], y1 = magrow[a + 1];
+                        return ((y1 - y0) / P.b_dx[(size_t)m * NB + i]) * of + y0;
+                    };
+                    const int i = P.u_idx[(size_t)m * NS + j];
+                    const double ya = own_node(i);
+                    v = (P.u_off[(size_t)m * NS + j] == 0.0) ? ya : lerp_np(stl[j], P.bt[i], P.bt[i + 1], ya, own_node(i + 1));
+                }
+            } else if (j >= jlo && j <= jhi && jhi > jlo) {
                 const double* magrow = magb + sl * NT;
                 const int i1 = s1i_l[j];
                 if (identity) {

@@ -1044,7 +1044,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             // it is the edge of that transient's time range -- no flux, the general form's value for (kn, +inf) -- anywhere else it
             // may be a gap that autocomplete_data fills from the transient's finite neighbours (utils.py:634-645): the sample is
             // flagged (an LDS OR issued by every lane) and re-evaluated after this launch by the kernels that materialise the curves.
+            // Union grids (nmma_em_config::base_times): the operand went through nmma_lc_regrid (aux.completed: its non-finite nodes are
+            // the ends of its time range wherever they lie -- no flux), and the KILONOVA has no value on the nodes outside its own grid
+            // (rows [0 | 1 | +inf]): the sum is then the second transient alone, the general form's value for (+inf, m2); a node where
+            // neither has a value sends the row to the re-evaluation launch.
             const double* tab2 = reinterpret_cast<const double*>(smem + L.nodes);
+            const bool completed = aux.completed != 0;
 #pragma unroll
             for (int u = 0; u < NSL; ++u) {
                 bool gap = false;
@@ -1053,10 +1058,12 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     const double kn = ynode_[e][u], m2 = g2_[u][e];
                     const int j = lo_[u] + e;
                     const bool m2_fin = (m2 - m2 == 0.0);
-                    const bool edge = !m2_fin & ((j == 0) | (j == NS - 1));
+                    const bool kn_out = kn == dinf();
+                    const bool edge = !m2_fin & (completed | (j == 0) | (j == NS - 1));
                     const double r = stack2_node(kn, m2, tab2);
-                    ynode_[e][u] = edge ? stack2_no_flux(kn) : r;
-                    gap |= !m2_fin & !edge;
+                    const double alone = stack2_no_flux(edge ? kn : m2);
+                    ynode_[e][u] = (edge | kn_out) ? alone : r;
+                    gap |= !m2_fin & (!edge | kn_out);
                 }
                 const int flag = (gap & valid_[u]) ? 1 : 0;
                 __hip_atomic_fetch_or((lds_ip)(bad + 5 * TS + s_[u]), flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

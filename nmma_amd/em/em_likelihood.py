@@ -145,10 +145,14 @@ class MultiFilterTransient:
                 # two sub-models on one grid (the reference drivers' case): ONE launch, the surrogate's curves never leave the chip
                 eng2 = self.stack2_engine(names)
                 th = th.to(f"cuda:{eng2.device}", dtype=torch.float64)
-                lc2, failed = model.second_operand(th, eng2.parameter_names, external_lc)
+                lc2, failed = model.second_operand(th, eng2.parameter_names, external_lc, stack_engine=eng2)
                 other = model.stack2_plan()[1]
-                out = eng2.loglike_stack2(th, lc2, failed, gap_free=bool(getattr(other, "batch_gap_free", False) if getattr(other, "batch_checked", False)
-                                                                        else getattr(other, "gap_free", False)))
+                base, plan2 = model.stack2_union()
+                regridded = plan2 is not None      # (own grid / filters: the operand went through regrid -- no interior gaps left)
+                # (a "no interior gaps" promise says nothing about nodes that NEITHER sub-model covers on a union grid: those rows need
+                #  the re-evaluation launch, so the promise is not forwarded there)
+                promise = bool(getattr(other, "batch_gap_free", False) if getattr(other, "batch_checked", False) else getattr(other, "gap_free", False))
+                out = eng2.loglike_stack2(th, lc2, failed, completed=regridded, gap_free=promise and base is None and not regridded)
                 if out is None:                             # (the handle has no one-launch form: decided once per likelihood)
                     self._stack2_off = True
                     self._engine2.close()

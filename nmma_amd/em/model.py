@@ -590,15 +590,30 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
 
     def stack2_plan(self):
         """``(surrogate_model, other_model)`` when the combination can be evaluated in ONE launch (``EMEngine.loglike_stack2``): two
-        sub-models that already live on the combination's grid and filters -- what the reference's drivers build, every sub-model
-        with the same ``filters`` and ``sample_times`` (model.py:1591-1614) -- one of them an SVD surrogate, whose curves then never
-        leave the chip; else None (union grids / filter lists: ``stacked_sets`` + ``EMEngine.loglike_lc_sets``)."""
-        if len(self.lc_models) != 2 or any(plan is not None for plan in self._regrid):
+        sub-models, one of them an SVD surrogate that lists every filter of the combination (in the combination's order) -- its
+        curves then never leave the chip.  Both on the combination's grid and filters is what the reference's drivers build (every
+        sub-model with the same ``filters`` and ``sample_times``, model.py:1591-1614).  Round 6: the sub-models may bring their OWN
+        time grids (model.py:1372-1374, :1440-1448) -- the surrogate's move onto the union grid is a static linear map folded into
+        the kernel's basis rows (``base_times`` of the engine), the other sub-model's curves take ``EMEngine.regrid`` (any filter
+        list: missing filters carry no flux, averaged bands their helper bands' mean) before they become the operand.  Else None
+        (a filter the surrogate does not list: ``stacked_sets`` + ``EMEngine.loglike_lc_sets``)."""
+        if len(self.lc_models) != 2:
             return None
         for i, m in enumerate(self.lc_models):
-            if isinstance(m, SVDLightCurveModel):
+            if not isinstance(m, SVDLightCurveModel):
+                continue
+            mf = list(m.gpu_filters) if hasattr(m, "gpu_filters") else list(m.filters)
+            if self._regrid[i] is None or (mf == self.filters and self._regrid[i] == [[k] for k in range(len(mf))]):
                 return m, self.lc_models[1 - i]
         return None
+
+    def stack2_union(self):
+        """``(surrogate's own sample_times or None, the other sub-model's regrid plan or None)`` of ``stack2_plan``: what differs from
+        the combination's grid / filters.  ``(None, None)``: both sub-models already live there."""
+        kn, other = self.stack2_plan()
+        i = self.lc_models.index(kn)
+        base = None if self._regrid[i] is None else np.asarray(kn.model_times, float)
+        return base, self._regrid[1 - i]
 
     def stack2_engine_kwargs(self):
         """Engine arguments of the one-launch form: the surrogate's tensors with the COMBINATION's grid, cosmology and extinction
@@ -609,13 +624,19 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         kw.pop("extinction_law", None)
         kw.update(sample_times=self.model_times, cosmo_grid=own["cosmo_grid"], device=own["device"], ebv_coeff=own["ebv_coeff"],
                   filter_nu0=own["filter_nu0"], stack_operands=1)
+        base, _ = self.stack2_union()
+        if base is not None:        # the surrogate on its own grid, the task's rows on the union grid
+            kw["base_times"] = base
         return kw
 
-    def second_operand(self, theta, names, external_lc=None):
+    def second_operand(self, theta, names, external_lc=None, stack_engine=None):
         """The other sub-model's source-frame set ``[B, M, NS]`` for ``EMEngine.loglike_stack2`` and the rows for which it
-        delivered no light curve (bool CUDA tensor or None) -- see ``stacked_sets`` for ``external_lc``."""
+        delivered no light curve (bool CUDA tensor or None) -- see ``stacked_sets`` for ``external_lc``.  A sub-model on its own
+        grid / filter list is moved onto the combination's by ``stack_engine.regrid`` (then pass ``completed=True`` to
+        ``loglike_stack2``: ``stack2_union()[1] is not None``)."""
         import torch
         _, m = self.stack2_plan()
+        _, plan = self.stack2_union()
         failed = None
         if isinstance(m, ExternalLightCurveModel):
             val = (external_lc or {})[m.model]
@@ -626,6 +647,10 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
             lc = torch.as_tensor(val).to(f"cuda:{self.device}")
         else:
             lc = m.lightcurves_abs(theta, names)
+        if plan is not None:
+            if stack_engine is None:
+                raise RuntimeError("second_operand: this combination's second sub-model lives on its own grid / filters: pass stack_engine")
+            lc = stack_engine.regrid(lc, np.asarray(m.model_times, float), plan)
         return lc, failed
 
     def stacked_sets(self, theta, names, external_lc=None, stack_engine=None):

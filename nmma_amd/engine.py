@@ -104,7 +104,7 @@ class EMEngine:
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
-                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None, stack_operands=0):
+                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None, stack_operands=0, base_times=None):
         self._handle = None
         self._host_out = {}
         lib = L.load_library()
@@ -285,6 +285,13 @@ class EMEngine:
 
         # (a combined model whose second transient arrives per call: lay the handle out for the one-launch form, ``loglike_stack2``)
         cfg.stack_operands = int(stack_operands)
+        # a combined model on a UNION grid (model.py:1372-1374): `sample_times` is the combination's grid, `base_times` the surrogate's own
+        self.base_times = None
+        if base_times is not None:
+            bt = _f64(base_times)
+            keep.append(bt)
+            cfg.n_base_times, cfg.base_times = len(bt), _ptr(bt, C.c_double)
+            self.base_times = bt
         h = C.c_void_p()
         L.check(lib.nmma_em_create(C.byref(cfg), C.byref(h)), "nmma_em_create")
         self._handle = h
@@ -476,7 +483,7 @@ class EMEngine:
                                                   self._stream()), "nmma_em_loglike_lc_sets")
         return out
 
-    def loglike_stack2(self, theta, lc2, bad_rows=None, out=None, stream=None, gap_free=False):
+    def loglike_stack2(self, theta, lc2, bad_rows=None, out=None, stream=None, gap_free=False, completed=False):
         """logL of the COMBINED model {this engine's surrogate + a second transient} in one launch: ``lc2[B, M, NS]`` are the second
         transient's source-frame curves on this engine's sample_times and model filters; the flux sum is formed on the two nodes
         every datum interpolates between (``nmma_em_loglike_stack2``).  Returns None when the handle has no one-launch form (not
@@ -484,6 +491,7 @@ class EMEngine:
         (``model_lightcurves``) and takes ``loglike_lc_sets`` on a likelihood-from-curves engine.  ``gap_free=True``: the caller guarantees
         that ``lc2`` has no non-finite node strictly inside the grid (e.g. afterglowpy curves: finite, or the row is in ``bad_rows``) --
         the re-evaluation launch is skipped; a row that breaks the promise poisons the engine (the next call raises).
+        ``completed=True``: ``lc2`` came out of ``regrid`` (its non-finite nodes are leading / trailing only: no flux wherever they lie).
         After a None, ``stack2_reason`` says why the handle has no one-launch form."""
         import torch
         t = self._dev_theta(theta)
@@ -502,7 +510,8 @@ class EMEngine:
             self._check_out(out, t.shape[0])
         status = self._lib.nmma_em_loglike_stack2(self._handle, C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0), C.c_void_p(lc2.data_ptr()),
                                                   C.c_void_p(bad.data_ptr()) if bad is not None else None, C.c_void_p(out.data_ptr()),
-                                                  L.STACK2_GAP_FREE if gap_free else 0, self._stream(stream))
+                                                  (L.STACK2_GAP_FREE if gap_free else 0) | (L.STACK2_COMPLETED if completed else 0),
+                                                  self._stream(stream))
         if status == 2:
             self.stack2_reason = L.last_error()       # why the handle has no one-launch form
             return None

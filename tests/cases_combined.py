@@ -96,3 +96,39 @@ def oracle_likelihood_union(case, use_scipy=True):
     obs = case["observed_filters"]
     return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in obs}), obs,
                                 detection_limit=np.inf, known_filters=[f for f in obs if f != "w"], use_scipy=use_scipy), grb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Own time grids (model.py:1372-1374, :1440-1448), filters the surrogate lists completely: the combination the one-launch form
+# covers since round 6 (``base_times``).  The kilonova lives on 0.1 .. 14.1 d (its SVD grid ends at 21 d), the second transient on a
+# log-spaced grid 0.25 .. 30 d that starts at 0.3 d, lacks one filter (no flux there) and has interior holes for the steeper half
+# of its slope prior; the photometry reaches beyond the kilonova's last node (flux sum = second transient alone there) and, for
+# early time shifts, beyond every node (floor).
+# ---------------------------------------------------------------------------------------------------------------
+def case_combined_owngrids(seed=9523, batch=48):
+    mp, svd = syn.make_svd_model(seed, FILTERS, model="Bu2019lm")
+    grid = syn.flat_lcdm_grid(1.0, 200.0)
+    counts = dict(syn.AT2017GFO_COUNTS)
+    counts["sdssu"] = 6
+    data = syn.make_photometry(seed + 1, svd, mp, filters=FILTERS, counts=counts, cosmo_grid=grid, t_range=(0.3, 19.0))
+    # (the filter the second transient lacks is the kilonova's alone: its epochs stay inside the kilonova's window for most time shifts)
+    keep = data[0]["2massh"] < 13.3
+    for d in data:
+        d["2massh"] = d["2massh"][keep]
+    names, theta = syn.draw_theta(seed + 2, batch, NAMES[:6])
+    rng = np.random.default_rng(seed + 3)
+    theta = np.concatenate([theta, rng.uniform(-17.5, -14.0, (batch, 1)), rng.uniform(0.8, 1.6, (batch, 1))], axis=1)
+    return dict(model="Bu2019lm", model_parameters=mp, svd=svd, filters=FILTERS, grb_filters=[f for f in FILTERS if f != "2massh"],
+                observed_filters=FILTERS, sample_times=np.arange(0.1, 14.6, 0.5), grb_times=np.geomspace(0.25, 30.0, 36),
+                grb_hole=(14, 16, 1.2), cosmo_grid=grid, data=data, names=NAMES, theta=theta)
+
+
+def oracle_likelihood_owngrids(case, use_scipy=True):
+    from oracle import nmma_oracle as orc
+    kn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=case["filters"],
+                            sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = orc.OraclePowerLawModel(case["grb_filters"], case["grb_times"], cosmo_grid=case["cosmo_grid"], hole=case.get("grb_hole"))
+    comb = orc.OracleCombinedModel([kn, grb])
+    obs = case["observed_filters"]
+    return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in obs}), obs,
+                                detection_limit=np.inf, known_filters=obs, use_scipy=use_scipy), grb

@@ -366,8 +366,9 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
     plain.close(); one.close()
 
 
-def test_union_grid_combination_keeps_the_materialising_path():
-    """Sub-models with different grids / filter lists (golden ``combined_union``) have no one-launch plan."""
+def test_union_filter_lists_keep_the_materialising_path():
+    """A combination with filters the surrogate does not list (golden ``combined_union``: a band only the second sub-model provides, an
+    averaged band) has no one-launch plan; own time grids alone do (``test_own_time_grids_go_through_the_one_launch_form``)."""
     from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
     case = cases_combined.case_combined_union()
     kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"], model_parameters=case["model_parameters"],
@@ -378,3 +379,135 @@ def test_union_grid_combination_keeps_the_materialising_path():
     same = CombinedLightCurveModelContainer([kn, ExternalLightCurveModel("PLGRB", case["filters"], case["sample_times"])],
                                             cosmo_grid=case["cosmo_grid"])
     assert same.stack2_plan() is not None and same.stack2_plan()[0] is kn
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Sub-models on their OWN time grids (model.py:1372-1374, :1440-1448): the one-launch form on the union grid (round 6; engine
+# argument ``base_times``) -- golden ``combined_owngrids`` written by the reference's own container.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _owngrids_plugin(case):
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["filters"], model_parameters=case["model_parameters"],
+                            sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", case["grb_filters"], case["grb_times"])
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(case["observed_filters"], error_budget=1.0, light_curve_times=times)
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    lik = EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors, filters=case["observed_filters"])
+    _, grb_oracle = cases_combined.oracle_likelihood_owngrids(case)
+    ext = np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), case["grb_times"])[f] for f in case["grb_filters"]])
+                    for row in case["theta"]])
+    return lik, comb, kn, ext
+
+
+def test_own_time_grids_go_through_the_one_launch_form():
+    """Golden ``combined_owngrids`` (the reference's container: kilonova on 0.1 .. 14.1 d, second transient on a log grid 0.25 .. 30 d
+    that lacks one filter and has interior holes for half of the rows; photometry beyond the kilonova's last node, and for early
+    time shifts beyond every node of the filter only the kilonova has) through the plugin: the likelihood picks the one-launch engine
+    on the UNION grid -- the surrogate's move there is in the kernel's basis rows, the operand went through ``regrid`` -- matches the
+    golden log L at 1e-6 with the same floor pattern (the floored rows meet a node NEITHER sub-model covers: the re-evaluation launch
+    decides them), and agrees with the materialising path (regrid of both sets + ``loglike_lc_sets``) to 1e-10."""
+    import torch
+    case = cases_combined.case_combined_owngrids()
+    gold = cases.load_golden("combined_owngrids")["logl"]
+    lik, comb, kn, ext = _owngrids_plugin(case)
+    assert comb.stack2_plan() is not None and comb.stack2_plan()[0] is kn
+    base, plan2 = comb.stack2_union()
+    assert np.array_equal(base, case["sample_times"]) and plan2 is not None and plan2[comb.filters.index("2massh")] == []
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None
+    assert sub._engine2.base_times is not None and sub._engine2.n_sample_times == len(comb.model_times)
+    floor = gold == FLOOR
+    assert floor.sum() >= 5 and (~floor).sum() >= 5
+    assert np.array_equal(got == FLOOR, floor)
+    err = rel_err(got[~floor], gold[~floor])
+    print(f"combined_owngrids, one launch on the union grid: max rel err {err.max():.3e}")
+    assert err.max() <= 1e-6
+    # the materialising path on the same inputs
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    assert sub._engine is not None
+    assert np.array_equal(mat == FLOOR, floor)
+    assert rel_err(got[~floor], mat[~floor]).max() <= FUSED_VS_MATERIALISED_RTOL
+    # single-sample reference API; a sub-model that reports "no light curve" for two rows
+    sub._stack2_off = False
+    ok = np.ones(len(ext), dtype=bool)
+    ok[[1, 30]] = False
+    got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": (torch.as_tensor(ext), ok)})
+    assert np.all(got2[~ok] == FLOOR) and np.array_equal(got2[ok], got[ok])
+
+
+def test_union_grid_handle_curves_and_refusals():
+    """A handle created with ``base_times``: ``model_lightcurves`` gives the surrogate's curves on the UNION grid (+inf outside its own
+    nodes) -- the kilonova engine's curves through ``regrid`` to 1e-13 -- and the entry points that would take the surrogate alone as
+    the likelihood's model refuse it; a union-grid engine on a grid that IS the surrogate's reproduces the plain one-launch form."""
+    import torch
+    from nmma_amd import _lib as L
+    from nmma_amd.engine import EMEngine
+    case = cases_combined.case_combined_owngrids()
+    union = np.array(sorted(set(case["sample_times"].tolist()) | set(case["grb_times"].tolist())))
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    one = EMEngine(case["svd"], case["filters"], case["model_parameters"], case["names"], sample_times=union, base_times=case["sample_times"],
+                   cosmo_grid=case["cosmo_grid"], data=case["data"], observed_filters=case["filters"], stack_operands=1)
+    kn = EMEngine(case["svd"], case["filters"], case["model_parameters"], case["names"], sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    own = kn.model_lightcurves(th)
+    want = one.regrid(own, case["sample_times"], [[k] for k in range(len(case["filters"]))]).cpu().numpy()
+    got = one.model_lightcurves(th).cpu().numpy()
+    fin = np.isfinite(want)
+    inside = (union >= case["sample_times"][0]) & (union <= case["sample_times"][-1])
+    assert np.array_equal(np.isfinite(got), fin) and np.array_equal(fin, np.broadcast_to(inside, fin.shape))
+    assert np.all(got[~fin] == np.inf)
+    assert np.abs(got[fin] - want[fin]).max() <= 1e-12
+    # the surrogate's own nodes carry the own-grid values themselves
+    at = np.searchsorted(union, case["sample_times"])
+    assert np.abs(got[:, :, at] - own.cpu().numpy()).max() <= 1e-12
+    for call in (lambda: one.loglike(th), lambda: one.lightcurves(th), lambda: one.loglike_parts(th)):
+        with pytest.raises(L.NMMAHipError, match="base_times"):
+            call()
+    # base_times == sample_times: the union map is the identity -- the plain one-launch form's values to a few ulp
+    c3 = cases_combined.case_combined()
+    same = EMEngine(c3["svd"], c3["filters"], c3["model_parameters"], c3["names"], sample_times=c3["sample_times"], base_times=c3["sample_times"],
+                    cosmo_grid=c3["cosmo_grid"], data=c3["data"], observed_filters=c3["filters"], stack_operands=1)
+    plain = EMEngine(c3["svd"], c3["filters"], c3["model_parameters"], c3["names"], sample_times=c3["sample_times"],
+                     cosmo_grid=c3["cosmo_grid"], data=c3["data"], observed_filters=c3["filters"], stack_operands=1)
+    _, grb_oracle = cases_combined.oracle_likelihood(c3)
+    lc2 = torch.as_tensor(np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(c3["names"], row)), c3["sample_times"])[f] for f in c3["filters"]])
+                                    for row in c3["theta"]]), device="cuda:0")
+    th3 = torch.as_tensor(c3["theta"], device="cuda:0")
+    a, b = same.loglike_stack2(th3, lc2).cpu().numpy(), plain.loglike_stack2(th3, lc2).cpu().numpy()
+    assert np.array_equal(a == FLOOR, b == FLOOR) and rel_err(a[a != FLOOR], b[b != FLOOR]).max() <= 1e-12
+    for e in (one, kn, same, plain):
+        e.close()
+
+
+def test_union_grid_one_launch_is_batch_size_independent_at_config3_size():
+    """8192 rows (32-sample tiles) against 16-sample tiles and ragged sub-batches of the same rows: the same bits; determinism."""
+    import torch
+    from nmma_amd.engine import EMEngine
+    case = cases_combined.case_combined_owngrids()
+    union = np.array(sorted(set(case["sample_times"].tolist()) | set(case["grb_times"].tolist())))
+    one = EMEngine(case["svd"], case["filters"], case["model_parameters"], case["names"], sample_times=union, base_times=case["sample_times"],
+                   cosmo_grid=case["cosmo_grid"], data=case["data"], observed_filters=case["filters"], stack_operands=1)
+    B = 8192
+    theta = _theta(77, B)
+    theta[:, 3] = np.random.default_rng(5).uniform(-1.0, 0.1, B)       # (time shifts that keep most rows off the floor)
+    _, grb_oracle = cases_combined.oracle_likelihood_owngrids(case)
+    t = case["grb_times"]
+    with np.errstate(divide="ignore"):
+        base = theta[:, 6:7] + 2.5 * theta[:, 7:8] * np.log10(t)[None, :]
+    ext = np.stack([np.where(t >= 0.3, base + 0.15 * k, np.inf) for k in range(len(case["grb_filters"]))], axis=1)
+    th = torch.as_tensor(theta, device="cuda:0")
+    plan = [[case["grb_filters"].index(f)] if f in case["grb_filters"] else [] for f in case["filters"]]
+    lc2 = one.regrid(torch.as_tensor(ext, device="cuda:0"), t, plan)
+    full = one.loglike_stack2(th, lc2, completed=True).cpu().numpy()
+    again = one.loglike_stack2(th, lc2, completed=True).cpu().numpy()
+    assert np.array_equal(full, again)
+    assert (full != FLOOR).sum() > B // 2
+    for lo, hi in ((0, 4096), (4096, 4096 + 1001), (8000, 8192)):
+        part = one.loglike_stack2(th[lo:hi], lc2[lo:hi], completed=True).cpu().numpy()
+        assert np.array_equal(part, full[lo:hi]), (lo, hi)
+    one.close()

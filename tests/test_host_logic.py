@@ -467,10 +467,22 @@ def test_combined_model_one_launch_plan_is_host_logic():
     kw = comb.stack2_engine_kwargs()
     assert kw["stack_operands"] == 1 and kw["svd_model"] is kn.svd_mag_model and np.array_equal(kw["sample_times"], st)
     assert kw["cosmo_grid"] is grid and "extinction_law" not in kw
+    assert comb.stack2_union() == (None, None) and "base_times" not in kw
+    # own time grids (round 6): still one launch -- the surrogate's own grid becomes base_times, the other sub-model's curves are regridded
     other_grid = ExternalLightCurveModel("GRB", filters, np.geomspace(0.2, 30.0, 30))
-    assert CombinedLightCurveModelContainer([kn, other_grid], cosmo_grid=grid).stack2_plan() is None
+    own = CombinedLightCurveModelContainer([kn, other_grid], cosmo_grid=grid)
+    assert own.stack2_plan() == (kn, other_grid)
+    base, plan2 = own.stack2_union()
+    assert np.array_equal(base, st) and plan2 == [[0], [1], [2]]
+    kw_own = own.stack2_engine_kwargs()
+    assert np.array_equal(kw_own["base_times"], st) and np.array_equal(kw_own["sample_times"], own.model_times) and len(own.model_times) == len(st) + 30
+    # a second sub-model that lists fewer filters: no flux there, still one launch; the surrogate already on the combination's grid
     other_filters = ExternalLightCurveModel("GRB", filters[:2], st)
-    assert CombinedLightCurveModelContainer([kn, other_filters], cosmo_grid=grid).stack2_plan() is None
+    fewer = CombinedLightCurveModelContainer([kn, other_filters], cosmo_grid=grid)
+    assert fewer.stack2_plan() == (kn, other_filters) and fewer.stack2_union()[0] is None and fewer.stack2_union()[1] == [[0], [1], []]
+    # a filter the SURROGATE does not list: the materialising path
+    more_filters = ExternalLightCurveModel("GRB", filters + ["sdssu"], st)
+    assert CombinedLightCurveModelContainer([kn, more_filters], cosmo_grid=grid).stack2_plan() is None
     assert CombinedLightCurveModelContainer([kn, grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
     assert CombinedLightCurveModelContainer([grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
 

@@ -65,3 +65,22 @@ def test_combined_union_oracle_matches_golden():
         fin = np.isfinite(want)
         assert np.array_equal(np.isfinite(lc[f]), fin)
         np.testing.assert_allclose(lc[f][fin], want[fin], rtol=1e-13)
+
+
+def test_combined_owngrids_oracle_matches_golden():
+    """Sub-models on their own time grids, all filters listed by the surrogate (the one-launch form's round-6 case)."""
+    case = cases_combined.case_combined_owngrids()
+    gold = cases.load_golden("combined_owngrids")
+    lik, _ = cases_combined.oracle_likelihood_owngrids(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:20])
+    assert np.array_equal(got == orc.LOGL_FLOOR, gold["logl"][:20] == orc.LOGL_FLOOR)
+    fin = got != orc.LOGL_FLOOR
+    np.testing.assert_allclose(got[fin], gold["logl"][:20][fin], rtol=1e-12)
+    p = lik.model.parameter_conversion(dict(zip(case["names"], (float(v) for v in case["theta"][0]))))
+    tobs, lc = lik.model.gen_detector_lc(p)
+    np.testing.assert_allclose(tobs, gold["s0_obs_times"], rtol=1e-15)
+    for f in ("ps1::g", "2massh", "sdssu"):
+        want = gold[f"s0_app_{f}"]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(lc[f]), fin)
+        np.testing.assert_allclose(lc[f][fin], want[fin], rtol=1e-13)

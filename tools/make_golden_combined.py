@@ -2,7 +2,8 @@
 """Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
 CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
 sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
-is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz."""
+is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz
+(`python tools/make_golden_combined.py combined_owngrids` writes that one alone)."""
 import os
 import sys
 
@@ -91,6 +92,9 @@ def run(case, oracle_builder, name, n_stage=3):
 
 
 def main():
+    if sys.argv[1:] == ["combined_owngrids"]:
+        run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
+        return
     case = cases_combined.case_combined()
     # (the shared-grid golden keeps its original key layout: s<i>_app_<filter index>)
     lik, comb = build_reference(case)
@@ -113,6 +117,7 @@ def main():
     run(cases_combined.case_combined_union(), cases_combined.oracle_likelihood_union, "combined_union")
     run(cases_combined.case_combined_syserr(), cases_combined.oracle_likelihood, "combined_syserr")
     run(cases_combined.case_combined_loggrid(), cases_combined.oracle_likelihood, "combined_loggrid")
+    run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
 
 
 if __name__ == "__main__":
