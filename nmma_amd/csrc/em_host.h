@@ -92,6 +92,7 @@ struct nmma_em_handle {
     int prof_n = 0, prof_cap = 0, prof_stride = 1, prof_group = 1;
     long prof_calls = 0;
     std::vector<int> same_grid, ranges;   // per model filter (host copies used to build item descriptors)
+    std::vector<double> st_host;          // host copy of EmDev::st (nmma_lc_regrid builds its bracket table against it)
     // combined model on a union grid (nmma_em_config::base_times): host copies of EmDev's b_* / u_* tables, used where the lean
     // task's rows are built; union_only = the entry points that take the surrogate alone as the likelihood's model refuse the handle
     std::vector<int32_t> u_idx, b_idx;

@@ -260,3 +260,45 @@ def test_two_model_stack_table_edges():
         got = eng.stack([torch.as_tensor(a, device="cuda:0"), torch.as_tensor(b, device="cuda:0")]).cpu().numpy()
         assert np.max(np.abs(got - want)) < 3e-14
     eng.close()
+
+
+@pytest.mark.parametrize("n_src", [36, 1100])
+def test_regrid_is_autocomplete_data_per_curve(n_src):
+    """``nmma_lc_regrid`` against the oracle's ``autocomplete_data(..., extrapolate=inf)`` (utils.py:626-645) curve by curve: random
+    source curves with holes (NaN and +inf), curves with fewer than two finite nodes, output nodes that coincide with source nodes,
+    lie before the first / after the last finite one; direct, averaged (two and three helper bands) and missing filters.  36 source
+    nodes take the kernel that keeps the source grid and curve in LDS with the static bracket table, 1100 the search through global
+    memory: bit-exact np.interp in both (``lerp_np``)."""
+    import torch
+    from nmma_amd.engine import EMEngine
+    from oracle import nmma_oracle as orc
+    rng = np.random.default_rng(100 + n_src)
+    xs = np.sort(rng.uniform(0.2, 30.0, n_src))
+    st = np.sort(np.concatenate([rng.uniform(0.05, 35.0, 60), xs[::5]]))          # (every fifth source node is an output node too)
+    filters = ["g", "r", "i", "z"]
+    eng = EMEngine(None, filters, [], ["luminosity_distance"], sample_times=st, cosmo_grid=syn.flat_lcdm_grid(1.0, 200.0), model_kind="external")
+    B, Ms = 37, 3
+    lc = rng.normal(-15.0, 2.0, (B, Ms, n_src))
+    lc[rng.uniform(size=lc.shape) < 0.15] = np.nan
+    lc[rng.uniform(size=lc.shape) < 0.05] = np.inf
+    lc[3, 1, :] = np.inf                     # no finite node
+    lc[4, 0, 1:] = np.nan                    # one finite node
+    lc[5, 2, :n_src // 2] = np.inf           # finite only in the second half
+    plan = [[0], [2, 1], [0, 1, 2], []]
+    got = eng.regrid(torch.as_tensor(lc, device="cuda:0"), xs, plan).cpu().numpy()
+    want = np.empty((B, len(filters), len(st)))
+    for b in range(B):
+        for m, src in enumerate(plan):
+            if not src:
+                want[b, m] = np.inf
+                continue
+            parts = [orc.autocomplete_data(st, xs, lc[b, k], extrapolate=np.inf) for k in src]
+            acc = parts[0]
+            for p in parts[1:]:
+                acc = acc + p
+            want[b, m] = acc if len(src) == 1 else acc / len(src)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isposinf(got), np.isposinf(want))
+    fin = np.isfinite(want)
+    assert fin.sum() > want.size // 3
+    assert np.array_equal(got[fin], want[fin])
+    eng.close()
