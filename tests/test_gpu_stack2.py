@@ -366,6 +366,52 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
     plain.close(); one.close()
 
 
+UNION_MIX_CASES = [n for n in MIX_CASES if n not in ("c2_dt05_limit", "averaging", "ncoeff7", "bulla_svd", "unobserved_filter_overflow")]
+
+
+@pytest.mark.parametrize("name", UNION_MIX_CASES)
+def test_union_grid_flavour_carries_every_feature_of_the_lean_task(name):
+    """The same on a UNION grid (engine argument ``base_times``): the handle's grid = the case's own sample_times + the midpoints of
+    every third interval + two nodes before / after them.  A lerp through extra nodes that lie ON the surrogate's piecewise-linear
+    curve changes nothing, and a second transient that is dark inside the surrogate's window and absent outside it (+inf, as ``regrid``
+    leaves it: ``completed=True``) contributes nothing -- so log L must again be the plain flavour's, to rounding; rows whose photometry
+    leaves the surrogate's window meet nodes NEITHER sub-model covers and get their floor from the re-evaluation launch."""
+    import torch
+    from nmma_amd.engine import EMEngine
+    case = (cases.CASES.get(name) or cases.SHAPE_CASES[name])()
+    plain = EMEngine.from_case(case)
+    s1 = np.asarray(plain.sample_times, float)
+    mids = 0.5 * (s1[:-1] + s1[1:])[::3]
+    extra = np.array([s1[0] - 0.013, s1[-1] + 0.4, s1[-1] + 1.7])
+    union = np.array(sorted(set(s1.tolist()) | set(mids.tolist()) | set(extra[extra > 0].tolist())))
+    one = EMEngine.from_case(dict(case, sample_times=union), stack_operands=1, base_times=s1)
+    th = torch.as_tensor(np.ascontiguousarray(case["theta"]), device="cuda:0")
+    B, M, NS = th.shape[0], len(case["model_filters"]), one.n_sample_times
+    assert NS == len(union) and NS > len(s1)
+    want = plain.loglike(th).cpu().numpy()
+    # the surrogate's own curves on the union grid say where its window is (per filter: sample_times may reach beyond the SVD grid)
+    kn_u = one.model_lightcurves(th[:1])[0]
+    faint = torch.where(torch.isfinite(kn_u), torch.full_like(kn_u, 45.0), torch.full_like(kn_u, float("inf"))).expand(B, M, NS).contiguous()
+    got = one.loglike_stack2(th, faint, completed=True)
+    assert got is not None, (name, getattr(one, "stack2_reason", None))
+    one.check()
+    got = got.cpu().numpy()
+    assert np.array_equal(got == FLOOR, want == FLOOR), name
+    fin = want > FLOOR
+    err = rel_err(got[fin], want[fin]).max() if fin.any() else 0.0
+    print(f"{name}: union-grid flavour ({len(s1)} -> {NS} nodes) with a dark second transient vs the plain flavour: max rel {err:.2e} over {int(fin.sum())} rows")
+    assert err <= 1e-11, name
+    # a second transient that is finite EVERYWHERE on the union grid but 60 mag fainter: outside the surrogate's window the flux sum is
+    # that transient alone -- a finite, absurdly faint curve: rows that were floored for leaving the window now have a (very negative) value
+    allf = torch.full((B, M, NS), 45.0, dtype=torch.float64, device="cuda:0")
+    got2 = one.loglike_stack2(th, allf, completed=True).cpu().numpy()
+    one.check()
+    assert np.array_equal(got2[fin], got[fin])
+    with pytest.raises(Exception, match="base_times"):
+        one.loglike(th)
+    plain.close(); one.close()
+
+
 def test_union_filter_lists_keep_the_materialising_path():
     """A combination with filters the surrogate does not list (golden ``combined_union``: a band only the second sub-model provides, an
     averaged band) has no one-launch plan; own time grids alone do (``test_own_time_grids_go_through_the_one_launch_form``)."""
