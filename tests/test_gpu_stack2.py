@@ -557,3 +557,39 @@ def test_union_grid_one_launch_is_batch_size_independent_at_config3_size():
         part = one.loglike_stack2(th[lo:hi], lc2[lo:hi], completed=True).cpu().numpy()
         assert np.array_equal(part, full[lo:hi]), (lo, hi)
     one.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_own_time_grids_random_grids_against_the_oracle(seed):
+    """Random pairs of grids through the plugin's one-launch form against the reference-pinned oracle's combined model: the kilonova's
+    grid equally or unequally spaced, inside the SVD grid or reaching beyond either end of it (nodes without a value), the second
+    transient's grid coarser or finer, sharing nodes with the kilonova's or not, starting before / after it, with holes for half of
+    the rows -- log L at 1e-6 with the identical floor pattern."""
+    import torch
+    from oracle import nmma_oracle as orc
+    rng = np.random.default_rng(8000 + seed)
+    case = cases_combined.case_combined_owngrids(seed=9600 + seed, batch=24)
+    kind = seed % 3
+    if kind == 0:      # equally spaced, inside the SVD grid (0 .. 21 d)
+        s1 = np.arange(0.2, 0.2 + 0.4 * rng.integers(30, 45), 0.4)
+    elif kind == 1:    # unequally spaced, reaching beyond the SVD grid's end
+        s1 = np.sort(np.unique(np.round(rng.uniform(0.05, 23.0, 40), 3)))
+    else:              # log-spaced
+        s1 = np.geomspace(0.08, 19.0, 33)
+    n2 = int(rng.integers(12, 60))
+    s2 = np.sort(np.unique(np.round(np.concatenate([rng.uniform(0.1, 28.0, n2), rng.choice(s1, 5, replace=False)]), 3)))
+    case["sample_times"], case["grb_times"] = s1, s2
+    case["grb_hole"] = (len(s2) // 3, len(s2) // 3 + 2, 1.2)
+    olik, grb_oracle = cases_combined.oracle_likelihood_owngrids(case)
+    want = orc.log_likelihood_batch(olik, case["names"], case["theta"])
+    lik, comb, kn, ext = _owngrids_plugin(case)
+    assert comb.stack2_plan() is not None
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor), (seed, np.nonzero((got == FLOOR) != floor)[0])
+    err = rel_err(got[~floor], want[~floor]).max() if (~floor).any() else 0.0
+    print(f"seed {seed}: kilonova grid {len(s1)} nodes ({s1[0]:.2f} .. {s1[-1]:.2f}), second grid {len(s2)}, union {len(comb.model_times)}; "
+          f"{int(floor.sum())} of {len(want)} rows floored; max rel err {err:.2e}")
+    assert err <= 1e-6
