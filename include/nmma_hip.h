@@ -174,6 +174,13 @@ typedef struct nmma_em_config {
      * likelihood's model refuse it.  Needs stack_operands = 1.  0 = the surrogate lives on sample_times itself. ---- */
     int32_t n_base_times;
     const double* base_times;     /* [n_base_times] strictly increasing */
+    /* ---- ... and whose surrogate has NOTHING for some of the combination's filters -- calc_svd_lc's null output "for other
+     * filters, especially radio and X-ray filters when using with GRB data" (lightcurve_generation.py:168-169: +inf on every node):
+     * null_filters[m] != 0 marks model filter m as such.  Its surrogate tensors are ignored (pass zeros of the common shapes); its
+     * curve is +inf everywhere, so in nmma_em_loglike_stack2 the flux sum of that band is the second transient alone, and a
+     * likelihood that takes the surrogate alone floors every sample whose photometry includes the band, as the reference does
+     * (sanity_check, em_likelihood.py:305-311).  NULL = every model filter has a surrogate.  Needs stack_operands = 1. ---- */
+    const int32_t* null_filters;  /* [M] or NULL */
 } nmma_em_config;
 
 typedef struct nmma_em_handle nmma_em_handle;

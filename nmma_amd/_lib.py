@@ -88,7 +88,7 @@ class EmConfig(C.Structure):
         ("detection_limit", _pd), ("n_sources", _pi), ("sources", _pi),
         ("sys_kind", _pi), ("sys_const", _pd), ("sys_n_nodes", _pi), ("sys_slot_offsets", _pi),
         ("sys_slots", C.POINTER(Slot)), ("sys_node_times", _pd),
-        ("stack_operands", C.c_int32), ("n_base_times", C.c_int32), ("base_times", _pd),
+        ("stack_operands", C.c_int32), ("n_base_times", C.c_int32), ("base_times", _pd), ("null_filters", _pi),
     ]
 
 

@@ -109,7 +109,8 @@ class MultiFilterTransient:
                 self._engine2.close()
             model = self.light_curve_model
             kn, _ = model.stack2_plan()
-            self._engine2 = self._build_engine(names, kn.gpu_filters, model.stack2_engine_kwargs())
+            kw = model.stack2_engine_kwargs()
+            self._engine2 = self._build_engine(names, kw["model_filters"], kw)
             self._names2 = names
         return self._engine2
 

@@ -602,8 +602,9 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         for i, m in enumerate(self.lc_models):
             if not isinstance(m, SVDLightCurveModel):
                 continue
-            mf = list(m.gpu_filters) if hasattr(m, "gpu_filters") else list(m.filters)
-            if self._regrid[i] is None or (mf == self.filters and self._regrid[i] == [[k] for k in range(len(mf))]):
+            # (the filters the model LISTS: one without a surrogate is its null output -- +inf on every node, "radio and X-ray filters
+            #  when using with GRB data", lightcurve_generation.py:168-169 -- and rides along as a null filter of the engine)
+            if list(m.filters) == self.filters and len(m.gpu_filters) > 0:
                 return m, self.lc_models[1 - i]
         return None
 
@@ -612,8 +613,8 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         the combination's grid / filters.  ``(None, None)``: both sub-models already live there."""
         kn, other = self.stack2_plan()
         i = self.lc_models.index(kn)
-        base = None if self._regrid[i] is None else np.asarray(kn.model_times, float)
-        return base, self._regrid[1 - i]
+        same_times = np.array_equal(np.asarray(kn.model_times, float), self.model_times)
+        return (None if same_times else np.asarray(kn.model_times, float)), self._regrid[1 - i]
 
     def stack2_engine_kwargs(self):
         """Engine arguments of the one-launch form: the surrogate's tensors with the COMBINATION's grid, cosmology and extinction
@@ -627,6 +628,15 @@ class CombinedLightCurveModelContainer(_TensorModelMixin):
         base, _ = self.stack2_union()
         if base is not None:        # the surrogate on its own grid, the task's rows on the union grid
             kw["base_times"] = base
+        # every filter the combination lists is a model filter of the engine; those without a surrogate as null filters
+        kw["model_filters"] = list(self.filters)
+        null = [f for f in self.filters if f not in kn.svd_mag_model]
+        if null:
+            kw["null_filters"] = null
+            if kw.get("filter_nu0") is not None and any(f not in kw["filter_nu0"] for f in null):
+                kw["filter_nu0"] = dict(kw["filter_nu0"], **{f: 1.0 for f in null if f not in kw["filter_nu0"]})
+            if kw.get("ebv_coeff") is not None:
+                kw["ebv_coeff"] = dict(kw["ebv_coeff"], **{f: 0.0 for f in null if f not in kw["ebv_coeff"]})
         return kw
 
     def second_operand(self, theta, names, external_lc=None, stack_engine=None):

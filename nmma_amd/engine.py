@@ -104,7 +104,8 @@ class EMEngine:
     def __init__(self, svd_model, model_filters, model_parameters, parameter_names, fixed=None,
                  sample_times=None, cosmo_grid=None, data=None, observed_filters=(), sources=None,
                  detection_limit=None, systematics=None, ebv_coeff=None, device=0, n_coeff=None,
-                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None, stack_operands=0, base_times=None):
+                 model_kind="svd", filter_nu0=None, extinction_law=None, hubble_reference=None, stack_operands=0, base_times=None,
+                 null_filters=()):
         self._handle = None
         self._host_out = {}
         lib = L.load_library()
@@ -125,7 +126,23 @@ class EMEngine:
         cfg.abi_version, cfg.device = L.ABI_VERSION, self.device
         cfg.model_kind = kinds[model_kind]
         cfg.n_model_filters = len(model_filters)
+        # model filters the surrogate has nothing for (calc_svd_lc's null output for "radio and X-ray filters when using with GRB data",
+        # lightcurve_generation.py:168-169): +inf on every node.  Only inside a combination (stack_operands=1); the library ignores
+        # their tensors -- zeros of the common shapes stand in
+        null_filters = [f for f in model_filters if f in set(null_filters)]
+        self.null_filters = null_filters
         if model_kind == "svd":
+            if null_filters:
+                real = [f for f in model_filters if f not in null_filters]
+                if not real:
+                    raise L.NMMAHipError("every model filter is a null filter: the surrogate contributes nothing")
+                tmpl = svd_model[real[0]]
+                blank = dict(tmpl)
+                for k in ("W1", "b1", "W2", "b2", "VA"):
+                    blank[k] = np.zeros_like(np.asarray(tmpl[k]))
+                svd_model = dict(svd_model)
+                for f in null_filters:
+                    svd_model[f] = blank
             first = svd_model[model_filters[0]]
             n_p = int(np.asarray(first["W1"]).shape[0])
             n_h = int(np.asarray(first["W1"]).shape[1])
@@ -286,6 +303,10 @@ class EMEngine:
         # (a combined model whose second transient arrives per call: lay the handle out for the one-launch form, ``loglike_stack2``)
         cfg.stack_operands = int(stack_operands)
         # a combined model on a UNION grid (model.py:1372-1374): `sample_times` is the combination's grid, `base_times` the surrogate's own
+        if null_filters:
+            nf = np.ascontiguousarray([1 if f in null_filters else 0 for f in model_filters], dtype=np.int32)
+            keep.append(nf)
+            cfg.null_filters = _ptr(nf, C.c_int32)
         self.base_times = None
         if base_times is not None:
             bt = _f64(base_times)

@@ -132,3 +132,38 @@ def oracle_likelihood_owngrids(case, use_scipy=True):
     obs = case["observed_filters"]
     return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in obs}), obs,
                                 detection_limit=np.inf, known_filters=obs, use_scipy=use_scipy), grb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Null filters (lightcurve_generation.py:168-169: "null output for other filters, especially radio and X-ray filters when using
+# with GRB data"): the drivers' shared grid and filter list (config 3's shape), two of the listed filters without a surrogate --
+# the kilonova is +inf there on every node and the band's curve is the afterglow's alone.
+# ---------------------------------------------------------------------------------------------------------------
+NULL_FILTERS = ["radio-3GHz", "X-ray-1keV"]
+
+
+def case_combined_nullfilters(seed=9723, batch=40):
+    c = case_combined(seed=seed, batch=batch)
+    rng = np.random.default_rng(seed + 7)
+    times, mags, sigmas = ({k: v for k, v in d.items()} for d in c["data"])
+    for k, f in enumerate(NULL_FILTERS):
+        n = 7 + 4 * k
+        t = np.sort(rng.uniform(0.6, 13.0, n))
+        sig = rng.uniform(0.05, 0.2, n)
+        m = -16.0 + 2.5 * 1.2 * np.log10(t) + 0.15 * (len(FILTERS) + k) + 5.0 * (5 + np.log10(40.0)) + sig * rng.standard_normal(n)
+        times[f], mags[f], sigmas[f] = t, m, sig
+    sigmas["X-ray-1keV"][2] = np.inf            # (an upper limit in a band only the afterglow has)
+    c["data"] = (times, mags, sigmas)
+    c["all_filters"] = FILTERS + NULL_FILTERS
+    c["grb_hole"] = (9, 12, 1.2)
+    return c
+
+
+def oracle_likelihood_nullfilters(case, use_scipy=True):
+    from oracle import nmma_oracle as orc
+    allf = case["all_filters"]
+    kn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=allf, sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    grb = orc.OraclePowerLawModel(allf, case["sample_times"], cosmo_grid=case["cosmo_grid"], hole=case.get("grb_hole"))
+    comb = orc.OracleCombinedModel([kn, grb])
+    return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in allf}), allf,
+                                detection_limit=np.inf, known_filters=allf, use_scipy=use_scipy), grb

@@ -593,3 +593,91 @@ def test_own_time_grids_random_grids_against_the_oracle(seed):
     print(f"seed {seed}: kilonova grid {len(s1)} nodes ({s1[0]:.2f} .. {s1[-1]:.2f}), second grid {len(s2)}, union {len(comb.model_times)}; "
           f"{int(floor.sum())} of {len(want)} rows floored; max rel err {err:.2e}")
     assert err <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Null filters: bands the surrogate LISTS without having a network for them (lightcurve_generation.py:168-169, "radio and X-ray filters
+# when using with GRB data") -- golden ``combined_nullfilters`` written by the reference's own container.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _nullfilters_plugin(case, kn_times=None):
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    allf = case["all_filters"]
+    kn = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=allf, model_parameters=case["model_parameters"],
+                            sample_times=case["sample_times"] if kn_times is None else kn_times, cosmo_grid=case["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", allf, case["sample_times"])
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(allf, error_budget=1.0, light_curve_times=times)
+    priors = {n: SimplePrior(0.0, 1.0) for n in case["names"]}
+    lik = EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors, filters=allf)
+    _, grb_oracle = cases_combined.oracle_likelihood_nullfilters(case)
+    ext = np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), case["sample_times"])[f] for f in allf])
+                    for row in case["theta"]])
+    return lik, comb, kn, ext
+
+
+def test_null_filters_go_through_the_one_launch_form():
+    """Golden ``combined_nullfilters`` (the reference's container on the drivers' shared grid; 9 optical filters + a radio and an X-ray band
+    the kilonova lists but has no network for; holes in the afterglow's curves for the steeper half of the slope prior; an upper limit in
+    the X-ray band) through the plugin: ONE launch -- the null filters are model filters of the engine whose rows give +inf, so the
+    band's flux sum is the afterglow alone -- log L at 1e-6, and the materialising path on the same inputs agrees to 1e-10."""
+    import torch
+    case = cases_combined.case_combined_nullfilters()
+    gold = cases.load_golden("combined_nullfilters")["logl"]
+    lik, comb, kn, ext = _nullfilters_plugin(case)
+    assert comb.stack2_plan() is not None and comb.stack2_plan()[0] is kn and comb.stack2_union() == (None, None)
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    assert sub._engine2.null_filters == cases_combined.NULL_FILTERS and len(sub._engine2.model_filters) == 11
+    assert not np.any(got == FLOOR) and not np.any(gold == FLOOR)
+    err = rel_err(got, gold)
+    print(f"combined_nullfilters, one launch: max rel err {err.max():.3e}")
+    assert err.max() <= 1e-6
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    assert sub._engine is not None and rel_err(mat, gold).max() <= 1e-6
+    assert rel_err(got, mat).max() <= FUSED_VS_MATERIALISED_RTOL
+    # the engine's curve outputs: +inf on every node of a null filter; the plain likelihood entry points refuse the handle
+    from nmma_amd import _lib as L
+    th = torch.as_tensor(case["theta"], device="cuda:0")
+    lc = sub._engine2.model_lightcurves(th).cpu().numpy()
+    assert np.all(lc[:, 9:, :] == np.inf) and np.all(np.isfinite(lc[:, :9, :]))
+    with pytest.raises(L.NMMAHipError, match="null_filters|base_times"):
+        sub._engine2.loglike(th)
+    # a band where the AFTERGLOW has no value either (a row whose X-ray curve is gone): nothing covers the photometry -> floor
+    ext2 = ext.copy()
+    ext2[5, 10, :] = np.inf
+    got2 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext2)})
+    sub._stack2_off = False
+    got3 = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext2)})
+    assert got2[5] == FLOOR and got3[5] == FLOOR
+    keep = np.arange(len(got)) != 5
+    assert np.array_equal(got3[keep], got[keep])
+
+
+def test_null_filters_on_own_time_grids():
+    """Both extensions together: null filters AND the kilonova on its own (coarser) grid -- against the oracle's combined model."""
+    import torch
+    from oracle import nmma_oracle as orc
+    case = cases_combined.case_combined_nullfilters(batch=24)
+    kn_times = np.arange(0.1, 18.0, 0.8)
+    allf = case["all_filters"]
+    okn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=allf, sample_times=kn_times, cosmo_grid=case["cosmo_grid"])
+    ogrb = orc.OraclePowerLawModel(allf, case["sample_times"], cosmo_grid=case["cosmo_grid"], hole=case.get("grb_hole"))
+    olik = orc.OracleLikelihood(orc.OracleCombinedModel([okn, ogrb]), case["data"], dict(mode="budget", values={f: 1.0 for f in allf}), allf,
+                                detection_limit=np.inf, known_filters=allf, use_scipy=True)
+    want = orc.log_likelihood_batch(olik, case["names"], case["theta"])
+    lik, comb, kn, ext = _nullfilters_plugin(case, kn_times=kn_times)
+    base, plan2 = comb.stack2_union()
+    assert np.array_equal(base, kn_times) and plan2 is not None
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": torch.as_tensor(ext)})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    floor = want == FLOOR
+    assert np.array_equal(got == FLOOR, floor)
+    err = rel_err(got[~floor], want[~floor]).max()
+    print(f"null filters on own grids: {int(floor.sum())} rows floored, max rel err {err:.2e}")
+    assert err <= 1e-6

@@ -483,6 +483,14 @@ def test_combined_model_one_launch_plan_is_host_logic():
     # a filter the SURROGATE does not list: the materialising path
     more_filters = ExternalLightCurveModel("GRB", filters + ["sdssu"], st)
     assert CombinedLightCurveModelContainer([kn, more_filters], cosmo_grid=grid).stack2_plan() is None
+    # ... but a filter it LISTS without having a network for it (calc_svd_lc's null output for radio / X-ray bands,
+    # lightcurve_generation.py:168-169) rides along as a null filter of the one-launch engine
+    kn_x = SVDLightCurveModel("Bu2019lm", svd_mag_model=svd, filters=filters + ["X-ray-1keV"], model_parameters=mp, sample_times=st, cosmo_grid=grid)
+    grb_x = ExternalLightCurveModel("GRB", filters + ["X-ray-1keV"], st)
+    joint = CombinedLightCurveModelContainer([kn_x, grb_x], cosmo_grid=grid)
+    assert joint.stack2_plan() == (kn_x, grb_x) and joint.stack2_union() == (None, None)
+    kw_x = joint.stack2_engine_kwargs()
+    assert kw_x["model_filters"] == filters + ["X-ray-1keV"] and kw_x["null_filters"] == ["X-ray-1keV"] and "base_times" not in kw_x
     assert CombinedLightCurveModelContainer([kn, grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
     assert CombinedLightCurveModelContainer([grb, ExternalLightCurveModel("SN", filters, st)], cosmo_grid=grid).stack2_plan() is None
 

@@ -84,3 +84,12 @@ def test_combined_owngrids_oracle_matches_golden():
         fin = np.isfinite(want)
         assert np.array_equal(np.isfinite(lc[f]), fin)
         np.testing.assert_allclose(lc[f][fin], want[fin], rtol=1e-13)
+
+
+def test_combined_nullfilters_oracle_matches_golden():
+    """Filters the surrogate lists without having a network for them (calc_svd_lc's null output): the band is the afterglow's alone."""
+    case = cases_combined.case_combined_nullfilters()
+    gold = cases.load_golden("combined_nullfilters")
+    lik, _ = cases_combined.oracle_likelihood_nullfilters(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
+    np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)

@@ -2,8 +2,8 @@
 """Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
 CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
 sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
-is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz
-(`python tools/make_golden_combined.py combined_owngrids` writes that one alone)."""
+is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz, combined_nullfilters.npz
+(`python tools/make_golden_combined.py combined_owngrids` / `combined_nullfilters` writes that one alone)."""
 import os
 import sys
 
@@ -22,10 +22,12 @@ def build_reference(case):
     """(likelihood, combined model) built from the reference's own classes for a tests.cases_combined case
     (shared grid / filters, or -- keys grb_filters, grb_times, observed_filters -- the general union case)."""
     ref = ref_harness.reference_modules()
-    grb_filters = list(case.get("grb_filters", case["filters"]))
+    # (key all_filters: both sub-models LIST these filters, the surrogate has a network for case["filters"] only -- null output for the rest)
+    listed = list(case.get("all_filters", case["filters"]))
+    grb_filters = list(case.get("grb_filters", listed))
     grb_times = case.get("grb_times", case["sample_times"])
-    obs_filters = list(case.get("observed_filters", case["filters"]))
-    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in set(case["filters"]) | set(grb_filters)
+    obs_filters = list(case.get("observed_filters", listed))
+    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in set(listed) | set(grb_filters)
                                                    if n not in ("w", "o", "c", "V", "I", "F606W", "F814W")]
     ref.utils.M4OPT_INSTALLED = False
     grid = case["cosmo_grid"]
@@ -37,9 +39,9 @@ def build_reference(case):
         d = {k: t[k] for k in ("param_mins", "param_maxs", "mins", "maxs", "tt", "n_coeff", "VA")}
         d["model"] = _KerasStandIn(t)
         svd_ref[f] = d
-    kn.model, kn.model_parameters, kn.filters = case["model"], list(case["model_parameters"]), list(case["filters"])
+    kn.model, kn.model_parameters, kn.filters = case["model"], list(case["model_parameters"]), list(listed)
     kn.svd_mag_model, kn.mag_ncoeff, kn.lbol_ncoeff, kn.good_parameters = svd_ref, None, None, True
-    kn.default_filts, kn.lambdas, kn.nu_0s = list(case["filters"]), np.ones(len(case["filters"])), np.ones(len(case["filters"]))
+    kn.default_filts, kn.lambdas, kn.nu_0s = list(listed), np.ones(len(listed)), np.ones(len(listed))
     kn.model_times, kn.redshift_func = case["sample_times"], zfun
     kn.check_vs_priors = lambda priors: None
 
@@ -95,6 +97,9 @@ def main():
     if sys.argv[1:] == ["combined_owngrids"]:
         run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
         return
+    if sys.argv[1:] == ["combined_nullfilters"]:
+        run(cases_combined.case_combined_nullfilters(), cases_combined.oracle_likelihood_nullfilters, "combined_nullfilters")
+        return
     case = cases_combined.case_combined()
     # (the shared-grid golden keeps its original key layout: s<i>_app_<filter index>)
     lik, comb = build_reference(case)
@@ -118,6 +123,7 @@ def main():
     run(cases_combined.case_combined_syserr(), cases_combined.oracle_likelihood, "combined_syserr")
     run(cases_combined.case_combined_loggrid(), cases_combined.oracle_likelihood, "combined_loggrid")
     run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
+    run(cases_combined.case_combined_nullfilters(), cases_combined.oracle_likelihood_nullfilters, "combined_nullfilters")
 
 
 if __name__ == "__main__":
