@@ -133,3 +133,55 @@ def test_em_likelihood_run_is_the_same_run_through_the_library_queue(torch_cuda)
     assert a["niter"] == b["niter"] and a["ncall"] == b["ncall"] and a["logz"] == b["logz"]
     assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["samples"], b["samples"])
     assert np.isfinite(a["logz"]) and a["info"] > 5.0 and a["niter"] > 400 * 5
+
+
+def test_em_likelihood_evidence_matches_a_quadrature_of_the_same_likelihood(torch_cuda):
+    """An anchor that does not come from the sampler: BASELINE config 2's likelihood with four parameters pinned by delta priors and
+    the two ejecta masses sampled under uniform priors.  The evidence is then a two-dimensional integral that the batch path evaluates
+    directly -- the mean of L over a 1024 x 1024 midpoint grid of the prior box (one million evaluations, converged against 512 x 512) --
+    and the nested-sampling run through ``GPUPool.map`` (device walk, library queue) has to land within 3 sigma of it and reproduce the
+    posterior mean of the grid."""
+    torch = torch_cuda
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    from tests.helpers import SimplePrior
+    case = syn.config2_case()
+    box = {"log10_mej_dyn": (-3.0, -1.7), "log10_mej_wind": (-3.0, -1.0)}
+    pinned = dict(luminosity_distance=40.0, KNphi=30.0, inclination_EM=np.deg2rad(25.0), timeshift=0.0)
+    priors = {k: SimplePrior(peak=v) for k, v in pinned.items()}
+    priors.update({k: UniformPrior(a, b) for k, (a, b) in box.items()})
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=case["model_filters"], model_parameters=case["model_parameters"],
+                               sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    kw = case["systematics_ref"]
+    handler = FilterSystematicsHandler(case["observed_filters"], systematics_file=kw["systematics_file"], error_budget=kw["error_budget"],
+                                       light_curve_times=times)
+    lik = EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, priors, filters=case["observed_filters"],
+                                detection_limit=case["detection_limit"])
+    names = list(box)
+    assert lik.parameter_names() == names
+
+    def quadrature(n):
+        ax = [a + (b - a) * (np.arange(n) + 0.5) / n for a, b in box.values()]
+        g = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 2)
+        ll = lik.log_likelihood_batch(torch.as_tensor(g, device="cuda:0"), names).cpu().numpy()
+        m = ll.max()
+        w = np.exp(ll - m)
+        return float(m + np.log(w.mean())), (w[:, None] * g).sum(axis=0) / w.sum()
+    z_half, _ = quadrature(512)
+    z_quad, mean_quad = quadrature(1024)
+    assert abs(z_quad - z_half) < 1e-3, (z_quad, z_half)
+    pri = {k: priors[k] for k in names}
+    pt = smp.BatchedPriorTransform(pri, names)
+    pool = GPUPool(lik, queue_size=256, names=names, prior_transform_many=pt, priors=pri)
+    walker = smp.EnsembleWalkSampler(ndim=2, naccept=20, walks=25, maxmcmc=2000)
+    res = nested_sampling(pool, walker, pt, lambda v: lik.log_likelihood_batch(np.ascontiguousarray(v), names), 2, 600, 256, seed=23, dlogz=0.01)
+    print(f"config-2 likelihood, two sampled masses: ln Z = {res['logz']:.3f} +/- {res['logz_err']:.3f} by nested sampling, {z_quad:.3f} by quadrature "
+          f"(512^2: {z_half:.3f}); H = {res['info']:.2f}, {res['niter']} iterations, {res['ncall']} calls in {res['n_queues']} queues")
+    assert pool.n_batches > 0 and res["n_queues"] > 5
+    assert abs(res["logz"] - z_quad) < 3.0 * res["logz_err"] and res["logz_err"] < 0.2
+    w, s = res["weights"], res["samples"]
+    mean = np.sum(w[:, None] * s, axis=0)
+    std = np.sqrt(np.sum(w[:, None] * (s - mean) ** 2, axis=0))
+    assert np.all(np.abs(mean - mean_quad) < 0.25 * std + 1e-3), (mean, mean_quad, std)
