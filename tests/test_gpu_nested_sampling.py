@@ -63,7 +63,7 @@ def nested_sampling(pool, walker, prior_transform, loglike_host, ndim, nlive, qu
     w = np.exp(dead_logwt - logz)
     info = float(np.sum(w * dead_l) - logz)                    # H = int p ln(L / Z)
     return dict(logz=float(logz), logz_err=float(np.sqrt(max(info, 0.0) / nlive)), info=info, niter=it, ncall=int(ncall), weights=w, samples=dead_v,
-                n_queues=n_queues, walks=float(walker.walks))
+                n_queues=n_queues, walks=float(getattr(walker, "walks", 0) or 0))
 
 
 @pytest.fixture(scope="module")
@@ -135,8 +135,10 @@ def test_em_likelihood_run_is_the_same_run_through_the_library_queue(torch_cuda)
     assert np.isfinite(a["logz"]) and a["info"] > 5.0 and a["niter"] > 400 * 5
 
 
-def test_em_likelihood_evidence_matches_a_quadrature_of_the_same_likelihood(torch_cuda):
-    """An anchor that does not come from the sampler: BASELINE config 2's likelihood with four parameters pinned by delta priors and
+@pytest.mark.parametrize("method", ["acceptance-walk", "rwalk", "act-walk"])
+def test_em_likelihood_evidence_matches_a_quadrature_of_the_same_likelihood(torch_cuda, method):
+    """An anchor that does not come from the sampler, for each of the three walker objects the reference builds by name
+    (nmma/core/mpi_setup.py:202-245: acceptance-walk and rwalk run on the device, act-walk on the host): BASELINE config 2's likelihood with four parameters pinned by delta priors and
     the two ejecta masses sampled under uniform priors.  The evidence is then a two-dimensional integral that the batch path evaluates
     directly -- the mean of L over a 1024 x 1024 midpoint grid of the prior box (one million evaluations, converged against 512 x 512) --
     and the nested-sampling run through ``GPUPool.map`` (device walk, library queue) has to land within 3 sigma of it and reproduce the
@@ -175,9 +177,11 @@ def test_em_likelihood_evidence_matches_a_quadrature_of_the_same_likelihood(torc
     pri = {k: priors[k] for k in names}
     pt = smp.BatchedPriorTransform(pri, names)
     pool = GPUPool(lik, queue_size=256, names=names, prior_transform_many=pt, priors=pri)
-    walker = smp.EnsembleWalkSampler(ndim=2, naccept=20, walks=25, maxmcmc=2000)
+    walker = {"acceptance-walk": lambda: smp.EnsembleWalkSampler(ndim=2, naccept=20, walks=25, maxmcmc=2000),
+              "rwalk": lambda: smp.AcceptanceTrackingRWalk(ndim=2, nact=10, maxmcmc=2000),
+              "act-walk": lambda: smp.ACTTrackingEnsembleWalk(ndim=2, nact=2, maxmcmc=2000)}[method]()
     res = nested_sampling(pool, walker, pt, lambda v: lik.log_likelihood_batch(np.ascontiguousarray(v), names), 2, 600, 256, seed=23, dlogz=0.01)
-    print(f"config-2 likelihood, two sampled masses: ln Z = {res['logz']:.3f} +/- {res['logz_err']:.3f} by nested sampling, {z_quad:.3f} by quadrature "
+    print(f"config-2 likelihood, two sampled masses, {method}: ln Z = {res['logz']:.3f} +/- {res['logz_err']:.3f} by nested sampling, {z_quad:.3f} by quadrature "
           f"(512^2: {z_half:.3f}); H = {res['info']:.2f}, {res['niter']} iterations, {res['ncall']} calls in {res['n_queues']} queues")
     assert pool.n_batches > 0 and res["n_queues"] > 5
     assert abs(res["logz"] - z_quad) < 3.0 * res["logz_err"] and res["logz_err"] < 0.2
