@@ -115,8 +115,17 @@ class MultiFilterTransient:
         return self._engine2
 
     # ---- evaluation -------------------------------------------------------------------
+    def _null_model_filters(self):
+        """Filters a single surrogate model lists without having a network for them (not for combinations)."""
+        model = self.light_curve_model
+        if hasattr(model, "stacked_lightcurves_abs") or not hasattr(model, "svd_mag_model"):
+            return []
+        return [f for f in (model.filters or []) if f not in model.svd_mag_model]
+
     def log_likelihood(self, parameters):
         """One parameter dict -> float (em_likelihood.py:186-204)."""
+        if self._null_model_filters():
+            return -np.inf
         names = self._names or self.sampling_layout()[0]
         names = [n for n in names if n in parameters] if self._names is None else names
         if hasattr(self.light_curve_model, "stacked_lightcurves_abs"):      # a combined model: the batched path with one row
@@ -134,6 +143,18 @@ class MultiFilterTransient:
         keys) -> logL[B] with the reference's floor already applied.  For combined models
         ``external_lc`` maps external sub-model names to their light-curve tensors."""
         model = self.light_curve_model
+        null = self._null_model_filters()
+        if null:
+            # the model LISTS filters its surrogate has nothing for: calc_svd_lc answers +inf on every node (lightcurve_generation.py:168-169)
+            # and sanity_check fails for every sample (em_likelihood.py:305-311) -- the reference's floor, without a launch.  (Inside
+            # a combination the same filters are fine: the other sub-model's flux is the band's curve.)
+            try:
+                import torch
+                if isinstance(theta, torch.Tensor):
+                    return torch.full((theta.shape[0],), LOGL_FLOOR, dtype=torch.float64, device=theta.device)
+            except ImportError:
+                pass
+            return np.full(len(np.asarray(theta)), LOGL_FLOOR)
         if hasattr(model, "stacked_lightcurves_abs"):       # CombinedLightCurveModelContainer
             import torch
             th = torch.as_tensor(np.asarray(theta)) if not isinstance(theta, torch.Tensor) else theta

@@ -647,3 +647,32 @@ def test_filters_and_detection_limits_from_driver_arguments():
             assert got == outcome(ref.create_detection_limit, types.SimpleNamespace(**vars(ns)), filt), f
     lim = amd.create_detection_limit(types.SimpleNamespace(detection_limit=None, em_detectors="ztf", rubin_ToO_type=None), filt, 30.0)
     assert lim["ztfg"] == 21.7 and lim["ps1::g"] == 30.0 and lim["ztfi"] == 20.9
+
+
+def test_single_model_that_lists_a_filter_without_a_network_floors_every_sample():
+    """A surrogate model that LISTS a filter it has no network for answers +inf on every node (calc_svd_lc's null output,
+    lightcurve_generation.py:168-169) and ``sanity_check`` (em_likelihood.py:305-311) then fails for every sample: the reference's
+    likelihood is the floor whatever the parameters (re-checked against the reference itself in tests/test_oracle_vs_reference.py).
+    The plugin answers the same without touching the device; inside a combination the same filters are legitimate (null filters of
+    the one-launch engine, tests/test_gpu_stack2.py)."""
+    from nmma_amd import synthetic as syn
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    from oracle import nmma_oracle as orc
+    from tests.helpers import SimplePrior
+    case = syn.config2_case()
+    allf = list(case["model_filters"]) + ["X-ray-1keV"]
+    okn = orc.OracleSVDModel(case["model_parameters"], case["svd"], filters=allf, sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    olik = orc.OracleLikelihood(okn, case["data"], dict(mode="budget", values={f: 1.0 for f in case["observed_filters"]}), case["observed_filters"],
+                                detection_limit=np.inf, known_filters=allf, use_scipy=True)
+    assert np.all(orc.log_likelihood_batch(olik, case["names"], case["theta"][:8]) == orc.LOGL_FLOOR)
+    model = SVDLightCurveModel(case["model"], svd_mag_model=case["svd"], filters=allf, model_parameters=case["model_parameters"],
+                               sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"])
+    times, mags, sigmas = case["data"]
+    handler = FilterSystematicsHandler(case["observed_filters"], error_budget=1.0, light_curve_times=times)
+    lik = EMTransientLikelihood(model, (times, mags, sigmas, 0.0), handler, {n: SimplePrior(0.0, 1.0) for n in case["names"]},
+                                filters=case["observed_filters"])
+    got = lik.log_likelihood_batch(case["theta"][:8], case["names"])
+    assert got.shape == (8,) and np.all(got == orc.LOGL_FLOOR)
+    assert lik.sub_model.log_likelihood(dict(zip(case["names"], map(float, case["theta"][0])))) == -np.inf

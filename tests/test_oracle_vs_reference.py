@@ -80,3 +80,34 @@ def test_reference_reproduces_combined_nullfilters_golden():
     lik, _ = build_reference(case)
     got = _rows(lik, case["names"], case["theta"])
     np.testing.assert_allclose(got, cases.load_golden("combined_nullfilters")["logl"], rtol=1e-13)
+
+
+def test_reference_floors_a_single_model_that_lists_a_filter_without_a_network():
+    """calc_svd_lc's null output (+inf on every node) fails sanity_check for every sample: what the plugin answers for such a model."""
+    from nmma_amd import synthetic as syn
+    from oracle import ref_harness
+    from tools.make_golden import _KerasStandIn
+    case = syn.config2_case()
+    allf = list(case["model_filters"]) + ["X-ray-1keV"]
+    ref = ref_harness.reference_modules()
+    ref.utils.get_all_bandpass_metadata = lambda: [{"name": n} for n in allf]
+    ref.utils.M4OPT_INSTALLED = False
+    grid = case["cosmo_grid"]
+    m = object.__new__(ref.model.SVDLightCurveModel)
+    svd_ref = {}
+    for f, t in case["svd"].items():
+        d = {k: t[k] for k in ("param_mins", "param_maxs", "mins", "maxs", "tt", "n_coeff", "VA")}
+        d["model"] = _KerasStandIn(t)
+        svd_ref[f] = d
+    m.model, m.model_parameters, m.filters = case["model"], list(case["model_parameters"]), list(allf)
+    m.svd_mag_model, m.mag_ncoeff, m.lbol_ncoeff, m.good_parameters = svd_ref, None, None, True
+    m.default_filts, m.lambdas, m.nu_0s = list(allf), np.ones(len(allf)), np.ones(len(allf))
+    m.model_times = case["sample_times"] if case["sample_times"] is not None else next(iter(svd_ref.values()))["tt"]
+    m.redshift_func = lambda p: np.interp(p["luminosity_distance"], grid[0], grid[1])
+    m.check_vs_priors = lambda priors: None
+    times, mags, sigmas = case["data"]
+    priors = ref.base.PriorDict({n: object() for n in case["names"]})
+    handler = ref.systematics.FilterSystematicsHandler(case["observed_filters"], systematics_file=None, error_budget=1.0, light_curve_times=times)
+    lik = ref.em_likelihood.EMTransientLikelihood(m, (times, mags, sigmas, 0.0), handler, priors, filters=case["observed_filters"], detection_limit=np.inf)
+    got = _rows(lik, case["names"], case["theta"][:6])
+    assert np.all(got == -1.7976931348623157e308)
