@@ -1118,6 +1118,32 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             v_[u] = (valid_[u] & !ul_[u]) ? v : 0.0;
             est_[u] = est; m_[u] = tm[1];
         }
+        if constexpr (COMB) {
+            // a finite detection limit on the band (em_likelihood.py:252-256; the general lean task's block, lean_gen_task): truncnorm's mass
+            // log Phi((lim - est) / sigma) from the table behind the flux-sum table.  1 / sigma and ln sigma are read again from the
+            // datum's record (constant systematics) instead of being kept across the flux sum: registers are what this flavour lacks
+            const bool lim_fin = (it.lim - it.lim == 0.0);                // uniform
+            if (lim_fin) {
+#pragma unroll
+                for (int u = 0; u < NSL; ++u)
+                    if (valid_[u] & !ul_[u]) {
+                        const f64x2 sl = D_[u][1];
+                        double isig = sl[0], lsig = sl[1];
+                        bool sbad = false;
+                        if constexpr (SYS) {
+                            const double s2 = sl[0] * sl[0] + esys_[u] * esys_[u];
+                            const double rs = rsqrt_pos(s2);
+                            isig = rs; lsig = log_pos(s2 * rs);
+                            sbad = ((s2 - s2 == 0.0) & !(s2 > 0)) | (s2 != s2);
+                        }
+                        const double b = (it.lim - est_[u]) * isig;
+                        const double x = (m_[u] - est_[u]) * isig;
+                        double v = ((-(x * x) / 2.0 - kNormPdfLogC) - log_gauss_mass_tab(b, (lds_cdp)(smem + L.nodes + STACK2_LDS_BYTES))) - lsig;
+                        v = x > b ? -dinf() : v;                                               // fainter than the limit, yet detected
+                        v_[u] = (inside_[u] & !sbad & (b > -dinf()) & (x == x)) ? v : dnan();
+                    }
+            }
+        }
         gp_[0] = 0.0; gp_[1] = 0.0;
         if (it.has_ul) {                                    // uniform; the term itself only on the lanes that hold a limit
 #pragma unroll

@@ -55,7 +55,7 @@ def oracle_likelihood(case, use_scipy=True):
     comb = orc.OracleCombinedModel([kn, grb])
     systematics = case.get("systematics") or dict(mode="budget", values={f: 1.0 for f in case["filters"]})
     return orc.OracleLikelihood(comb, case["data"], systematics,
-                                case["filters"], detection_limit=np.inf, known_filters=case["filters"],
+                                case["filters"], detection_limit=case.get("detection_limit", np.inf), known_filters=case["filters"],
                                 use_scipy=use_scipy), grb
 
 
@@ -167,3 +167,13 @@ def oracle_likelihood_nullfilters(case, use_scipy=True):
     comb = orc.OracleCombinedModel([kn, grb])
     return orc.OracleLikelihood(comb, case["data"], dict(mode="budget", values={f: 1.0 for f in allf}), allf,
                                 detection_limit=np.inf, known_filters=allf, use_scipy=use_scipy), grb
+
+
+def case_combined_limit(seed=9823, batch=40):
+    """The shared-grid combination under finite detection limits (truncated Gaussian per detection, em_likelihood.py:252-256): a limit
+    0.3 mag above the faintest datum of every filter -- except one, where a detection is fainter than its limit (-inf for every sample:
+    the reference's floor) in the variant ``violated=True``."""
+    c = case_combined(seed=seed, batch=batch)
+    c["detection_limit"] = {f: float(np.max(c["data"][1][f][np.isfinite(c["data"][2][f])]) + 0.3) for f in c["filters"]}
+    c["grb_hole"] = (9, 12, 1.2)
+    return c

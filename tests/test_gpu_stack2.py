@@ -328,10 +328,11 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
     faint = torch.full((B, M, NS), 45.0, dtype=torch.float64, device="cuda:0")
     want = plain.loglike(th).cpu().numpy()
     got = one.loglike_stack2(th, faint)
-    # no one-launch form: the general task (limits / averaged bands; surrogates with other than 10 coefficients -- ncoeff7, bulla_svd;
+    # no one-launch form: the general task (averaged bands; surrogates with other than 10 coefficients -- ncoeff7;
     # a model filter nobody observed)
-    no_form = {"c2_dt05_limit": "general task", "averaging": "general task", "ncoeff7": "general task", "bulla_svd": "general task",
-               "unobserved_filter_overflow": "general task"}
+    # (finite detection limits alone no longer are: since round 6 the combined-model flavours carry the truncation mass -- the plain
+    #  flavours of the same handle do not, so its plain entry points refuse it and the reference value comes from `plain`)
+    no_form = {"averaging": "general task", "ncoeff7": "general task", "unobserved_filter_overflow": "general task"}
     if name in no_form:
         assert got is None, name
         assert no_form[name] in one.stack2_reason, (name, one.stack2_reason)
@@ -346,6 +347,10 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
         err = rel_err(got[fin], want[fin]).max() if fin.any() else 0.0
         print(f"{name}: one-launch flavour with a dark second transient vs the plain flavour: max rel {err:.2e} over {int(fin.sum())} rows")
         assert err <= 1e-12, name
+        if name in ("c2_dt05_limit", "bulla_svd"):
+            from nmma_amd import _lib as L
+            with pytest.raises(L.NMMAHipError, match="finite detection limits"):
+                one.loglike(th)
         # the promise form takes the same rows through the kernel alone
         again = one.loglike_stack2(th, faint, gap_free=True).cpu().numpy()
         assert np.array_equal(again, got)
@@ -366,7 +371,7 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
     plain.close(); one.close()
 
 
-UNION_MIX_CASES = [n for n in MIX_CASES if n not in ("c2_dt05_limit", "averaging", "ncoeff7", "bulla_svd", "unobserved_filter_overflow")]
+UNION_MIX_CASES = [n for n in MIX_CASES if n not in ("averaging", "ncoeff7", "unobserved_filter_overflow")]
 
 
 @pytest.mark.parametrize("name", UNION_MIX_CASES)
@@ -681,3 +686,42 @@ def test_null_filters_on_own_time_grids():
     err = rel_err(got[~floor], want[~floor]).max()
     print(f"null filters on own grids: {int(floor.sum())} rows floored, max rel err {err:.2e}")
     assert err <= 1e-6
+
+
+def test_finite_detection_limits_go_through_the_one_launch_form():
+    """Golden ``combined_limit`` (the reference's container under per-filter detection limits, 0.3 mag above each filter's faintest
+    detection; holes in the afterglow's curves for half of the rows): since round 6 the combined-model flavours of the lean task carry the
+    truncated Gaussian's mass (log Phi from the table behind the flux-sum table), so the plugin stays on ONE launch -- log L at 1e-6,
+    the materialising path (general term in ``em_lc_loglike``) within 1e-10; a limit BELOW a detection floors every sample in both."""
+    import torch
+    case = cases_combined.case_combined_limit()
+    gold = cases.load_golden("combined_limit")["logl"]
+    _, grb_oracle = cases_combined.oracle_likelihood(case)
+    ext = torch.as_tensor(np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), case["sample_times"])[f] for f in case["filters"]])
+                                    for row in case["theta"]]))
+
+    def plugin(limits):
+        lik = _plugin(case)
+        lik.sub_model.set_detection_limit(limits)
+        return lik
+    lik = plugin(case["detection_limit"])
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    assert not np.any(gold == FLOOR) and not np.any(got == FLOOR)
+    err = rel_err(got, gold)
+    print(f"combined_limit, one launch: max rel err {err.max():.3e}")
+    assert err.max() <= 1e-6
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
+    assert sub._engine is not None and rel_err(mat, gold).max() <= 1e-6 and rel_err(got, mat).max() <= FUSED_VS_MATERIALISED_RTOL
+    # the limits matter: without them the values differ
+    free = plugin(np.inf).log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
+    assert np.abs(free - got).max() > 1e-3
+    # one filter's limit below its faintest detection: -inf for every sample
+    bad = dict(case["detection_limit"])
+    f0 = case["filters"][2]
+    bad[f0] = float(np.max(case["data"][1][f0][np.isfinite(case["data"][2][f0])]) - 0.2)
+    lik_bad = plugin(bad)
+    assert np.all(lik_bad.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext}) == FLOOR)
+    assert lik_bad.sub_model._engine2 is not None and not lik_bad.sub_model._stack2_off

@@ -541,6 +541,8 @@ def test_kernel_register_budget():
             # except the ones that carry the Constraint interpreter, WALKF & 64: two dozen registers around its libm calls, in the epilogue)
             con = (targs[5] & 64) != 0
             assert v["vgpr_spill_count"] <= (32 if con else 0) and (v["private_segment_fixed_size"] == 0 or targs[5] != 0), (k, v)
+        if fastm in (7, 8):     # (the combined-model flavours with the finite-limit block of round 6: none / two registers on the unequally spaced grids)
+            assert v["vgpr_spill_count"] <= 4 and v["private_segment_fixed_size"] <= 32, (k, v)
         if fastm == 5:      # (the general lean task with its out-of-line limit terms: two registers; with the fused MCMC step up to ten)
             assert v["vgpr_spill_count"] <= (12 if targs[5] else 4), (k, v)
         assert v["private_segment_fixed_size"] <= (160 if (targs[5] & 64) else 64), (k, v)

@@ -93,3 +93,10 @@ def test_combined_nullfilters_oracle_matches_golden():
     lik, _ = cases_combined.oracle_likelihood_nullfilters(case)
     got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
     np.testing.assert_allclose(got, gold["logl"][:16], rtol=1e-12)
+
+
+def test_combined_limit_oracle_matches_golden():
+    case = cases_combined.case_combined_limit()
+    lik, _ = cases_combined.oracle_likelihood(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
+    np.testing.assert_allclose(got, cases.load_golden("combined_limit")["logl"][:16], rtol=1e-12)

@@ -111,3 +111,12 @@ def test_reference_floors_a_single_model_that_lists_a_filter_without_a_network()
     lik = ref.em_likelihood.EMTransientLikelihood(m, (times, mags, sigmas, 0.0), handler, priors, filters=case["observed_filters"], detection_limit=np.inf)
     got = _rows(lik, case["names"], case["theta"][:6])
     assert np.all(got == -1.7976931348623157e308)
+
+
+def test_reference_reproduces_combined_limit_golden():
+    from tests import cases_combined
+    from tools.make_golden_combined import build_reference
+    case = cases_combined.case_combined_limit()
+    lik, _ = build_reference(case)
+    got = _rows(lik, case["names"], case["theta"])
+    np.testing.assert_allclose(got, cases.load_golden("combined_limit")["logl"], rtol=1e-13)

@@ -2,8 +2,8 @@
 """Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
 CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
 sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
-is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz, combined_nullfilters.npz
-(`python tools/make_golden_combined.py combined_owngrids` / `combined_nullfilters` writes that one alone)."""
+is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz, combined_nullfilters.npz, combined_limit.npz
+(`python tools/make_golden_combined.py combined_owngrids` / `combined_nullfilters` / `combined_limit` writes that one alone)."""
 import os
 import sys
 
@@ -68,7 +68,7 @@ def build_reference(case):
     handler = ref.systematics.FilterSystematicsHandler(obs_filters, systematics_file=sys_ref["systematics_file"],
                                                        error_budget=sys_ref["error_budget"], light_curve_times=times)
     lik = ref.em_likelihood.EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, priors,
-                                                  filters=obs_filters, detection_limit=np.inf)
+                                                  filters=obs_filters, detection_limit=case.get("detection_limit", np.inf))
     return lik, comb
 
 
@@ -97,6 +97,9 @@ def main():
     if sys.argv[1:] == ["combined_owngrids"]:
         run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
         return
+    if sys.argv[1:] == ["combined_limit"]:
+        run(cases_combined.case_combined_limit(), cases_combined.oracle_likelihood, "combined_limit")
+        return
     if sys.argv[1:] == ["combined_nullfilters"]:
         run(cases_combined.case_combined_nullfilters(), cases_combined.oracle_likelihood_nullfilters, "combined_nullfilters")
         return
@@ -124,6 +127,7 @@ def main():
     run(cases_combined.case_combined_loggrid(), cases_combined.oracle_likelihood, "combined_loggrid")
     run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
     run(cases_combined.case_combined_nullfilters(), cases_combined.oracle_likelihood_nullfilters, "combined_nullfilters")
+    run(cases_combined.case_combined_limit(), cases_combined.oracle_likelihood, "combined_limit")
 
 
 if __name__ == "__main__":
