@@ -251,8 +251,8 @@ int32_t nmma_em_loglike_lc_sets(nmma_em_handle* h, const double* theta_dev, int6
  * NaN at the first / last node are fine) -- the re-evaluation launch is then not enqueued (4 us of 89 at BASELINE config 3's shape);
  * a row that breaks the promise is floored AND poisons the handle: every later call fails with a message saying so.
  * Returns 2 -- nothing launched, nmma_last_error() says why -- when the handle has no one-launch form (not created with
- * stack_operands = 1; a configuration that needs the general task: averaged bands, time-node systematics (finite detection limits are
- * carried by the one-launch form itself -- such a handle then serves this entry point only),
+ * stack_operands = 1; a configuration that needs the general task: averaged bands (finite detection limits and time-node systematics
+ * are carried by the one-launch form itself -- such a handle then serves this entry point only),
  * other than 10 coefficients; sample_times reaching beyond the surrogate's grid; more curve nodes per sample than the
  * re-evaluation kernel stages -- 4 x M x NS x 8 bytes within 159 KiB of LDS): the caller then takes nmma_em_model_lightcurves +
  * nmma_em_loglike_lc_sets.  Asynchronous. */

@@ -971,6 +971,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const lds_cip s1i_l = (lds_cip)(tbl + P.tab_off_s1i);
         double v_[NSL], gp_[NSL], esys_[NSL] = {0.0, 0.0};
         const int sv0 = SYS ? __builtin_amdgcn_readfirstlane(P.sys_off[o]) : 0;      // first slot of the filter's parameter
+        const int svl = (SYS && COMB) ? __builtin_amdgcn_readfirstlane(P.sys_nn[o]) - 1 : 0;   // last time node (combined-model flavours)
         const lds_cdp ext_l = (lds_cdp)(smem + L.exttab) + (P.has_ebv ? k : 0) * TS;
         auto stage_q = [&]() {
         double ynode_[2][NSL];            // magnitudes at the two sample nodes of every slot
@@ -1096,7 +1097,18 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             bool sig_bad = false;
             if constexpr (SYS) {
                 const double sd = sl[0];                      // sigma_data
-                const double e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
+                double e_sys;
+                if constexpr (COMB) {
+                    // (combined-model flavours, round 6: systematics at time nodes too -- the record's fourth word is the datum's node
+                    //  index + fraction, written at create; a single parameter: i0 = i1 = 0, fr = 0 -- exactly e0.  lean_gen_task's lines)
+                    const double qf = floor(sl[1]), fr = sl[1] - qf;
+                    const int i0 = (int)qf, i1 = i0 < svl ? i0 + 1 : svl;
+                    const lds_cdp ep = (lds_cdp)(smem + L.epar) + sv0 * TS + s_[u];
+                    const double e0 = ep[i0 * TS], e1 = ep[i1 * TS];
+                    e_sys = (e1 - e0) * fr + e0;
+                } else {
+                    e_sys = ((lds_cdp)(smem + L.epar))[sv0 * TS + s_[u]];
+                }
                 esys_[u] = e_sys;
                 // (1 / sigma_tot and ln sigma_tot without the library's sqrt, division and log: rsqrt_pos / log_pos above.  The exact
                 //  shape of these five lines matters to hipcc: taking the log of sigma^2 instead, or the finite test from sqrt(s2),
@@ -1877,7 +1889,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 // (round 6: no task is two-stage any more -- where sample_times differ from the SVD grid the handle's table holds rows ON
                 //  the sample grid with the stage-1 lerp folded in, nmma_em_create -- so every lean flavour reconstructs two rows per
                 //  datum; the TWO = true forms of the lambdas are no longer instantiated: half the inlined task variants per kernel)
-                const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || (FASTM == 5 && itab[k].kind == NMMA_SYS_NODES));
+                const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || ((FASTM == 5 || COMB) && itab[k].kind == NMMA_SYS_NODES));
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
                     if constexpr (FASTM == 4 || FASTM == 8) {          // unequally spaced sample_times: bracket by lookup + bisection

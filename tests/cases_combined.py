@@ -177,3 +177,32 @@ def case_combined_limit(seed=9823, batch=40):
     c["detection_limit"] = {f: float(np.max(c["data"][1][f][np.isfinite(c["data"][2][f])]) + 0.3) for f in c["filters"]}
     c["grb_hole"] = (9, 12, 1.2)
     return c
+
+
+def case_combined_nodes(seed=9923, batch=40):
+    """The shared-grid combination with time-dependent systematics (systematics.py:288-296: four linear time nodes shared by two blue
+    bands, four for 2massj, one sampled parameter for the rest), non-finite sampled node values in a few rows (autocomplete_data's
+    mask: fewer than two finite nodes turn the group's detections into upper limits) and holes in the afterglow's curves."""
+    c = case_combined(seed=seed, batch=batch)
+    rng = np.random.default_rng(seed + 9)
+    g1 = ["ps1::g", "ps1::r"]
+    nodes = np.linspace(0.0, 21.0, 4)
+    n_a = [f"em_syserr_blue_{i}" for i in range(4)]
+    n_b = [f"em_syserr_2massj_{i}" for i in range(4)]
+    extra = ["em_syserr_rest"] + n_a + n_b
+    c["names"] = NAMES + extra
+    th = np.concatenate([c["theta"], rng.uniform(0.1, 1.5, (batch, len(extra)))], axis=1)
+    names = c["names"]
+    th[1, names.index(n_a[1])] = np.nan                                            # a middle node
+    th[2, names.index(n_a[0])] = np.inf                                            # the first node
+    th[3, [names.index(n) for n in n_b[:3]]] = np.nan                              # one finite node left: 2massj's detections become upper limits
+    th[4, names.index(n_b[3])] = -np.inf
+    c["theta"] = th
+    c["systematics"] = dict(mode="mixed", names={f: "em_syserr_rest" for f in FILTERS if f not in g1 + ["2massj"]},
+                            nodes={**{f: (n_a, nodes) for f in g1}, "2massj": (n_b, nodes)})
+    c["systematics_ref"] = dict(error_budget=None, systematics_file={
+        "blue": {"filters": g1, "time_nodes": 4, "time_range": "lin 0.0 21.0"},
+        "2massj": {"time_nodes": 4, "time_range": "lin 0.0 21.0"},
+        "rest": {"prior": "unused"}})
+    c["grb_hole"] = (9, 12, 1.2)
+    return c

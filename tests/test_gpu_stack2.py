@@ -306,7 +306,8 @@ def test_one_launch_on_a_log_spaced_grid():
 
 MIX_CASES = ["c2_default", "c2_dt05", "grid_subset", "syserr_param", "fast_np6", "ncoeff7", "fast_many_filters", "fast_single_filter",
              "fixed_distance", "conversions", "conversions_cos", "real_nets", "bulla_svd", "log_grid", "nonuniform_tt", "extinction_linear",
-             "hubble_sampled", "edges", "unobserved_filter_overflow", "c2_dt05_limit", "averaging", "c4_shape"]
+             "hubble_sampled", "edges", "unobserved_filter_overflow", "c2_dt05_limit", "averaging", "c4_shape", "syserr_time_nodes",
+             "syserr_nodes_masked"]
 
 
 @pytest.mark.parametrize("name", MIX_CASES)
@@ -347,9 +348,9 @@ def test_one_launch_flavour_carries_every_feature_of_the_lean_task(name):
         err = rel_err(got[fin], want[fin]).max() if fin.any() else 0.0
         print(f"{name}: one-launch flavour with a dark second transient vs the plain flavour: max rel {err:.2e} over {int(fin.sum())} rows")
         assert err <= 1e-12, name
-        if name in ("c2_dt05_limit", "bulla_svd"):
+        if name in ("c2_dt05_limit", "bulla_svd", "syserr_time_nodes"):
             from nmma_amd import _lib as L
-            with pytest.raises(L.NMMAHipError, match="finite detection limits"):
+            with pytest.raises(L.NMMAHipError, match="finite detection limits or time-node systematics"):
                 one.loglike(th)
         # the promise form takes the same rows through the kernel alone
         again = one.loglike_stack2(th, faint, gap_free=True).cpu().numpy()
@@ -725,3 +726,29 @@ def test_finite_detection_limits_go_through_the_one_launch_form():
     lik_bad = plugin(bad)
     assert np.all(lik_bad.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext}) == FLOOR)
     assert lik_bad.sub_model._engine2 is not None and not lik_bad.sub_model._stack2_off
+
+
+def test_time_node_systematics_go_through_the_one_launch_form():
+    """Golden ``combined_nodes`` (the reference's container with systematics at time nodes for two filter groups and one sampled
+    parameter for the rest; non-finite sampled node values in a few rows -- one leaves 2massj a single finite node, which turns its
+    detections into upper limits; holes in the afterglow's curves): since round 6 the combined-model flavours interpolate the nodes
+    themselves -- ONE launch, log L at 1e-6, the materialising path within 1e-10."""
+    import torch
+    case = cases_combined.case_combined_nodes()
+    gold = cases.load_golden("combined_nodes")["logl"]
+    _, grb_oracle = cases_combined.oracle_likelihood(case)
+    ext = torch.as_tensor(np.stack([np.stack([grb_oracle.abs_lightcurves(dict(zip(case["names"], row)), case["sample_times"])[f] for f in case["filters"]])
+                                    for row in case["theta"]]))
+    lik = _plugin(case)
+    got = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    floor = gold == FLOOR
+    assert np.array_equal(got == FLOOR, floor)
+    err = rel_err(got[~floor], gold[~floor])
+    print(f"combined_nodes, one launch: max rel err {err.max():.3e} ({int(floor.sum())} rows floored)")
+    assert err.max() <= 1e-6
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
+    assert sub._engine is not None and np.array_equal(mat == FLOOR, floor)
+    assert rel_err(got[~floor], mat[~floor]).max() <= FUSED_VS_MATERIALISED_RTOL

@@ -100,3 +100,10 @@ def test_combined_limit_oracle_matches_golden():
     lik, _ = cases_combined.oracle_likelihood(case)
     got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
     np.testing.assert_allclose(got, cases.load_golden("combined_limit")["logl"][:16], rtol=1e-12)
+
+
+def test_combined_nodes_oracle_matches_golden():
+    case = cases_combined.case_combined_nodes()
+    lik, _ = cases_combined.oracle_likelihood(case)
+    got = orc.log_likelihood_batch(lik, case["names"], case["theta"][:16])
+    np.testing.assert_allclose(got, cases.load_golden("combined_nodes")["logl"][:16], rtol=1e-12)

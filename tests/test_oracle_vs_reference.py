@@ -120,3 +120,12 @@ def test_reference_reproduces_combined_limit_golden():
     lik, _ = build_reference(case)
     got = _rows(lik, case["names"], case["theta"])
     np.testing.assert_allclose(got, cases.load_golden("combined_limit")["logl"], rtol=1e-13)
+
+
+def test_reference_reproduces_combined_nodes_golden():
+    from tests import cases_combined
+    from tools.make_golden_combined import build_reference
+    case = cases_combined.case_combined_nodes()
+    lik, _ = build_reference(case)
+    got = _rows(lik, case["names"], case["theta"])
+    np.testing.assert_allclose(got, cases.load_golden("combined_nodes")["logl"], rtol=1e-13)

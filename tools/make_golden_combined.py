@@ -2,8 +2,8 @@
 """Golden vectors for the combined-model path (BASELINE config 3 shape) from the REFERENCE'S OWN
 CombinedLightCurveModelContainer (nmma/em/model.py:1342-1510) under oracle/ref_harness.py.  The GRB
 sub-model is a power-law stand-in subclassing the reference's LightCurveModelContainer (afterglowpy
-is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz, combined_nullfilters.npz, combined_limit.npz
-(`python tools/make_golden_combined.py combined_owngrids` / `combined_nullfilters` / `combined_limit` writes that one alone)."""
+is third-party and absent).  Output: tests/golden/combined.npz, combined_union.npz, combined_syserr.npz, combined_loggrid.npz, combined_owngrids.npz, combined_nullfilters.npz, combined_limit.npz, combined_nodes.npz
+(`python tools/make_golden_combined.py combined_owngrids` / `combined_nullfilters` / `combined_limit` / `combined_nodes` writes that one alone)."""
 import os
 import sys
 
@@ -97,6 +97,9 @@ def main():
     if sys.argv[1:] == ["combined_owngrids"]:
         run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
         return
+    if sys.argv[1:] == ["combined_nodes"]:
+        run(cases_combined.case_combined_nodes(), cases_combined.oracle_likelihood, "combined_nodes")
+        return
     if sys.argv[1:] == ["combined_limit"]:
         run(cases_combined.case_combined_limit(), cases_combined.oracle_likelihood, "combined_limit")
         return
@@ -128,6 +131,7 @@ def main():
     run(cases_combined.case_combined_owngrids(), cases_combined.oracle_likelihood_owngrids, "combined_owngrids")
     run(cases_combined.case_combined_nullfilters(), cases_combined.oracle_likelihood_nullfilters, "combined_nullfilters")
     run(cases_combined.case_combined_limit(), cases_combined.oracle_likelihood, "combined_limit")
+    run(cases_combined.case_combined_nodes(), cases_combined.oracle_likelihood, "combined_nodes")
 
 
 if __name__ == "__main__":
