@@ -752,3 +752,76 @@ def test_time_node_systematics_go_through_the_one_launch_form():
     mat = lik.log_likelihood_batch(case["theta"], case["names"], external_lc={"PLGRB": ext})
     assert sub._engine is not None and np.array_equal(mat == FLOOR, floor)
     assert rel_err(got[~floor], mat[~floor]).max() <= FUSED_VS_MATERIALISED_RTOL
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_one_launch_form_random_feature_mixes_against_the_materialising_path(seed):
+    """Random mixes of everything the one-launch form carries since round 6 -- shared or own time grids, zero to two null filters, constant /
+    sampled / time-node systematics, finite detection limits on some filters, extra upper limits, holes and failed rows in the second
+    transient's curves -- through the plugin twice: ONE launch against the materialising path (``em_fused`` + ``regrid`` +
+    ``em_lc_loglike``, itself pinned by the goldens): identical floor patterns, log L within 1e-10."""
+    import torch
+    from nmma_amd.em.em_likelihood import EMTransientLikelihood
+    from nmma_amd.em.model import CombinedLightCurveModelContainer, ExternalLightCurveModel, SVDLightCurveModel
+    from nmma_amd.em.systematics import FilterSystematicsHandler
+    rng = np.random.default_rng(31000 + seed)
+    base = cases_combined.case_combined(seed=9100 + seed, batch=32)
+    F = list(base["filters"])
+    null = list(rng.choice(cases_combined.NULL_FILTERS, size=int(rng.integers(0, 3)), replace=False))
+    allf = F + null
+    times, mags, sigmas = ({k: np.array(v, float) for k, v in d.items()} for d in base["data"])
+    for k, f in enumerate(null):
+        n = int(rng.integers(4, 12))
+        t = np.sort(rng.uniform(0.6, 13.0, n))
+        times[f], sigmas[f] = t, rng.uniform(0.05, 0.2, n)
+        mags[f] = -16.0 + 3.0 * np.log10(t) + 33.0 + sigmas[f] * rng.standard_normal(n)
+    for f in rng.choice(allf, size=3, replace=False):           # a few more upper limits
+        i = int(rng.integers(0, len(times[f])))
+        sigmas[f][i] = np.inf
+    st = base["sample_times"]
+    own = bool(rng.integers(0, 2))
+    kn_times = np.arange(0.1, 18.0, 0.7) if own else st
+    grb_times = np.geomspace(0.25, 30.0, int(rng.integers(20, 45))) if own else st
+    names = list(cases_combined.NAMES)
+    theta = base["theta"].copy()
+    sys_mode = ["budget", "param", "nodes"][seed % 3]
+    if sys_mode == "budget":
+        sys_file, budget = None, 1.0
+    elif sys_mode == "param":
+        sys_file, budget = None, None
+        names, theta = names + ["em_syserr"], np.concatenate([theta, rng.uniform(0.1, 1.5, (len(theta), 1))], axis=1)
+    else:
+        g1 = F[:2]
+        extra = ["em_syserr_rest"] + [f"em_syserr_blue_{i}" for i in range(3)]
+        sys_file, budget = {"blue": {"filters": g1, "time_nodes": 3, "time_range": "lin 0.0 21.0"}, "rest": {"prior": "unused"}}, None
+        names, theta = names + extra, np.concatenate([theta, rng.uniform(0.1, 1.5, (len(theta), len(extra)))], axis=1)
+        theta[3, names.index("em_syserr_blue_1")] = np.nan
+    limits = np.inf
+    if rng.integers(0, 2):
+        limits = {f: (float(np.max(mags[f][np.isfinite(sigmas[f])]) + 0.3) if rng.integers(0, 2) else np.inf) for f in allf}
+    kn = SVDLightCurveModel(base["model"], svd_mag_model=base["svd"], filters=allf, model_parameters=base["model_parameters"],
+                            sample_times=kn_times, cosmo_grid=base["cosmo_grid"])
+    grb = ExternalLightCurveModel("PLGRB", allf, grb_times)
+    comb = CombinedLightCurveModelContainer([kn, grb], cosmo_grid=base["cosmo_grid"])
+    handler = FilterSystematicsHandler(allf, systematics_file=sys_file, error_budget=budget, light_curve_times=times)
+    lik = EMTransientLikelihood(comb, (times, mags, sigmas, 0.0), handler, {n: SimplePrior(0.0, 1.0) for n in names}, filters=allf,
+                                detection_limit=limits)
+    from oracle import nmma_oracle as orc
+    helper = orc.OraclePowerLawModel(allf, grb_times, hole=(len(grb_times) // 3, len(grb_times) // 3 + 2, 1.2))
+    ext = np.stack([np.stack([helper.abs_lightcurves(dict(zip(names, row)), grb_times)[f] for f in allf]) for row in theta])
+    ok = np.ones(len(theta), dtype=bool)
+    ok[int(rng.integers(0, len(theta)))] = False
+    ext_lc = {"PLGRB": (torch.as_tensor(ext), ok)}
+    got = lik.log_likelihood_batch(theta, names, external_lc=ext_lc)
+    sub = lik.sub_model
+    assert sub._engine2 is not None and not sub._stack2_off and sub._engine is None, getattr(sub._engine2, "stack2_reason", None)
+    sub._stack2_off = True
+    mat = lik.log_likelihood_batch(theta, names, external_lc=ext_lc)
+    assert sub._engine is not None
+    floor = mat == FLOOR
+    assert np.array_equal(got == FLOOR, floor), (seed, np.nonzero((got == FLOOR) != floor)[0])
+    assert floor[~ok].all()
+    err = rel_err(got[~floor], mat[~floor]).max() if (~floor).any() else 0.0
+    print(f"seed {seed}: {'own' if own else 'shared'} grids, null {null}, systematics {sys_mode}, limits {'yes' if isinstance(limits, dict) else 'no'}: "
+          f"{int(floor.sum())} of {len(theta)} rows floored, one launch vs materialising {err:.2e}")
+    assert err <= FUSED_VS_MATERIALISED_RTOL
