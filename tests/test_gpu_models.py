@@ -262,19 +262,20 @@ def test_two_model_stack_table_edges():
     eng.close()
 
 
-@pytest.mark.parametrize("n_src", [36, 1100])
-def test_regrid_is_autocomplete_data_per_curve(n_src):
+@pytest.mark.parametrize("n_src,n_out,averaged", [(36, 60, True), (1100, 60, True), (36, 60, False), (36, 25, False), (90, 140, False), (36, 300, False)])
+def test_regrid_is_autocomplete_data_per_curve(n_src, n_out, averaged):
     """``nmma_lc_regrid`` against the oracle's ``autocomplete_data(..., extrapolate=inf)`` (utils.py:626-645) curve by curve: random
     source curves with holes (NaN and +inf), curves with fewer than two finite nodes, output nodes that coincide with source nodes,
-    lie before the first / after the last finite one; direct, averaged (two and three helper bands) and missing filters.  36 source
-    nodes take the kernel that keeps the source grid and curve in LDS with the static bracket table, 1100 the search through global
-    memory: bit-exact np.interp in both (``lerp_np``)."""
+    lie before the first / after the last finite one; direct, averaged (two and three helper bands) and missing filters.  With an
+    averaged band, 36 source nodes take the kernel that keeps the source grid and one curve per wave in LDS with the static bracket
+    table, 1100 the search through global memory; without one (every output filter copies at most one source filter) several curves
+    share a wave -- four for output grids of up to 80 nodes, two up to 160, one curve per wave beyond: bit-exact np.interp in all."""
     import torch
     from nmma_amd.engine import EMEngine
     from oracle import nmma_oracle as orc
-    rng = np.random.default_rng(100 + n_src)
+    rng = np.random.default_rng(100 + n_src + 7 * n_out + (1 if averaged else 0))
     xs = np.sort(rng.uniform(0.2, 30.0, n_src))
-    st = np.sort(np.concatenate([rng.uniform(0.05, 35.0, 60), xs[::5]]))          # (every fifth source node is an output node too)
+    st = np.sort(np.concatenate([rng.uniform(0.05, 35.0, n_out), xs[::5]]))       # (every fifth source node is an output node too)
     filters = ["g", "r", "i", "z"]
     eng = EMEngine(None, filters, [], ["luminosity_distance"], sample_times=st, cosmo_grid=syn.flat_lcdm_grid(1.0, 200.0), model_kind="external")
     B, Ms = 37, 3
@@ -284,7 +285,7 @@ def test_regrid_is_autocomplete_data_per_curve(n_src):
     lc[3, 1, :] = np.inf                     # no finite node
     lc[4, 0, 1:] = np.nan                    # one finite node
     lc[5, 2, :n_src // 2] = np.inf           # finite only in the second half
-    plan = [[0], [2, 1], [0, 1, 2], []]
+    plan = [[0], [2, 1], [0, 1, 2], []] if averaged else [[1], [0], [2], []]
     got = eng.regrid(torch.as_tensor(lc, device="cuda:0"), xs, plan).cpu().numpy()
     want = np.empty((B, len(filters), len(st)))
     for b in range(B):
