@@ -176,10 +176,12 @@ typedef struct nmma_em_config {
     const double* base_times;     /* [n_base_times] strictly increasing */
     /* ---- ... and whose surrogate has NOTHING for some of the combination's filters -- calc_svd_lc's null output "for other
      * filters, especially radio and X-ray filters when using with GRB data" (lightcurve_generation.py:168-169: +inf on every node):
-     * null_filters[m] != 0 marks model filter m as such.  Its surrogate tensors are ignored (pass zeros of the common shapes); its
-     * curve is +inf everywhere, so in nmma_em_loglike_stack2 the flux sum of that band is the second transient alone, and a
-     * likelihood that takes the surrogate alone floors every sample whose photometry includes the band, as the reference does
-     * (sanity_check, em_likelihood.py:305-311).  NULL = every model filter has a surrogate.  Needs stack_operands = 1. ---- */
+     * null_filters[m] != 0 marks model filter m as such.  Pass zero weights, biases and basis for it, and the tt / param_mins /
+     * param_maxs of a real filter (the record stream still walks the item; its inputs must normalise to finite numbers).  Its rows
+     * give +inf on every node, so in nmma_em_loglike_stack2 the flux sum of that band is the second transient alone; the entry
+     * points that take the surrogate ALONE as the likelihood's model refuse the handle (the reference floors every sample there:
+     * sanity_check on the all-inf curve, em_likelihood.py:305-311).  NULL = every model filter has a surrogate.  Needs
+     * stack_operands = 1. ---- */
     const int32_t* null_filters;  /* [M] or NULL */
 } nmma_em_config;
 
