@@ -276,7 +276,7 @@ def test_regrid_is_autocomplete_data_per_curve(n_src, n_out, averaged):
     rng = np.random.default_rng(100 + n_src + 7 * n_out + (1 if averaged else 0))
     xs = np.sort(rng.uniform(0.2, 30.0, n_src))
     st = np.sort(np.concatenate([rng.uniform(0.05, 35.0, n_out), xs[::5]]))       # (every fifth source node is an output node too)
-    filters = ["g", "r", "i", "z"]
+    filters = ["g", "r", "i", "z"] if averaged else ["g", "r", "i", "z", "y"]      # (37 x 5 curves: a ragged last group of the packed kernel)
     eng = EMEngine(None, filters, [], ["luminosity_distance"], sample_times=st, cosmo_grid=syn.flat_lcdm_grid(1.0, 200.0), model_kind="external")
     B, Ms = 37, 3
     lc = rng.normal(-15.0, 2.0, (B, Ms, n_src))
@@ -285,7 +285,7 @@ def test_regrid_is_autocomplete_data_per_curve(n_src, n_out, averaged):
     lc[3, 1, :] = np.inf                     # no finite node
     lc[4, 0, 1:] = np.nan                    # one finite node
     lc[5, 2, :n_src // 2] = np.inf           # finite only in the second half
-    plan = [[0], [2, 1], [0, 1, 2], []] if averaged else [[1], [0], [2], []]
+    plan = [[0], [2, 1], [0, 1, 2], []] if averaged else [[1], [0], [2], [], [0]]
     got = eng.regrid(torch.as_tensor(lc, device="cuda:0"), xs, plan).cpu().numpy()
     want = np.empty((B, len(filters), len(st)))
     for b in range(B):
