@@ -346,7 +346,10 @@ constexpr int DAT_MAX = 2560;
 #endif
 constexpr int LEAN_NF_MAX = NMMA_LEAN_NF_MAX;
 
-template <int R, int KP, int PF, int NMW, int NVW, bool FAST, class LateX>
+// SKIPNULL (the combined-model flavours): the first EmDev::n_items_null work items are NULL filters -- bands the surrogate has no network for
+// (nmma_em_config::null_filters; their basis rows give +inf whatever the coefficients).  The record stream does not walk them: this role
+// publishes zero partial sums for them before it starts, so their tasks run beside the stream of the real items.
+template <int R, int KP, int PF, int NMW, int NVW, bool FAST, bool SKIPNULL, class LateX>
 __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R][KP], double* xnl, const int wave, const int lane,
                                           float* __restrict__ part, const int NBUF, int* sync,
                                           long long* __restrict__ dbg_generic, LateX&& late_xraw) {
@@ -393,7 +396,23 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
         }
     };
 
-    int base = item_base(0);
+    const int Wn = SKIPNULL ? P.n_items_null : 0;        // (null items come first: nmma_em_create orders them so)
+    if constexpr (SKIPNULL) {
+        for (int k = 0; k < Wn; ++k) {
+            float* pk = part + (k % NBUF) * (NSLICE * TS * PSTR);
+            if (k >= NBUF) sync_wait(sync + W + 1 + (k - NBUF + 1), FAST ? idesc[(k - NBUF) * ITEM_WORDS + 22 + (R - 1)] : NVW, P.watchdog, 100 + k);
+#pragma unroll 1
+            for (int sl = 0; sl < NSL; ++sl) {
+                const int slice = wave * NSL + sl;
+#pragma unroll
+                for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[((slice * R + rb) * 16 + (lane & 15)) * PSTR + (lane >> 4) * 4 + r] = 0.f;
+            }
+            sync_signal(sync + k, lane);      // item k published: zero coefficients
+        }
+    }
+    int base = item_base(Wn);
     f32x4 ra2[PF], rbias[PF];
     float ra1[PF][KP];
     // The ring holds records g .. g+PF-2 when record g is consumed; the step that consumes slot g % PF
@@ -412,7 +431,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     }
     late_xraw();          // (measurement build -DNMMA_DBG_PRELOAD_FIRST: theta is read only now, behind the ring's first loads)
     float xB[R][KP], xN[R][KP];
-    load_x(0, xB);
+    load_x(Wn, xB);
     f32x4 d[R];
 #pragma unroll
     for (int rb = 0; rb < R; ++rb) {
@@ -423,7 +442,7 @@ __device__ __forceinline__ void mfma_role(const EmDev& P, const double (&xraw)[R
     }
 
 #pragma unroll 1
-    for (int k = 0; k < W; ++k) {
+    for (int k = Wn; k < W; ++k) {
         if (dbg && blockIdx.x == 0 && wave == 0 && lane == 0) dbg[2 * k] = clock64();
         const int nbase = (k + 1 < W) ? item_base(k + 1) : base;     // last item: harmless re-read
         if (k + 1 < W) load_x(k + 1, xN);

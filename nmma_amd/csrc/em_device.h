@@ -152,6 +152,7 @@ struct EmDev {
     // pi / 2 about the real axis whatever the data -- tabulated per item as Chebyshev series of degree 14 on LNSIG_NI intervals of
     // width 1/2 in w (built and verified at nmma_em_create; null: not built, or a band failed the check): the datum loop then needs
     // 1 / sigma_tot^2 only -- no square root, no logarithm per (datum, sample).
+    int32_t n_items_null, pad_null;   // combined-model flavours: the first n_items_null work items are null filters (no record stream: mfma_role<.., SKIPNULL>)
     const double* lnsig_tab;  // [n_items][LNSIG_NI][16]
     double lnsig_w0;          // left end of the first interval (in w = ln e)
 };

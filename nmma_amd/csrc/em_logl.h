@@ -101,9 +101,9 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
             default: break;
         }
 #ifdef NMMA_DBG_PRELOAD_FIRST
-        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, fill_xraw);
+        mfma_role<R, KP, PF, NMW, NVW, FAST, COMB>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, fill_xraw);
 #else
-        mfma_role<R, KP, PF, NMW, NVW, FAST>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, [] {});
+        mfma_role<R, KP, PF, NMW, NVW, FAST, COMB>(P, xraw, xnl, wave, lane, part, L.nbuf, sync, dbg, [] {});
 #endif
         if (!FAST || !P.helpers) return;
         // fast mode: the record stream is done -- join the likelihood workers for the remaining tasks
