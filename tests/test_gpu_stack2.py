@@ -825,3 +825,27 @@ def test_one_launch_form_random_feature_mixes_against_the_materialising_path(see
     print(f"seed {seed}: {'own' if own else 'shared'} grids, null {null}, systematics {sys_mode}, limits {'yes' if isinstance(limits, dict) else 'no'}: "
           f"{int(floor.sum())} of {len(theta)} rows floored, one launch vs materialising {err:.2e}")
     assert err <= FUSED_VS_MATERIALISED_RTOL
+
+
+def test_null_filters_and_limits_are_batch_size_independent():
+    """5000 rows of the null-filter case under finite limits (16- and 32-sample tiles, the null items ahead of the record stream): a row's
+    value does not depend on the batch it arrives in, nor on the call -- the same bits from ragged sub-batches and from a second call."""
+    import torch
+    from nmma_amd.engine import EMEngine
+    case = cases_combined.case_combined_nullfilters()
+    A = case["all_filters"]
+    limits = {f: float(np.max(case["data"][1][f][np.isfinite(case["data"][2][f])]) + 0.3) for f in A}
+    one = EMEngine(case["svd"], A, case["model_parameters"], case["names"], sample_times=case["sample_times"], cosmo_grid=case["cosmo_grid"],
+                   data=case["data"], observed_filters=A, detection_limit=limits, stack_operands=1, null_filters=cases_combined.NULL_FILTERS)
+    B = 5000
+    theta = _theta(91, B)
+    st = case["sample_times"]
+    with np.errstate(divide="ignore"):
+        base = theta[:, 6:7] + 2.5 * theta[:, 7:8] * np.log10(st)[None, :]
+    ext = torch.as_tensor(np.stack([np.where(st >= 0.3, base + 0.15 * k, np.inf) for k in range(len(A))], axis=1), device="cuda:0")
+    th = torch.as_tensor(theta, device="cuda:0")
+    full = one.loglike_stack2(th, ext).cpu().numpy()
+    assert (full != FLOOR).mean() > 0.5 and np.array_equal(full, one.loglike_stack2(th, ext).cpu().numpy())
+    for lo, hi in ((0, 4096), (4096, 5000), (17, 1040), (4999, 5000)):
+        assert np.array_equal(one.loglike_stack2(th[lo:hi], ext[lo:hi]).cpu().numpy(), full[lo:hi]), (lo, hi)
+    one.close()
