@@ -94,10 +94,11 @@ struct nmma_em_handle {
     std::vector<int> same_grid, ranges;   // per model filter (host copies used to build item descriptors)
     std::vector<double> st_host;          // host copy of EmDev::st (nmma_lc_regrid builds its bracket table against it)
     // combined model on a union grid (nmma_em_config::base_times): host copies of EmDev's b_* / u_* tables, used where the lean
-    // task's rows are built; union_only = the entry points that take the surrogate alone as the likelihood's model refuse the handle
+    // task's rows are built; stack2_only = the handle serves nmma_em_loglike_stack2 (and the curve outputs) only -- a union grid, null filters,
+    // or finite limits / time-node systematics that only the combined-model flavours carry: the entry points that take the surrogate alone refuse it
     std::vector<int32_t> u_idx, b_idx;
     std::vector<double> u_dx, u_off, b_dx, b_off;
-    bool union_only = false;
+    bool stack2_only = false;
     long long* dbg = nullptr;   // device buffer of in-kernel timestamps (nmma_em_debug_timeline)
     int* wd_host = nullptr;     // pinned, device-mapped watchdog words written by em_logl's hand-off waits
 };
