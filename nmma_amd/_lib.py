@@ -18,7 +18,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "em_kernels.hip")
 #: took 170 s; em_lc.hip holds the fourteen variants of the likelihood-from-curves kernel (inside em_kernels.hip they made it the
 #: critical path).  Order = this machine's unit times, longest first (tools: _lib.UNIT_SECONDS after a forced build).
 SOURCES = ("em_kernels.hip", "em_lc64.hip", "em_lc.hip", "em_logl_w3.hip", "em_logl_w2.hip", "em_logl_wc1.hip", "em_logl_w1.hip", "em_logl_f5.hip", "em_logl_f02.hip",
-           "em_logl_w4.hip", "em_logl_wc2.hip", "em_logl_w5.hip", "em_logl_f8.hip", "em_logl_f6.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f7.hip",
+           "em_logl_w4.hip", "em_logl_wc2.hip", "em_logl_w5.hip", "em_logl_f8.hip", "em_logl_f6.hip", "em_logl_f9.hip", "em_logl_f4.hip", "em_logl_f3.hip", "em_logl_f7.hip",
            "gw_kernels.hip", "em_logl_f1.hip", "walk_kernels.hip")
 #: per-unit flags after the common ones.  The EM unit keeps -ffp-contract=off (the reference's numpy expressions are not fused and
 #: the parity tests compare bit patterns of intermediate results); the GW unit has no bit-level counterpart (its reference

@@ -99,6 +99,7 @@ struct nmma_em_handle {
     std::vector<int32_t> u_idx, b_idx;
     std::vector<double> u_dx, u_off, b_dx, b_off;
     bool stack2_only = false;
+    bool dense_plain = false;       // dense task, constant systematics, equally spaced grid: em_logl<.., 9> (that variant alone in its kernel)
     long long* dbg = nullptr;   // device buffer of in-kernel timestamps (nmma_em_debug_timeline)
     int* wd_host = nullptr;     // pinned, device-mapped watchdog words written by em_logl's hand-off waits
 };

@@ -25,7 +25,10 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
     constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2 && FASTM != 7 && FASTM != 8;    // small batches: one band per workgroup (launch_logl_one)
-    constexpr bool DENSE = FASTM == 6;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
+    constexpr bool DENSE = FASTM == 6 || FASTM == 9;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
+    // FASTM == 9: the dense task's ONE variant BASELINE config 4 takes -- constant systematics, equally spaced sample_times -- alone in its
+    // kernel: with the other three variants (sampled systematic, unequally spaced grid) inlined next to it, code it never runs cost that
+    // variant 3 % (134.2 against 130.5 us at 8192 rows, 964 against 939 at 65 536: tools/experiments/ab_dense_variants.sh)
     constexpr bool LEANX = FASTM >= 3;       // 3: equally spaced sample_times, 4: unequally spaced (fewer inlined variants per kernel)
     // FASTM == 7: the lean task with extras (as 3) for a COMBINED model of two transients that share sample_times and filters
     // (CombinedLightCurveModelContainer, model.py:1411-1459 -- what the reference's drivers build, :1591-1614): the second transient's
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 for (int j = cvt; j < LOGPHI_NINT * LOGPHI_ROW; j += cnv) dst2[j] = kLogPhiTab[j];
             }
         }
-        if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4 || FASTM == 5 || FASTM == 6) {       // log Phi for upper limits / detections under a finite limit (logphi_tab.h)
+        if constexpr (FASTM == 1 || FASTM == 3 || FASTM == 4 || FASTM == 5 || FASTM == 6 || FASTM == 9) {       // log Phi for upper limits / detections under a finite limit (logphi_tab.h)
             if (P.mass_tab) {
                 // (the dense task keeps it behind its node buffers)
                 double* dst = reinterpret_cast<double*>(smem + L.nodes) + (DENSE ? DENSE_NBUF * ((NS + 15) & ~15) * DENSE_STRIDE : 0);
@@ -1904,11 +1907,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                         // stage-1 lerp lives in the A operands, an unequally spaced grid only changes how a datum finds its bracket
                         if (P.st_uniform) { if (sysp) dense_task(T{}, F{}, k, t); else dense_task(F{}, F{}, k, t); }
                         else { if (sysp) dense_task(T{}, T{}, k, t); else dense_task(F{}, T{}, k, t); }
+                    } else if constexpr (FASTM == 9) {   // ... its constant-systematics, equally-spaced variant alone (the launcher checks)
+                        dense_task(F{}, F{}, k, t);
                     } else {
                         lean_task(tb, F{}, F{}, F{}, k, t);
                     }
                 };
-                if constexpr (FASTM == 6) run(std::false_type{});
+                if constexpr (DENSE) run(std::false_type{});
                 else if (itab[k].nf <= 16) run(std::true_type{}); else run(std::false_type{});
             }
 #else
@@ -2052,7 +2057,7 @@ hipError_t launch_logl_one(nmma_em_handle* h, const double* theta, int64_t B, in
     const EmDev& P = h->dev;
     const LdsW L = lds_layout_logl(R, lds_ns_arg(P), h->nf_avg_max, P.tab_bytes, P.tab_fast_bytes, P.n_items, P.M, P.NP, P.all_fast, P.n_data, P.n_sys_slots,
                                    (P.all_fast == 1 && (P.lean_x || FAST == 7 || FAST == 8)) ? (P.has_ebv ? P.n_items : 1) : 0, h->ring_max, P.dense ? 0 : (P.dat_in_tab ? 8 : 32),
-                                   P.dense ? ((P.NS + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES + (P.mass_tab2 ? LOGPHI_LDS_BYTES : 0) : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5 || FAST == 6) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
+                                   P.dense ? ((P.NS + 15) & ~15) : 0, (FAST == 7 || FAST == 8) ? STACK2_LDS_BYTES + (P.mass_tab2 ? LOGPHI_LDS_BYTES : 0) : ((FAST == 1 || FAST == 3 || FAST == 4 || FAST == 5 || FAST == 6 || FAST == 9) && P.mass_tab) ? LOGPHI_LDS_BYTES : 0,
                                    ((WALKF & 31) == 16 || (WALKF != 0 && R == 2)) ? (WALKF & 31) : 0);
     const int TS = 16 * R;
     g_launch_note.clear();
