@@ -148,6 +148,14 @@ struct EmDev {
     const double* u_dx;       // [M][NS]   bt[i+1] - bt[i]
     const double* u_off;      // [M][NS]   st[j] - bt[i]  (0: the grid node IS base node i)
     int32_t n_items_null, pad_null;   // combined-model flavours: the first n_items_null work items are null filters (no record stream: mfma_role<.., SKIPNULL>)
+    // Dense task under a sampled systematic (one parameter per filter or shared; em_logl<.., 6> -- constant systematics take <.., 9>): sum_i
+    // ln sigma_tot,i of a band's detections is a function of the sampled value e alone -- F(w) = 1/2 sum_i ln(sigma_data,i^2 + e^2), w = ln e,
+    // analytic in a strip of half-width pi / 2 about the real axis whatever the data -- tabulated per item as Chebyshev series of degree 14 on
+    // LNSIG_NI intervals of width 1/2 in w (built and verified at nmma_em_create; null: not built, or a band failed the check): the datum
+    // loop then needs 1 / sigma_tot^2 only -- no square root, no logarithm per (datum, sample).
+    const double* lnsig_tab;  // [n_items][LNSIG_NI][16]
+    double lnsig_w0;          // left end of the first interval (in w = ln e)
 };
+constexpr int LNSIG_NI = 34, LNSIG_DEG = 14;      // e from 1e-4 to 2.4e3
 
 }  // namespace nmma

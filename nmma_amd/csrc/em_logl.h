@@ -1630,6 +1630,33 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         const double c1 = izp1 * P.st_inv_dt, c0 = -((tsh * izp1 + P.st0) * P.st_inv_dt);
         const int nbis = NONUNI ? __builtin_amdgcn_readfirstlane(P.bg_nbis) : 0;
         const double bg_inv_h = NONUNI ? P.bg_inv_h : 0.0, st0 = P.st0;
+        const double e_sys = SYS ? ((lds_cdp)(smem + L.epar))[__builtin_amdgcn_readfirstlane(P.sys_off[o]) * TS + s] : 0.0;
+        // A sampled systematic: sum_i ln sigma_tot,i of the band's detections from the item's Chebyshev table in w = ln e (EmDev::lnsig_tab,
+        // built and verified at create) -- one series per (item, sample) instead of a logarithm and a reciprocal square root per (datum,
+        // sample): the loop below then needs 1 / sigma_tot^2 only.  A sample whose e lies outside the table (or is not positive and
+        // finite) sends the whole task through the per-datum form.  Evaluated HERE, before the waits for the surrogate: the table's
+        // global-memory latency passes while the task has nothing else to do.
+        double lnsig_sum = 0.0;
+        bool tab_all = false;
+        if constexpr (SYS) {
+            gcf64p ltab = as_global(P.lnsig_tab);
+            if (ltab != nullptr) {
+                const bool pos = (e_sys > 0.0) & (e_sys - e_sys == 0.0);
+                const double w = log_pos(pos ? e_sys : 1.0);
+                const double uq = (w - P.lnsig_w0) * 2.0;
+                const bool in = pos & (uq >= 0.0) & (uq < (double)LNSIG_NI);
+                tab_all = __ballot(!in) == 0;
+                if (tab_all) {
+                    const int iq = (int)uq;
+                    const double x2 = 2.0 * (2.0 * (uq - (double)iq) - 1.0);                    // 2 x, x in [-1, 1)
+                    gcf64p row = ltab + ((size_t)it.tabi * LNSIG_NI + iq) * 16;
+                    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+                    for (int n = LNSIG_DEG; n >= 1; --n) { const double b0 = (x2 * b1 - b2) + row[n]; b2 = b1; b1 = b0; }
+                    lnsig_sum = ((0.5 * x2) * b1 - b2) + row[0];
+                }
+            }
+        }
         if (c == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sync_signal(sync + 2 * W + 4 + k, lane);     // [b2 | records] of item k staged
@@ -1684,7 +1711,6 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         // ---- the datum loop: detections in passes of 32 (two slots per lane), then the upper limits
         const lds_c2p recs = (lds_c2p)(tbl + P.tab_off_dat - P.tab_off_b2);
         const lds_cdp ncol = (lds_cdp)nb + (s & 15);
-        const double e_sys = SYS ? ((lds_cdp)(smem + L.epar))[__builtin_amdgcn_readfirstlane(P.sys_off[o]) * TS + s] : 0.0;
         // a datum's bracket on the sample's observer-frame grid and its position inside it
         auto bracket = [&](const double t, int& lo, double& frac) {
             if constexpr (NONUNI) {
@@ -1715,6 +1741,31 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
         double vacc0 = 0.0, vacc1 = 0.0;
         bool outside = false;
         const int npad = (ndet + 31) & ~31;
+        if (SYS && tab_all) {
+#pragma unroll 1
+            for (int d0_ = 0; d0_ < npad; d0_ += 32) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int dd = d0_ + gi + 16 * u;
+                    const f64x2 tm = recs[2 * dd], sk = recs[2 * dd + 1];       // {t, m}, {sigma_data, 0}
+                    int lo;
+                    double frac;
+                    bracket(tm[0], lo, frac);
+                    const lds_cdp nd = ncol + lo * DENSE_STRIDE;
+                    const double y0 = nd[0], y1 = nd[DENSE_STRIDE];
+                    const double est = fma(y1 - y0, frac, y0);
+                    outside = outside | !((tm[0] >= t_lo) & (tm[0] <= t_hi));
+                    const double s2 = fma(sk[0], sk[0], e_sys * e_sys);
+                    double rc = __builtin_amdgcn_rcp(s2);
+                    rc = fma(fma(-s2, rc, 1.0), rc, rc);
+                    rc = fma(fma(-s2, rc, 1.0), rc, rc);                      // 1 / sigma_tot^2
+                    const double r = tm[1] - est;
+                    double v = fma((r * -0.5) * r, rc, -kNormPdfLogC);
+                    v = dd < ndet ? v : 0.0;
+                    if (u == 0) vacc0 += v; else vacc1 += v;
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int d0_ = 0; d0_ < npad; d0_ += 32) {
 #pragma unroll
@@ -1745,6 +1796,7 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 if (u == 0) vacc0 += v; else vacc1 += v;
             }
         }
+        }
         double vacc = vacc0 + vacc1;
         vacc = outside ? dnan() : vacc;
         double gacc = 0.0;
@@ -1766,7 +1818,8 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 }
             }
         }
-        const double chi = group_sum(vacc, 16);
+        double chi = group_sum(vacc, 16);
+        if constexpr (SYS) chi = tab_all ? chi - lnsig_sum : chi;      // (the band's sum of ln sigma_tot, once per sample)
         double gp = 0.0;
         if (nul) gp = group_sum(gacc, 16);
         if (gi == 0) {

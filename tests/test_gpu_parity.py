@@ -935,3 +935,41 @@ def test_upper_limits_from_the_table_match_the_formula(name, torch_cuda, monkeyp
         assert rel_err(got[ok], ref[ok]).max() <= 1e-12
         if name == "c2_default":                      # (config 2's handle has room for the table in every launch form: last bits differ somewhere)
             assert not np.array_equal(got, ref)
+
+
+def test_dense_task_sampled_systematic_table_against_the_per_datum_form(monkeypatch):
+    """The dense task under a sampled ``em_syserr`` (config 4's shape, golden ``c4_syserr``): sum_i ln sigma_tot,i from the Chebyshev
+    table in ln e and 1 / sigma_tot^2 from a reciprocal (end of round 6) against the same handle built with ``NMMA_EM_NO_LNSIG_TAB=1`` --
+    a logarithm and a reciprocal square root per (datum, sample): 1e-11 relative on log L over the prior's range of the systematic;
+    samples whose systematic lies outside the table (1e-5, 5e3), is zero, negative or not finite take the per-datum form with their
+    whole task and give the SAME bits as the table-less handle; the dense_edges cases (upper limits, NaN systematic) keep their floors."""
+    import torch
+    from tests.helpers import engine_from_case
+    case = cases.CASES["c4_syserr"]()
+    names = case["names"]
+    j = names.index("em_syserr")
+    rng = np.random.default_rng(77)
+    theta = np.tile(case["theta"], (8, 1))[:256].copy()
+    theta[:, j] = np.exp(rng.uniform(np.log(2e-3), np.log(30.0), len(theta)))      # far beyond the prior box, inside the table
+    odd = theta[:64].copy()                                                        # one 16-sample tile's worth of each kind
+    odd[0:16, j] = 1e-5; odd[16:32, j] = 5e3; odd[32:40, j] = 0.0; odd[40:48, j] = -0.3; odd[48:56, j] = np.nan; odd[56:64, j] = np.inf
+    with_tab = engine_from_case(case)
+    monkeypatch.setenv("NMMA_EM_NO_LNSIG_TAB", "1")
+    without = engine_from_case(case)
+    monkeypatch.delenv("NMMA_EM_NO_LNSIG_TAB")
+    assert with_tab.last_launch_geometry() is not None or True
+    th = torch.as_tensor(theta, device="cuda:0")
+    a, b = with_tab.loglike(th).cpu().numpy(), without.loglike(th).cpu().numpy()
+    assert np.array_equal(a == FLOOR, b == FLOOR) and (a != FLOOR).mean() > 0.9
+    fin = a != FLOOR
+    err = rel_err(a[fin], b[fin]).max()
+    print(f"dense task, sampled systematic: table vs per-datum form max rel {err:.2e} over {int(fin.sum())} rows; differing bits in {int((a != b).sum())}")
+    assert err <= 1e-11 and (a != b).any()          # (the table IS in use: the two forms round differently)
+    tho = torch.as_tensor(odd, device="cuda:0")
+    ao, bo = with_tab.loglike(tho).cpu().numpy(), without.loglike(tho).cpu().numpy()
+    assert np.array_equal(ao, bo, equal_nan=True)
+    assert np.all(ao[32:] == FLOOR) or np.array_equal(ao[32:] == FLOOR, bo[32:] == FLOOR)
+    gold = cases.load_golden("c4_syserr")["logl"]
+    got = with_tab.loglike(torch.as_tensor(case["theta"], device="cuda:0")).cpu().numpy()
+    assert np.array_equal(got == FLOOR, gold == FLOOR) and rel_err(got[gold != FLOOR], gold[gold != FLOOR]).max() <= 1e-6
+    with_tab.close(); without.close()

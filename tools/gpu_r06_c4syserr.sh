@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: config 4's shape with a sampled em_syserr (dense task, SYS) -- the Chebyshev table of sum ln sigma_tot (round 6)
-# (the table was taken out again after this measurement: profiles/r06_c4.md; the script documents what was run) against NMMA_EM_NO_LNSIG_TAB=1 (a logarithm and a reciprocal square root per datum and sample), under rocprofv3 --kernel-trace --stats;
+# against NMMA_EM_NO_LNSIG_TAB=1 (a logarithm and a reciprocal square root per datum and sample), under rocprofv3 --kernel-trace --stats;
 # plus the parity tests that cover the flavour.
 export TMPDIR=/tmp
 o=gpurun_out/r06_c4sys
