@@ -1945,7 +1945,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                 // (round 6: no task is two-stage any more -- where sample_times differ from the SVD grid the handle's table holds rows ON
                 //  the sample grid with the stage-1 lerp folded in, nmma_em_create -- so every lean flavour reconstructs two rows per
                 //  datum; the TWO = true forms of the lambdas are no longer instantiated: half the inlined task variants per kernel)
+                #ifdef NMMA_DBG_NO_SYS_VARIANTS      // measurement build: the constant-systematics variants alone in the kernel
+                constexpr bool sysp = false;
+#else
                 const bool sysp = LEANX && (itab[k].kind == NMMA_SYS_PARAM || ((FASTM == 5 || COMB) && itab[k].kind == NMMA_SYS_NODES));
+#endif
                 auto run = [&](auto tb) {
                     using T = std::true_type; using F = std::false_type;
                     if constexpr (FASTM == 4 || FASTM == 8) {          // unequally spaced sample_times: bracket by lookup + bisection
