@@ -24,7 +24,11 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
     constexpr bool FAST = FASTM != 0, EXT = FASTM == 2;
     // FASTM == 3: the lean task with its extras compiled in (filters with more than 32 points, a sampled em_syserr); the
     // plain lean kernel (FASTM == 1, BASELINE config 2 and the CLI grid) does not carry them: they cost it 2 % when present
+#ifdef NMMA_DBG_NO_SPLIT      // measurement build: the kernel without the band-split forms of its epilogue (what their code costs the full-batch launch)
+    constexpr bool SPLITTABLE = false;
+#else
     constexpr bool SPLITTABLE = R == 1 && FASTM != 0 && FASTM != 2 && FASTM != 7 && FASTM != 8;    // small batches: one band per workgroup (launch_logl_one)
+#endif
     constexpr bool DENSE = FASTM == 6 || FASTM == 9;       // lean task that reconstructs ALL nodes of (item, 16 samples) on the fp64 matrix cores (many points per filter)
     // FASTM == 9: the dense task's ONE variant BASELINE config 4 takes -- constant systematics, equally spaced sample_times -- alone in its
     // kernel: with the other three variants (sampled systematic, unequally spaced grid) inlined next to it, code it never runs cost that
