@@ -1959,9 +1959,13 @@ __global__ __launch_bounds__(logl_threads(NMW, NVW), (NMW + NVW) / 4) void em_lo
                     if constexpr (FASTM == 4 || FASTM == 8) {          // unequally spaced sample_times: bracket by lookup + bisection
                         if (sysp) lean_task(tb, F{}, T{}, T{}, k, t); else lean_task(tb, F{}, F{}, T{}, k, t);
                     } else if constexpr (FASTM == 5) {
+#ifdef NMMA_DBG_GEN_PLAIN_ONLY      // measurement build: the general lean task's constant-systematics, equally-spaced variants alone in the kernel
+                        lean_gen_task(tb, F{}, F{}, F{}, k, t);
+#else
                         if (!P.st_uniform) { if (sysp) lean_gen_task(tb, F{}, T{}, T{}, k, t); else lean_gen_task(tb, F{}, F{}, T{}, k, t); }
                         else if (sysp) lean_gen_task(tb, F{}, T{}, F{}, k, t);
                         else lean_gen_task(tb, F{}, F{}, F{}, k, t);
+#endif
                     } else if constexpr (FASTM == 3 || FASTM == 7) {
                         if (sysp) lean_task(tb, F{}, T{}, F{}, k, t); else lean_task(tb, F{}, F{}, F{}, k, t);
                     } else if constexpr (FASTM == 6) {   // dense: more than 16 points in every filter (host); any sample grid -- the
